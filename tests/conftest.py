@@ -1,0 +1,112 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    with np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False) as z:
+        return {k: z[k] for k in z.files}
+
+
+def rel_err(a, b):
+    """||a-b|| / max(||b||, tiny) - the per-tensor relative error every parity test uses."""
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def _is_grad_key(k):
+    k = k.split("/")
+    return any(t in ("gnorm", "gsamp", "gproj", "grad", "dx") for t in k)
+
+
+def check_model_result(res, gold, tol_fwd, tol_grad, dev="ref32_err", factor=4.0, samp_factor=10.0):
+    """Compare a summarized protocol result with the golden file (values = fp64 truth).
+
+    Allowed error per key = max(spec tolerance, factor x the REFERENCE'S OWN deviation from the
+    fp64 truth in the matching precision, recorded by make_golden as `<dev>/<key>`): the
+    gradients of these BatchNorm-heavy nets are ill-conditioned (the reference's fp32 path is
+    itself 1.5e-2 off on MobileNetLarge3D's first layers), so a flat tolerance would either
+    fail the reference against itself or check nothing.  Gradients are checked through their
+    norm and N_PROJ full-tensor random-sign projections (`gproj`); the N_SAMPLE raw elements
+    (`gsamp`) get `samp_factor` x more room (8 values carry more relative noise than the norm).
+    Returns a list of (key, err, allowed) for violations."""
+    gmax = max([float(gold[k][0]) for k in gold if k.startswith("gnorm/")] + [0.0])
+    bad, worst = [], ("", 0.0, 0.0)
+    for k, v in res.items():
+        if k not in gold:
+            bad.append((k, float("nan"), 0.0))
+            continue
+        g = np.asarray(gold[k], np.float64)
+        v = np.asarray(v, np.float64)
+        assert g.shape == v.shape, (k, g.shape, v.shape)
+        kind, _, name = k.partition("/")
+        if kind in ("gnorm", "gsamp", "gproj"):
+            d = gold.get(dev + "/grad/" + name)
+            allowed = max(tol_grad, factor * float(d[0])) if d is not None else tol_grad
+            gn = float(gold["gnorm/" + name][0])
+            if gn < 1e-6 * gmax:           # structurally zero (e.g. conv bias feeding train-mode BN)
+                den, allowed = gmax, tol_grad
+            else:
+                if kind == "gsamp":        # 8 raw elements: measured against their own norm
+                    den = float(np.linalg.norm(g))
+                    allowed *= samp_factor
+                else:                      # a +-1 projection of a tensor of norm gn has size ~gn
+                    den = gn * (1.0 if kind == "gnorm" else np.sqrt(len(g)))
+            err = float(np.linalg.norm(v - g)) / max(den, 1e-300)
+        else:
+            d = gold.get(dev + "/" + k)
+            allowed = max(tol_fwd, factor * float(d[0])) if d is not None else tol_fwd
+            err = float(np.linalg.norm(v - g)) / max(float(np.linalg.norm(g)), 1e-300)
+        if not np.isfinite(err) or err > allowed:
+            bad.append((k, err, allowed))
+        if np.isfinite(err) and allowed > 0 and err / allowed > worst[1] / max(worst[2], 1e-300):
+            worst = (k, err, allowed)
+    return bad, worst
+
+
+def compare_full(res, gold, prefix, tol_fwd, tol_grad, dev="ref32_err", factor=4.0):
+    """Full-tensor comparison for the tiny-block fixtures (`<case>/<key>` arrays)."""
+    gkeys = [k for k in res if k.startswith("grad/") or k == "dx"]
+    gmax = max([float(np.linalg.norm(gold[prefix + k])) for k in gkeys] + [0.0])
+    bad, worst = [], ("", 0.0, 0.0)
+    for k, v in res.items():
+        g = np.asarray(gold[prefix + k], np.float64)
+        v = np.asarray(v, np.float64)
+        assert g.shape == v.shape, (k, g.shape, v.shape)
+        isg = k in gkeys
+        d = gold.get(prefix + dev + "/" + k)
+        base = tol_grad if isg else tol_fwd
+        allowed = max(base, factor * float(d[0])) if d is not None else base
+        den = float(np.linalg.norm(g))
+        if isg and den < 1e-6 * gmax:
+            den, allowed = gmax, base
+        err = float(np.linalg.norm(v - g)) / max(den, 1e-300)
+        if not np.isfinite(err) or err > allowed:
+            bad.append((k, err, allowed))
+        if np.isfinite(err) and err / allowed > worst[1] / max(worst[2], 1e-300):
+            worst = (k, err, allowed)
+    return bad, worst
+
+
+@pytest.fixture(scope="session")
+def golden():
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            cache[name] = load_golden(name)
+        return cache[name]
+    return get
