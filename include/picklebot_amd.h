@@ -1,0 +1,185 @@
+/*
+ * picklebot_amd - MI355X (gfx950) kernels for Picklebot's video-model forward/backward hot path.
+ *
+ * C ABI (plain pointers + sizes, no torch types).  Every entry point:
+ *   - takes raw DEVICE pointers, explicit sizes, a dtype enum for activations, the device
+ *     ordinal and the hipStream_t (as void*) to launch on;
+ *   - returns 0 on success, non-zero on failure (see pb_last_error(), thread-local);
+ *   - never allocates, never synchronises the device, never throws; re-entrant (backward is
+ *     driven from PyTorch's autograd thread, SURVEY.md 8b "Threading").
+ *
+ * Activations are NDHWC ("channels_last_3d"): a tensor of logical shape (N,C,T,H,W) is the
+ * row-major matrix [M = N*T*H*W rows][C channels].  That is the physical layout the
+ * reference's training loop already produces (train.py:106).  Parameters stay fp32 in the
+ * reference's own shapes (state_dict compatible); kernels convert on load.
+ *
+ * What each entry replaces in the reference (which has no native code: every op below is a
+ * stock torch op there) is cited per function as /root/reference file:line.
+ */
+#ifndef PICKLEBOT_AMD_H
+#define PICKLEBOT_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { PB_F32 = 0, PB_BF16 = 1 } pb_dtype;
+
+/* Activations used on the path: mobilenet.py:18,20,143,147-175 (ReLU, Hardsigmoid, Hardswish,
+ * LeakyReLU), mobilevit.py:16,23,34 (SiLU). */
+typedef enum {
+  PB_ACT_NONE = 0, PB_ACT_RELU = 1, PB_ACT_LEAKY_RELU = 2, PB_ACT_HSWISH = 3,
+  PB_ACT_HSIGMOID = 4, PB_ACT_SILU = 5
+} pb_act;
+
+#define PB_ABI_VERSION 1
+int pb_abi_version(void);
+/* Last error message of the calling thread ("" if none). */
+const char* pb_last_error(void);
+
+/* ---------------------------------------------------------------- pointwise 1x1x1 convolution
+ * Replaces nn.Conv3d(Cin,Cout,1) forward / backward: mobilenet.py:64,79,141(head),179,187,189;
+ * movinet.py:47,64,140; mobilevit.py:14; and every nn.Linear on tokens (mobilevit.py:32-36,58-61).
+ *
+ * GEMM  Y[M,N] = P(X)[M,K] * Wl[N,K]^T  with fused prologue/epilogue:
+ *   P(x)[m,k] = act_in(x*in_scale[k] + in_shift[k]) * row_scale[m / rows_per_group, k]
+ *   y[m,n]    = act_out(acc*out_scale[n] + out_shift[n])           (bias = out_shift)
+ *   stats[0..N) += sum_m y, stats[N..2N) += sum_m y^2  (of the stored, rounded y; atomics)
+ * Wl is fp32: element (n,k) at w[n*ldw + k], or at w[k*ldw + n] when w_transposed != 0 (this is
+ * how backward-data reuses the entry: dX = dY * W is the same GEMM with W read transposed).
+ * Any of in_scale/in_shift/row_scale/out_scale/out_shift/stats may be NULL.
+ */
+int pb_pwconv_fwd(const void* x, const float* w, void* y, int64_t M, int K, int N, int ldw,
+                  int w_transposed, pb_dtype dtype,
+                  const float* in_scale, const float* in_shift, pb_act in_act, float in_slope,
+                  const float* row_scale, int64_t rows_per_group,
+                  const float* out_scale, const float* out_shift, pb_act out_act, float out_slope,
+                  float* stats, int device, void* stream);
+
+/* Weight gradient  dW[N,K] += sum_m dY[m,n] * P(X)[m,k]   (same prologue P as above; fp32
+ * atomics into dw, which the caller zero-fills or holds a running gradient).
+ * Replaces the weight half of Conv3d/Linear backward for the sites listed above. */
+int pb_pwconv_bwd_weight(const void* dy, const void* x, float* dw, int64_t M, int K, int N, pb_dtype dtype,
+                         const float* in_scale, const float* in_shift, pb_act in_act, float in_slope,
+                         const float* row_scale, int64_t rows_per_group, int device, void* stream);
+
+/* ---------------------------------------------------------------- depthwise 3-D convolution
+ * Replaces nn.Conv3d(C,C,(kt,kh,kw),groups=C,bias=False) forward/backward:
+ * mobilenet.py:67-75 (kernel (1,k,k), scalar stride AND padding on T,H,W: T_out grows),
+ * movinet.py:52-61 ((kt,k,k), stride (1,s,s), symmetric padding), movinet.py:31 (CausalConv3d:
+ * pad_t_front = kt-1, pad_t_back = 0).
+ * x [N,Ti,Hi,Wi,C] -> y [N,To,Ho,Wo,C]; w fp32 in the reference's layout [C][kt*kh*kw].
+ * Temporal padding is asymmetric-capable: frame index t_in = t_out*st - pt_front + a.
+ * pool (optional) [N][C] fp32 += sum over (To,Ho,Wo) of y  (squeeze for SEBlock3D, mobilenet.py:16).
+ */
+typedef struct {
+  int N, C;
+  int Ti, Hi, Wi;
+  int To, Ho, Wo;
+  int kt, kh, kw;
+  int st, sh, sw;
+  int pt, ph, pw;      /* front paddings (symmetric convs: also the back padding) */
+} pb_dwconv_shape;
+
+int pb_dwconv3d_fwd(const void* x, const float* w, void* y, const pb_dwconv_shape* s, pb_dtype dtype,
+                    float* pool, int device, void* stream);
+
+/* Backward.  The incoming gradient may carry the fused squeeze-excite backward:
+ *   g[n,t,h,w,c] = dy[n,t,h,w,c] * g_scale[n,c] + g_shift[n,c]   (either may be NULL)
+ * dx = conv_transpose(g, w);  dw[C][kt*kh*kw] += sum g * x  (fp32 atomics). */
+int pb_dwconv3d_bwd_data(const void* dy, const float* w, void* dx, const pb_dwconv_shape* s, pb_dtype dtype,
+                         const float* g_scale, const float* g_shift, int device, void* stream);
+int pb_dwconv3d_bwd_weight(const void* dy, const void* x, float* dw, const pb_dwconv_shape* s, pb_dtype dtype,
+                           const float* g_scale, const float* g_shift, int device, void* stream);
+
+/* ---------------------------------------------------------------- dense conv with tiny Cin (stems)
+ * Replaces nn.Conv3d(3,Cout,k,stride,pad) on the raw clip: mobilenet.py:141,221 (3x3x3 s2 p1 +bias),
+ * movinet.py:92 ((1,3,3) s(1,2,2) p(0,1,1)), mobilevit.py:165 (3x3x3 s2 p1, no bias).
+ * The input is addressed through element strides, so both the NDHWC view train.py:106 produces and
+ * a plain contiguous NCDHW tensor are read in place.  x_dtype: PB_F32 / PB_BF16 or 2 = uint8 (the
+ * raw dataloader clip, scaled by x_scale = 1/255 on load: SURVEY.md 8f rank 2).
+ * y [N,To,Ho,Wo,Cout] in `dtype`; Cout <= 32; stats as in pb_pwconv_fwd. */
+typedef struct {
+  int N, Cin, Cout;
+  int Ti, Hi, Wi;
+  int To, Ho, Wo;
+  int kt, kh, kw;
+  int st, sh, sw;
+  int pt, ph, pw;
+  int64_t xs_n, xs_c, xs_t, xs_h, xs_w;   /* input element strides */
+} pb_stem_shape;
+
+int pb_stem_conv3d_fwd(const void* x, int x_dtype, float x_scale, const float* w, const float* bias, void* y,
+                       const pb_stem_shape* s, pb_dtype dtype, float* stats, int device, void* stream);
+/* dw[Cout][Cin][kt][kh][kw] += ..., dbias[Cout] += sum dy (dbias may be NULL). */
+int pb_stem_conv3d_bwd_weight(const void* dy, const void* x, int x_dtype, float x_scale, float* dw, float* dbias,
+                              const pb_stem_shape* s, pb_dtype dtype, int device, void* stream);
+
+/* ---------------------------------------------------------------- per-channel statistics / norm / activation
+ * Replace nn.BatchNorm3d (+ the activation and Dropout3d after it): mobilenet.py:80-82,90-92,142-143;
+ * movinet.py:65-66,75-76,93-94,141-143; mobilevit.py:15-16,22-23.
+ */
+/* stats[0..C) += sum_m x, stats[C..2C) += sum_m x^2 */
+int pb_chan_stats(const void* x, int64_t M, int C, pb_dtype dtype, float* stats, int device, void* stream);
+
+/* Training: mean/var from stats (count = M), running stats updated in place (unbiased var,
+ * `momentum`), or evaluation (use_running != 0): from running_mean / running_var.
+ * Outputs scale = gamma*rstd, shift = beta - mean*scale, plus mean and rstd for backward.
+ * gamma/beta NULL = affine-free BatchNorm (mobilevit.py:15). */
+int pb_bn_finalize(const float* stats, double count, const float* gamma, const float* beta, float eps,
+                   float momentum, float* running_mean, float* running_var, int use_running,
+                   float* scale, float* shift, float* mean, float* rstd, int C, int device, void* stream);
+
+/* y = act(x*scale[c] + shift[c]) * row_scale[g, c] + row_shift[g, c], g = m / rows_per_group;
+ * optional stats of y. */
+int pb_affine_act_fwd(const void* x, void* y, int64_t M, int C, pb_dtype dtype, const float* scale,
+                      const float* shift, pb_act act, float slope, const float* row_scale,
+                      const float* row_shift, int64_t rows_per_group, float* stats, int device, void* stream);
+
+/* g = dy * row_scale * act'(z*scale+shift); sums[0..C) += sum g, sums[C..2C) += sum g*(z-mean)*rstd.
+ * dy_rows_per_group > 0: dy is [M/dy_rows_per_group][C] broadcast over each row group (the
+ * backward of a global average pool, with dy pre-divided by the caller or via dy_mul).
+ * g_out may be NULL (reduction only). */
+int pb_act_bwd_reduce(const void* dy, const void* z, void* g_out, int64_t M, int C, pb_dtype dtype,
+                      const float* scale, const float* shift, pb_act act, float slope,
+                      const float* row_scale, int64_t rows_per_group, int64_t dy_rows_per_group, float dy_mul,
+                      const float* mean, const float* rstd, float* sums, int device, void* stream);
+
+/* BatchNorm backward coefficients: dz = A*g + B*z + Cc;  dgamma = sum g*xhat, dbeta = sum g. */
+int pb_bn_bwd_finalize(const float* sums, double count, const float* gamma, const float* mean, const float* rstd,
+                       int training, float* coefA, float* coefB, float* coefC, float* dgamma, float* dbeta,
+                       int C, int device, void* stream);
+
+/* out = A[c]*g + B[c]*z + Cc[c]   (B, Cc may be NULL) */
+int pb_affine2(const void* g, const void* z, void* out, int64_t M, int C, pb_dtype dtype, const float* A,
+               const float* B, const float* Cc, int device, void* stream);
+
+/* ---------------------------------------------------------------- squeeze-excite / pooling
+ * SEBlock3D (mobilenet.py:11-26) and the classifier's AdaptiveAvgPool3d (mobilenet.py:186,252;
+ * movinet.py:147; mobilevit.py:191). */
+/* out[g][c] += sum over the group's rows of a (b == NULL) or of a*b. */
+int pb_rowgroup_reduce(const void* a, const void* b, float* out, int64_t G, int64_t rows_per_group, int C,
+                       pb_dtype dtype, int device, void* stream);
+
+/* scale[g][c] = hardsigmoid(W2 relu(W1 (pool[g]/count) + b1) + b2); saves hidden (post-relu) [G][Cm].
+ * W1 [Cm][C], W2 [C][Cm] fp32 (the reference's Conv3d 1x1x1 weights flattened). */
+int pb_se_fc_fwd(const float* pool, float inv_count, const float* w1, const float* b1, const float* w2,
+                 const float* b2, float* scale, float* hidden, int G, int C, int Cm, int device, void* stream);
+
+/* Backward of the above.  dscale[g][c] = sum_rows dOut*x.  Produces g_shift[g][c] = dmean/count (the
+ * term the depthwise backward adds to every element) and accumulates dW1,db1,dW2,db2.
+ * work: fp32 scratch of G*(C+Cm) floats. */
+int pb_se_fc_bwd(const float* dscale, const float* pool, float inv_count, const float* scale, const float* hidden,
+                 const float* w1, const float* w2, float* g_shift, float* dw1, float* db1, float* dw2, float* db2,
+                 float* work, int G, int C, int Cm, int device, void* stream);
+
+/* ---------------------------------------------------------------- misc
+ * fp32 [R][C] -> [C][R] (depthwise weight [C][taps] -> [taps][C] staging). */
+int pb_transpose_f32(const float* in, float* out, int R, int C, int device, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PICKLEBOT_AMD_H */

@@ -1,0 +1,279 @@
+"""Per-kernel CPU restatement (TEST INFRASTRUCTURE ONLY - never imported by picklebot_amd).
+
+Function-for-function mirror of picklebot_amd/kernels.py in plain torch, fp32 arithmetic with
+the output rounded to the activation dtype exactly where the HIP kernel rounds.  Two uses:
+  * -m gpu tests compare every HIP kernel against its mirror on the same seeded inputs;
+  * CPU tests monkeypatch these into picklebot_amd.kernels to check the fused forward/backward
+    DATAFLOW (picklebot_amd/functional.py) against the oracle models' autograd without a GPU.
+Each mirror is itself pinned by tests/test_kernel_ref_cpu.py against torch.nn.functional ops
+(conv3d / batch_norm / ... i.e. the stock ops the reference calls).
+"""
+import torch
+import torch.nn.functional as F
+
+
+def _act(x, act, slope=0.0):
+    if act == "none":
+        return x
+    if act == "relu":
+        return torch.relu(x)
+    if act == "leaky_relu":
+        return torch.where(x > 0, x, x * slope)
+    if act == "hardswish":
+        return x * torch.clamp(x + 3, 0, 6) / 6
+    if act == "hardsigmoid":
+        return torch.clamp(x / 6 + 0.5, 0, 1)
+    if act == "silu":
+        return x * torch.sigmoid(x)
+    raise ValueError(act)
+
+
+def _act_grad(x, act, slope=0.0):
+    one, zero = torch.ones_like(x), torch.zeros_like(x)
+    if act == "none":
+        return one
+    if act == "relu":
+        return torch.where(x > 0, one, zero)
+    if act == "leaky_relu":
+        return torch.where(x > 0, one, one * slope)
+    if act == "hardswish":
+        return torch.where(x < -3, zero, torch.where(x <= 3, x / 3 + 0.5, one))
+    if act == "hardsigmoid":
+        return torch.where((x > -3) & (x < 3), one / 6, zero)
+    if act == "silu":
+        s = torch.sigmoid(x)
+        return s * (1 + x * (1 - s))
+    raise ValueError(act)
+
+
+def _prologue(x, in_scale, in_shift, in_act, in_slope, row_scale, rows_per_group):
+    xf = x.float()
+    if in_scale is not None:
+        xf = xf * in_scale
+    if in_shift is not None:
+        xf = xf + in_shift
+    xf = _act(xf, in_act, in_slope)
+    if row_scale is not None:
+        xf = xf * row_scale.repeat_interleave(rows_per_group, 0)
+    return xf.to(x.dtype).float()      # the kernel rounds the staged operand to the activation dtype
+
+
+def pw_fwd(x, w, *, w_transposed=False, in_scale=None, in_shift=None, in_act="none", in_slope=0.0, row_scale=None,
+           rows_per_group=0, out_scale=None, out_shift=None, out_act="none", out_slope=0.0, stats=None):
+    xf = _prologue(x, in_scale, in_shift, in_act, in_slope, row_scale, rows_per_group)
+    wl = (w.t() if w_transposed else w).to(x.dtype).float()
+    acc = xf @ wl.t()
+    if out_scale is not None:
+        acc = acc * out_scale
+    if out_shift is not None:
+        acc = acc + out_shift
+    y = _act(acc, out_act, out_slope).to(x.dtype)
+    if stats is not None:
+        stats[0] += y.float().sum(0)
+        stats[1] += (y.float() ** 2).sum(0)
+    return y
+
+
+def pw_bwd_weight(dy, x, dw, *, in_scale=None, in_shift=None, in_act="none", in_slope=0.0, row_scale=None,
+                  rows_per_group=0):
+    xf = _prologue(x, in_scale, in_shift, in_act, in_slope, row_scale, rows_per_group)
+    dw += dy.float().t() @ xf
+    return dw
+
+
+def dw_out_shape(in_thw, kernel, stride, pad_front, pad_back=None):
+    pad_back = pad_front if pad_back is None else pad_back
+    return tuple((i + pf + pb - k) // s + 1 for i, k, s, pf, pb in zip(in_thw, kernel, stride, pad_front, pad_back))
+
+
+def _pad_ncdhw(x5, pad_front, pad_back):
+    """[N,T,H,W,C] -> padded NCDHW float."""
+    xn = x5.permute(0, 4, 1, 2, 3).float()
+    return F.pad(xn, (pad_front[2], pad_back[2], pad_front[1], pad_back[1], pad_front[0], pad_back[0]))
+
+
+def dw_fwd(x, w, kernel, stride, pad_front, pad_back=None, pool=None):
+    pad_back = pad_front if pad_back is None else pad_back
+    C = x.shape[4]
+    y = F.conv3d(_pad_ncdhw(x, pad_front, pad_back), w.view(C, 1, *kernel), stride=stride, groups=C)
+    y = y.permute(0, 2, 3, 4, 1).contiguous().to(x.dtype)
+    if pool is not None:
+        pool += y.float().sum((1, 2, 3))
+    return y
+
+
+def _g(dy, g_scale, g_shift):
+    g = dy.float()
+    if g_scale is not None:
+        g = g * g_scale[:, None, None, None, :]
+    if g_shift is not None:
+        g = g + g_shift[:, None, None, None, :]
+    return g
+
+
+@torch.enable_grad()
+def dw_bwd_data(dy, w, in_thw, kernel, stride, pad_front, g_scale=None, g_shift=None):
+    N, To, Ho, Wo, C = dy.shape
+    g = _g(dy, g_scale, g_shift).permute(0, 4, 1, 2, 3)
+    xin = torch.zeros((N, C) + tuple(in_thw), requires_grad=True)
+    pb = [(o - 1) * s + k - i - pf for o, s, k, i, pf in zip((To, Ho, Wo), stride, kernel, in_thw, pad_front)]
+    pb = [max(p, 0) for p in pb]
+    xp = F.pad(xin, (pad_front[2], pb[2], pad_front[1], pb[1], pad_front[0], pb[0]))
+    y = F.conv3d(xp, w.view(C, 1, *kernel), stride=stride, groups=C)[:, :, :To, :Ho, :Wo]
+    (dx,) = torch.autograd.grad(y, xin, g)
+    return dx.permute(0, 2, 3, 4, 1).contiguous().to(dy.dtype)
+
+
+@torch.enable_grad()
+def dw_bwd_weight(dy, x, dw, kernel, stride, pad_front, g_scale=None, g_shift=None):
+    N, To, Ho, Wo, C = dy.shape
+    g = _g(dy, g_scale, g_shift).permute(0, 4, 1, 2, 3)
+    wv = w_ = torch.zeros(C, 1, *kernel, requires_grad=True)
+    in_thw = tuple(x.shape[1:4])
+    pb = [max((o - 1) * s + k - i - pf, 0) for o, s, k, i, pf in zip((To, Ho, Wo), stride, kernel, in_thw, pad_front)]
+    xp = F.pad(x.permute(0, 4, 1, 2, 3).float(), (pad_front[2], pb[2], pad_front[1], pb[1], pad_front[0], pb[0]))
+    y = F.conv3d(xp, wv, stride=stride, groups=C)[:, :, :To, :Ho, :Wo]
+    (gw,) = torch.autograd.grad(y, w_, g)
+    dw += gw.view(C, -1)
+    return dw
+
+
+def stem_fwd(x, w, bias, kernel, stride, pad, out_dtype, x_scale=1.0, stats=None):
+    xf = x.float() * x_scale
+    y = F.conv3d(xf, w, bias, stride=stride, padding=pad).permute(0, 2, 3, 4, 1).contiguous().to(out_dtype)
+    if stats is not None:
+        yf = y.float().reshape(-1, y.shape[-1])
+        stats[0] += yf.sum(0)
+        stats[1] += (yf ** 2).sum(0)
+    return y
+
+
+@torch.enable_grad()
+def stem_bwd_weight(dy, x, dw, dbias, kernel, stride, pad, x_scale=1.0):
+    wv = torch.zeros_like(dw, requires_grad=True)
+    y = F.conv3d(x.float() * x_scale, wv, None, stride=stride, padding=pad)
+    (gw,) = torch.autograd.grad(y, wv, dy.float().permute(0, 4, 1, 2, 3))
+    dw += gw
+    if dbias is not None:
+        dbias += dy.float().sum((0, 1, 2, 3))
+    return dw
+
+
+def chan_stats(x, stats):
+    stats[0] += x.float().sum(0)
+    stats[1] += (x.float() ** 2).sum(0)
+    return stats
+
+
+def bn_finalize(stats, count, gamma, beta, eps, momentum, running_mean, running_var, use_running, C, device):
+    if use_running:
+        mean, var = running_mean.double(), running_var.double()
+    else:
+        mean = stats[0].double() / count
+        var = (stats[1].double() / count - mean * mean).clamp_min(0)
+        if running_mean is not None:
+            running_mean.copy_(((1 - momentum) * running_mean.double() + momentum * mean).float())
+        if running_var is not None:
+            unb = var * count / (count - 1) if count > 1 else var
+            running_var.copy_(((1 - momentum) * running_var.double() + momentum * unb).float())
+    rstd = 1.0 / torch.sqrt(var + eps)
+    g = gamma.double() if gamma is not None else torch.ones(C, dtype=torch.float64)
+    b = beta.double() if beta is not None else torch.zeros(C, dtype=torch.float64)
+    return (g * rstd).float(), (b - mean * g * rstd).float(), mean.float(), rstd.float()
+
+
+def affine_act_fwd(x, scale=None, shift=None, act="none", slope=0.0, row_scale=None, rows_per_group=0, stats=None,
+                   row_shift=None):
+    xf = x.float()
+    if scale is not None:
+        xf = xf * scale
+    if shift is not None:
+        xf = xf + shift
+    y = _act(xf, act, slope)
+    if row_scale is not None:
+        y = y * row_scale.repeat_interleave(rows_per_group, 0)
+    if row_shift is not None:
+        y = y + row_shift.repeat_interleave(rows_per_group, 0)
+    y = y.to(x.dtype)
+    if stats is not None:
+        stats[0] += y.float().sum(0)
+        stats[1] += (y.float() ** 2).sum(0)
+    return y
+
+
+def act_bwd_reduce(dy, z, *, scale=None, shift=None, act="none", slope=0.0, row_scale=None, rows_per_group=0,
+                   dy_rows_per_group=0, dy_mul=1.0, mean=None, rstd=None, sums=None, want_g=True):
+    zf = z.float()
+    pre = zf
+    if scale is not None:
+        pre = pre * scale
+    if shift is not None:
+        pre = pre + shift
+    d = dy.float()
+    if dy_rows_per_group > 0:
+        d = d.repeat_interleave(dy_rows_per_group, 0)
+    g = d * dy_mul
+    if row_scale is not None:
+        g = g * row_scale.repeat_interleave(rows_per_group, 0)
+    g = g * _act_grad(pre, act, slope)
+    gr = g.to(z.dtype).float() if want_g else g
+    if sums is not None:
+        xhat = zf
+        if mean is not None:
+            xhat = xhat - mean
+        if rstd is not None:
+            xhat = xhat * rstd
+        sums[0] += gr.sum(0)
+        sums[1] += (gr * xhat).sum(0)
+    return g.to(z.dtype) if want_g else None
+
+
+def bn_bwd_finalize(sums, count, gamma, mean, rstd, training, want_affine_grads):
+    C = mean.shape[0]
+    g = gamma.double() if gamma is not None else torch.ones(C, dtype=torch.float64)
+    r, mu = rstd.double(), mean.double()
+    sg, sgx = sums[0].double(), sums[1].double()
+    A = g * r
+    if training:
+        B = -g * r * r * (sgx / count)
+        Cc = -B * mu - g * r * (sg / count)
+    else:
+        B, Cc = torch.zeros_like(A), torch.zeros_like(A)
+    return (A.float(), B.float(), Cc.float(), sgx.float() if want_affine_grads else None,
+            sg.float() if want_affine_grads else None)
+
+
+def affine2(g, z, A, B=None, Cc=None):
+    out = g.float() * A
+    if B is not None:
+        out = out + z.float() * B
+    if Cc is not None:
+        out = out + Cc
+    return out.to(g.dtype)
+
+
+def rowgroup_reduce(a, b, G):
+    M, C = a.shape
+    v = a.float() if b is None else a.float() * b.float()
+    return v.view(G, M // G, C).sum(1)
+
+
+def se_fc_fwd(pool, inv_count, w1, b1, w2, b2):
+    mean = pool * inv_count
+    h = mean @ w1.t()
+    if b1 is not None:
+        h = h + b1
+    h = torch.relu(h)
+    pre = h @ w2.t()
+    if b2 is not None:
+        pre = pre + b2
+    return torch.clamp(pre / 6 + 0.5, 0, 1), h
+
+
+def se_fc_bwd(dscale, pool, inv_count, scale, hidden, w1, w2, want_bias=True):
+    dpre2 = torch.where((scale > 0) & (scale < 1), dscale / 6, torch.zeros_like(dscale))
+    dh = (dpre2 @ w2) * (hidden > 0).float()
+    g_shift = (dh @ w1) * inv_count
+    dw2 = dpre2.t() @ hidden
+    dw1 = dh.t() @ (pool * inv_count)
+    return g_shift, dw1, (dh.sum(0) if want_bias else None), dw2, (dpre2.sum(0) if want_bias else None)

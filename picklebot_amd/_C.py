@@ -1,0 +1,83 @@
+"""ctypes binding of the C-ABI library (include/picklebot_amd.h).
+
+The product path has NO fallback: if the HIP library is missing or a call fails, a RuntimeError
+is raised.  PyTorch only supplies device memory, the current HIP stream and the device ordinal.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpicklebot_amd.so")
+
+PB_F32, PB_BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_LEAKY_RELU, ACT_HSWISH, ACT_HSIGMOID, ACT_SILU = range(6)
+ABI_VERSION = 1
+
+
+class DwShape(Structure):
+    _fields_ = [(n, c_int) for n in ("N", "C", "Ti", "Hi", "Wi", "To", "Ho", "Wo", "kt", "kh", "kw",
+                                     "st", "sh", "sw", "pt", "ph", "pw")]
+
+
+class StemShape(Structure):
+    _fields_ = ([(n, c_int) for n in ("N", "Cin", "Cout", "Ti", "Hi", "Wi", "To", "Ho", "Wo", "kt", "kh", "kw",
+                                      "st", "sh", "sw", "pt", "ph", "pw")] +
+                [(n, c_int64) for n in ("xs_n", "xs_c", "xs_t", "xs_h", "xs_w")])
+
+
+P, F, I, L, D = c_void_p, c_float, c_int, c_int64, c_double
+
+# name -> argument types (every entry returns int status except the two noted)
+SIGNATURES = {
+    "pb_pwconv_fwd": [P, P, P, L, I, I, I, I, I, P, P, I, F, P, L, P, P, I, F, P, I, P],
+    "pb_pwconv_bwd_weight": [P, P, P, L, I, I, I, P, P, I, F, P, L, I, P],
+    "pb_dwconv3d_fwd": [P, P, P, POINTER(DwShape), I, P, I, P],
+    "pb_dwconv3d_bwd_data": [P, P, P, POINTER(DwShape), I, P, P, I, P],
+    "pb_dwconv3d_bwd_weight": [P, P, P, POINTER(DwShape), I, P, P, I, P],
+    "pb_stem_conv3d_fwd": [P, I, F, P, P, P, POINTER(StemShape), I, P, I, P],
+    "pb_stem_conv3d_bwd_weight": [P, P, I, F, P, P, POINTER(StemShape), I, I, P],
+    "pb_chan_stats": [P, L, I, I, P, I, P],
+    "pb_bn_finalize": [P, D, P, P, F, F, P, P, I, P, P, P, P, I, I, P],
+    "pb_affine_act_fwd": [P, P, L, I, I, P, P, I, F, P, P, L, P, I, P],
+    "pb_act_bwd_reduce": [P, P, P, L, I, I, P, P, I, F, P, L, L, F, P, P, P, I, P],
+    "pb_bn_bwd_finalize": [P, D, P, P, P, I, P, P, P, P, P, I, I, P],
+    "pb_affine2": [P, P, P, L, I, I, P, P, P, I, P],
+    "pb_rowgroup_reduce": [P, P, P, L, L, I, I, I, P],
+    "pb_se_fc_fwd": [P, F, P, P, P, P, P, P, I, I, I, I, P],
+    "pb_se_fc_bwd": [P, P, F, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P],
+    "pb_transpose_f32": [P, P, I, I, I, P],
+}
+
+_lib = None
+
+
+def load():
+    """Load (once) and type the library.  Raises RuntimeError when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"picklebot_amd: HIP library not built ({LIB_PATH}); run `python -m picklebot_amd.build` "
+            "(there is no CPU/eager fallback)")
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.pb_last_error.restype = c_char_p
+    lib.pb_last_error.argtypes = []
+    lib.pb_abi_version.restype = c_int
+    lib.pb_abi_version.argtypes = []
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = c_int
+        fn.argtypes = args
+    if lib.pb_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"picklebot_amd: ABI version mismatch ({lib.pb_abi_version()} != {ABI_VERSION}); rebuild")
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed (status {rc}): {lib.pb_last_error().decode()}")

@@ -1,0 +1,11 @@
+"""picklebot_amd - MI355X-native (gfx950) forward/backward hot path for Picklebot's video models.
+
+    from picklebot_amd import MobileNetLarge3D, MobileNetSmall3D, MoViNetA2, MobileViT
+
+mirrors the reference's `from mobilenet import ...` / `from movinet import ...` /
+`from mobilevit import ...` (train.py:19-21).  Importing the package does not need a GPU; running
+a module does (hand-written HIP kernels behind a C ABI, no eager fallback).
+"""
+from .mobilenet import Bottleneck3D, MobileNetLarge3D, MobileNetSmall3D, SEBlock3D  # noqa: F401
+
+__all__ = ["SEBlock3D", "Bottleneck3D", "MobileNetLarge3D", "MobileNetSmall3D"]

@@ -1,0 +1,639 @@
+// Depthwise 3-D convolution over NDHWC activations (HBM-bound stencil; no MFMA on purpose).
+//
+// Fast path ("strip" kernels) for Bottleneck3D's (1,k,k) filters, k in {3,5}, spatial stride
+// s in {1,2} (mobilenet.py:67-75).  A thread owns CH channels (16 B or 8 B per access) of one
+// output column and TH=4 vertically adjacent outputs, keeps the k*k*CH filter taps in registers
+// and walks the (TH-1)*s+k input rows once: each row it loads feeds up to k/s outputs from
+// registers.  Lanes run along (channel-vector, then x), so every access of a wave is one
+// contiguous span of the NDHWC row.  The temporal axis is only an index map (kernel extent 1):
+// frame t_in = t_out*t_mul + t_off; output frames that map outside the clip are the reference's
+// zero frames (stride/padding applied to T, SURVEY "temporal growth quirk") and are written as
+// zeros without reading anything.
+//   forward            : y = conv(x)                      [+ fused squeeze-excite pooling]
+//   backward-data, s=1 : the same kernel on dy with the filter flipped
+//   backward-weight    : same walk, taps accumulated in registers across a persistent loop
+// Generic path: any (kt,kh,kw)/stride/padding (MoViNet blocks, CausalConv3d, s=2 backward-data).
+#include "pb_common.h"
+
+namespace {
+
+template <typename T, int CH>
+__device__ __forceinline__ void load_ch(const T* p, float (&o)[CH]) {
+  if constexpr (sizeof(T) * CH == 16) {
+    Vec16<T> v = vec_load<T>(p);
+#pragma unroll
+    for (int i = 0; i < CH; ++i) o[i] = v.get(i);
+  } else if constexpr (sizeof(T) * CH == 8) {   // 4 x bf16
+    bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+#pragma unroll
+    for (int i = 0; i < CH; ++i) o[i] = (float)v[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < CH; ++i) o[i] = to_f32(p[i]);
+  }
+}
+template <typename T, int CH>
+__device__ __forceinline__ void store_ch(T* p, const float (&o)[CH]) {
+  if constexpr (sizeof(T) * CH == 16) {
+    Vec16<T> v;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) v.set(i, o[i]);
+    vec_store<T>(p, v);
+  } else if constexpr (sizeof(T) * CH == 8) {
+    bf16x4 v;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) v[i] = (bf16_t)o[i];
+    *reinterpret_cast<bf16x4*>(p) = v;
+  } else {
+#pragma unroll
+    for (int i = 0; i < CH; ++i) p[i] = from_f32<T>(o[i]);
+  }
+}
+
+struct StripArgs {
+  const void* src;     // [N, Tsrc, Hs, Ws, C]
+  const float* w;      // [C][K*K]
+  void* dst;           // [N, Tdst, Hd, Wd, C]
+  const void* x;       // backward-weight: the forward input
+  float* dw;           // backward-weight: [C][K*K]
+  int N, C, CV, CVB, P;
+  int Tsrc, Hs, Ws;
+  int Tdst, Hd, Wd;
+  int pad;             // spatial padding seen from dst: hs = hd*S - pad + kh
+  int t_mul, t_off;    // tsrc = tdst*t_mul + t_off
+  int flip;
+  const float* g_scale;   // optional [N][C]: src value = v*g_scale + g_shift (valid positions only)
+  const float* g_shift;
+  float* pool;            // optional [N][C] += sum of outputs
+  int HB;                 // ceil(Hd / TH)
+  int64_t items;          // backward-weight: N*Tdst*ceil(HB*Wd/P)
+  int xblocks;            // ceil(HB*Wd / P)
+};
+
+constexpr int TH = 4;
+
+template <typename T, int K, int S, int CH>
+__global__ __launch_bounds__(256) void dw_strip_fwd_kernel(StripArgs a) {
+  __shared__ __attribute__((aligned(16))) float wl[K * K * 32 * CH];   // [tap][CVB*CH] filter taps of this channel chunk
+  __shared__ float red[32 * 8];
+  const int tid = threadIdx.x;
+  const int cvl = tid % a.CVB, p = tid / a.CVB;
+  const int cv = blockIdx.y * a.CVB + cvl;
+  const bool lane_ok = p < a.P && cv < a.CV;
+  const int z = blockIdx.z;
+  const int n = z / a.Tdst, td = z - n * a.Tdst;
+  const int ts = td * a.t_mul + a.t_off;
+  const bool frame_ok = ts >= 0 && ts < a.Tsrc;
+  const int c0 = cv * CH;
+  const int CW = a.CVB * CH;                 // channels of this chunk
+  const T* src = (const T*)a.src;
+  T* dst = (T*)a.dst;
+  if (frame_ok) {
+    // the chunk's taps are contiguous in the [C][K*K] filter: coalesced read, transposed to LDS
+    const int cbase = blockIdx.y * CW;
+    for (int i = tid; i < CW * K * K; i += 256) {
+      const int cl = i / (K * K), tap = i - cl * (K * K);
+      const int kh = tap / K, kw = tap - kh * K;
+      const int t2 = a.flip ? (K - 1 - kh) * K + (K - 1 - kw) : tap;
+      wl[t2 * CW + cl] = (cbase + cl < a.C) ? a.w[(int64_t)(cbase + cl) * (K * K) + tap] : 0.f;
+    }
+  }
+  if (tid < 256) red[tid] = 0.f;
+  __syncthreads();
+
+  float gs[CH], gh[CH], psum[CH];
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    gs[i] = (a.g_scale && lane_ok) ? a.g_scale[(int64_t)n * a.C + c0 + i] : 1.f;
+    gh[i] = (a.g_shift && lane_ok) ? a.g_shift[(int64_t)n * a.C + c0 + i] : 0.f;
+    psum[i] = 0.f;
+  }
+  const bool has_g = a.g_scale || a.g_shift;
+  const T* fbase = src + ((int64_t)n * a.Tsrc + (frame_ok ? ts : 0)) * a.Hs * a.Ws * a.C + c0;
+
+  for (int xb = blockIdx.x; xb < a.xblocks; xb += gridDim.x) {
+    const int pix = xb * a.P + p;
+    const bool active = lane_ok && pix < a.HB * a.Wd;
+    const int hb = pix / a.Wd, wd = pix - hb * a.Wd;
+    const int hd0 = hb * TH;
+    float acc[TH][CH];
+#pragma unroll
+    for (int j = 0; j < TH; ++j)
+#pragma unroll
+      for (int i = 0; i < CH; ++i) acc[j][i] = 0.f;
+
+    if (active && frame_ok) {
+      constexpr int RH = (TH - 1) * S + K;
+#pragma unroll
+      for (int r = 0; r < RH; ++r) {
+        const int hs = hd0 * S - a.pad + r;
+        if (hs < 0 || hs >= a.Hs) continue;
+        float in[K][CH];
+#pragma unroll
+        for (int kw = 0; kw < K; ++kw) {
+          const int ws = wd * S - a.pad + kw;
+          if (ws >= 0 && ws < a.Ws) {
+            load_ch<T, CH>(fbase + ((int64_t)hs * a.Ws + ws) * a.C, in[kw]);
+            if (has_g) {
+#pragma unroll
+              for (int i = 0; i < CH; ++i) in[kw][i] = in[kw][i] * gs[i] + gh[i];
+            }
+          } else {
+#pragma unroll
+            for (int i = 0; i < CH; ++i) in[kw][i] = 0.f;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < TH; ++j) {
+          const int kh = r - j * S;            // compile-time after unrolling
+          if (kh >= 0 && kh < K) {
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw) {
+              float wv[CH];
+#pragma unroll
+              for (int q = 0; q < CH / 4; ++q) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(&wl[(kh * K + kw) * CW + cvl * CH + 4 * q]);
+                wv[4 * q] = t[0]; wv[4 * q + 1] = t[1]; wv[4 * q + 2] = t[2]; wv[4 * q + 3] = t[3];
+              }
+#pragma unroll
+              for (int i = 0; i < CH; ++i) acc[j][i] += in[kw][i] * wv[i];
+            }
+          }
+        }
+      }
+    }
+    if (active) {
+#pragma unroll
+      for (int j = 0; j < TH; ++j) {
+        const int hd = hd0 + j;
+        if (hd < a.Hd) {
+          T* o = dst + (((int64_t)z * a.Hd + hd) * a.Wd + wd) * a.C + c0;
+          store_ch<T, CH>(o, acc[j]);
+          if (a.pool) {
+#pragma unroll
+            for (int i = 0; i < CH; ++i) psum[i] += to_f32(from_f32<T>(acc[j][i]));
+          }
+        }
+      }
+    }
+  }
+  if (a.pool && frame_ok) {
+    if (lane_ok) {
+#pragma unroll
+      for (int i = 0; i < CH; ++i) atomicAdd(&red[cvl * CH + i], psum[i]);
+    }
+    __syncthreads();
+    if (tid < CW) {
+      const int c = blockIdx.y * CW + tid;
+      if (c < a.C && red[tid] != 0.f) atomicAdd(a.pool + (int64_t)n * a.C + c, red[tid]);
+    }
+  }
+}
+
+// Weight gradient for the strip family: dst-shaped tensor = dy (gradient of the conv output),
+// src-shaped tensor = x (conv input).  dw[c][kh][kw] += sum dy[hd][wd] * x[hd*S-pad+kh][wd*S-pad+kw].
+template <typename T, int K, int S, int CH>
+__global__ __launch_bounds__(256) void dw_strip_wgrad_kernel(StripArgs a) {
+  __shared__ float red[K * K * 32 * CH];
+  const int tid = threadIdx.x;
+  const int cvl = tid % a.CVB, p = tid / a.CVB;
+  const int cv = blockIdx.y * a.CVB + cvl;
+  const bool lane_ok = p < a.P && cv < a.CV;
+  const int c0 = cv * CH;
+  const T* dy = (const T*)a.dst;
+  const T* x = (const T*)a.x;
+  for (int i = tid; i < K * K * a.CVB * CH; i += 256) red[i] = 0.f;
+  __syncthreads();
+
+  float acc[K][K][CH];
+#pragma unroll
+  for (int kh = 0; kh < K; ++kh)
+#pragma unroll
+    for (int kw = 0; kw < K; ++kw)
+#pragma unroll
+      for (int i = 0; i < CH; ++i) acc[kh][kw][i] = 0.f;
+  const bool has_g = a.g_scale || a.g_shift;
+
+  for (int64_t it = blockIdx.x; it < a.items; it += gridDim.x) {
+    const int z = (int)(it / a.xblocks);
+    const int xb = (int)(it - (int64_t)z * a.xblocks);
+    const int n = z / a.Tdst, td = z - n * a.Tdst;
+    const int ts = td * a.t_mul + a.t_off;
+    if (ts < 0 || ts >= a.Tsrc) continue;        // zero frame: no dependence on x
+    const int pix = xb * a.P + p;
+    if (!lane_ok || pix >= a.HB * a.Wd) continue;
+    const int hb = pix / a.Wd, wd = pix - hb * a.Wd;
+    const int hd0 = hb * TH;
+    float gs[CH], gh[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      gs[i] = a.g_scale ? a.g_scale[(int64_t)n * a.C + c0 + i] : 1.f;
+      gh[i] = a.g_shift ? a.g_shift[(int64_t)n * a.C + c0 + i] : 0.f;
+    }
+    float g[TH][CH];
+#pragma unroll
+    for (int j = 0; j < TH; ++j) {
+      const int hd = hd0 + j;
+      if (hd < a.Hd) {
+        load_ch<T, CH>(dy + (((int64_t)z * a.Hd + hd) * a.Wd + wd) * a.C + c0, g[j]);
+        if (has_g) {
+#pragma unroll
+          for (int i = 0; i < CH; ++i) g[j][i] = g[j][i] * gs[i] + gh[i];
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < CH; ++i) g[j][i] = 0.f;
+      }
+    }
+    const T* fbase = x + ((int64_t)n * a.Tsrc + ts) * a.Hs * a.Ws * a.C + c0;
+    constexpr int RH = (TH - 1) * S + K;
+#pragma unroll
+    for (int r = 0; r < RH; ++r) {
+      const int hs = hd0 * S - a.pad + r;
+      if (hs < 0 || hs >= a.Hs) continue;
+      float in[K][CH];
+#pragma unroll
+      for (int kw = 0; kw < K; ++kw) {
+        const int ws = wd * S - a.pad + kw;
+        if (ws >= 0 && ws < a.Ws) {
+          load_ch<T, CH>(fbase + ((int64_t)hs * a.Ws + ws) * a.C, in[kw]);
+        } else {
+#pragma unroll
+          for (int i = 0; i < CH; ++i) in[kw][i] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < TH; ++j) {
+        const int kh = r - j * S;
+        if (kh >= 0 && kh < K) {
+#pragma unroll
+          for (int kw = 0; kw < K; ++kw)
+#pragma unroll
+            for (int i = 0; i < CH; ++i) acc[kh][kw][i] += g[j][i] * in[kw][i];
+        }
+      }
+    }
+  }
+  if (lane_ok) {
+#pragma unroll
+    for (int kh = 0; kh < K; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < K; ++kw)
+#pragma unroll
+        for (int i = 0; i < CH; ++i) atomicAdd(&red[(kh * K + kw) * (a.CVB * CH) + cvl * CH + i], acc[kh][kw][i]);
+  }
+  __syncthreads();
+  for (int i = tid; i < K * K * a.CVB * CH; i += 256) {
+    const int tap = i / (a.CVB * CH), cl = i - tap * (a.CVB * CH);
+    const int c = blockIdx.y * a.CVB * CH + cl;
+    if (c < a.C && red[i] != 0.f) atomicAdd(a.dw + (int64_t)c * (K * K) + tap, red[i]);
+  }
+}
+
+// ----------------------------------------------------------------------------- generic path
+struct GenArgs {
+  const void* src;
+  const float* w;
+  void* dst;
+  const void* x;
+  float* dw;
+  pb_dwconv_shape s;
+  const float* g_scale;
+  const float* g_shift;
+  float* pool;
+  int CV;               // C / CH
+  int64_t total;        // threads of work
+};
+
+// forward: one thread = CH channels of one output voxel
+template <typename T, int CH>
+__global__ __launch_bounds__(256) void dw_gen_fwd_kernel(GenArgs a) {
+  const pb_dwconv_shape& s = a.s;
+  const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (f >= a.total) return;
+  const int cv = (int)(f % a.CV);
+  int64_t pix = f / a.CV;
+  const int wo = (int)(pix % s.Wo); pix /= s.Wo;
+  const int ho = (int)(pix % s.Ho); pix /= s.Ho;
+  const int to = (int)(pix % s.To);
+  const int n = (int)(pix / s.To);
+  const int c0 = cv * CH;
+  const int taps = s.kt * s.kh * s.kw;
+  const T* x = (const T*)a.src;
+  float acc[CH];
+#pragma unroll
+  for (int i = 0; i < CH; ++i) acc[i] = 0.f;
+  for (int at = 0; at < s.kt; ++at) {
+    const int ti = to * s.st - s.pt + at;
+    if (ti < 0 || ti >= s.Ti) continue;
+    for (int ah = 0; ah < s.kh; ++ah) {
+      const int hi = ho * s.sh - s.ph + ah;
+      if (hi < 0 || hi >= s.Hi) continue;
+      for (int aw = 0; aw < s.kw; ++aw) {
+        const int wi = wo * s.sw - s.pw + aw;
+        if (wi < 0 || wi >= s.Wi) continue;
+        float v[CH];
+        load_ch<T, CH>(x + ((((int64_t)n * s.Ti + ti) * s.Hi + hi) * s.Wi + wi) * s.C + c0, v);
+        const int tap = (at * s.kh + ah) * s.kw + aw;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) acc[i] += v[i] * a.w[(int64_t)(c0 + i) * taps + tap];
+      }
+    }
+  }
+  store_ch<T, CH>((T*)a.dst + ((((int64_t)n * s.To + to) * s.Ho + ho) * s.Wo + wo) * s.C + c0, acc);
+  if (a.pool) {
+#pragma unroll
+    for (int i = 0; i < CH; ++i) atomicAdd(a.pool + (int64_t)n * s.C + c0 + i, to_f32(from_f32<T>(acc[i])));
+  }
+}
+
+// backward-data: one thread = CH channels of one INPUT voxel
+template <typename T, int CH>
+__global__ __launch_bounds__(256) void dw_gen_bwd_data_kernel(GenArgs a) {
+  const pb_dwconv_shape& s = a.s;
+  const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (f >= a.total) return;
+  const int cv = (int)(f % a.CV);
+  int64_t pix = f / a.CV;
+  const int wi = (int)(pix % s.Wi); pix /= s.Wi;
+  const int hi = (int)(pix % s.Hi); pix /= s.Hi;
+  const int ti = (int)(pix % s.Ti);
+  const int n = (int)(pix / s.Ti);
+  const int c0 = cv * CH;
+  const int taps = s.kt * s.kh * s.kw;
+  const T* dy = (const T*)a.src;
+  float gs[CH], gh[CH], acc[CH];
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    gs[i] = a.g_scale ? a.g_scale[(int64_t)n * s.C + c0 + i] : 1.f;
+    gh[i] = a.g_shift ? a.g_shift[(int64_t)n * s.C + c0 + i] : 0.f;
+    acc[i] = 0.f;
+  }
+  for (int at = 0; at < s.kt; ++at) {
+    const int tn = ti + s.pt - at;
+    if (tn < 0 || tn % s.st) continue;
+    const int to = tn / s.st;
+    if (to >= s.To) continue;
+    for (int ah = 0; ah < s.kh; ++ah) {
+      const int hn = hi + s.ph - ah;
+      if (hn < 0 || hn % s.sh) continue;
+      const int ho = hn / s.sh;
+      if (ho >= s.Ho) continue;
+      for (int aw = 0; aw < s.kw; ++aw) {
+        const int wn = wi + s.pw - aw;
+        if (wn < 0 || wn % s.sw) continue;
+        const int wo = wn / s.sw;
+        if (wo >= s.Wo) continue;
+        float v[CH];
+        load_ch<T, CH>(dy + ((((int64_t)n * s.To + to) * s.Ho + ho) * s.Wo + wo) * s.C + c0, v);
+        const int tap = (at * s.kh + ah) * s.kw + aw;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) acc[i] += (v[i] * gs[i] + gh[i]) * a.w[(int64_t)(c0 + i) * taps + tap];
+      }
+    }
+  }
+  store_ch<T, CH>((T*)a.dst + ((((int64_t)n * s.Ti + ti) * s.Hi + hi) * s.Wi + wi) * s.C + c0, acc);
+}
+
+// backward-weight: blockIdx.y = tap; threads (channel-vector, voxel lane) grid-stride over output
+// voxels, then a block reduction per channel.
+template <typename T, int CH>
+__global__ __launch_bounds__(256) void dw_gen_wgrad_kernel(GenArgs a, int CVB, int P, int cchunks) {
+  __shared__ float red[32 * 8];
+  const pb_dwconv_shape& s = a.s;
+  const int tid = threadIdx.x;
+  const int cvl = tid % CVB, p = tid / CVB;
+  const int tap = blockIdx.y / cchunks, chunk = blockIdx.y - tap * cchunks;
+  const int cv = chunk * CVB + cvl;
+  const bool lane_ok = p < P && cv < a.CV;
+  const int c0 = cv * CH;
+  const int aw = tap % s.kw, ah = (tap / s.kw) % s.kh, at = tap / (s.kw * s.kh);
+  const int taps = s.kt * s.kh * s.kw;
+  if (tid < 256) red[tid] = 0.f;
+  __syncthreads();
+  const T* dy = (const T*)a.src;
+  const T* x = (const T*)a.x;
+  float acc[CH];
+#pragma unroll
+  for (int i = 0; i < CH; ++i) acc[i] = 0.f;
+  const int64_t nvox = (int64_t)s.N * s.To * s.Ho * s.Wo;
+  if (lane_ok) {
+    for (int64_t v0 = (int64_t)blockIdx.x * P + p; v0 < nvox; v0 += (int64_t)gridDim.x * P) {
+      int64_t pix = v0;
+      const int wo = (int)(pix % s.Wo); pix /= s.Wo;
+      const int ho = (int)(pix % s.Ho); pix /= s.Ho;
+      const int to = (int)(pix % s.To);
+      const int n = (int)(pix / s.To);
+      const int ti = to * s.st - s.pt + at, hi = ho * s.sh - s.ph + ah, wi = wo * s.sw - s.pw + aw;
+      if (ti < 0 || ti >= s.Ti || hi < 0 || hi >= s.Hi || wi < 0 || wi >= s.Wi) continue;
+      float g[CH], xv[CH];
+      load_ch<T, CH>(dy + v0 * s.C + c0, g);
+      load_ch<T, CH>(x + ((((int64_t)n * s.Ti + ti) * s.Hi + hi) * s.Wi + wi) * s.C + c0, xv);
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const float gs = a.g_scale ? a.g_scale[(int64_t)n * s.C + c0 + i] : 1.f;
+        const float gh = a.g_shift ? a.g_shift[(int64_t)n * s.C + c0 + i] : 0.f;
+        acc[i] += (g[i] * gs + gh) * xv[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < CH; ++i) atomicAdd(&red[cvl * CH + i], acc[i]);
+  }
+  __syncthreads();
+  if (tid < CVB * CH) {
+    const int c = chunk * CVB * CH + tid;
+    if (c < s.C && red[tid] != 0.f) atomicAdd(a.dw + (int64_t)c * taps + tap, red[tid]);
+  }
+}
+
+// channel-vector lanes per workgroup: the largest divisor of CV that is <= 32 (all lanes busy);
+// a prime CV > 32 falls back to 16 with the tail chunk masked.
+int pick_cvb(int CV) {
+  for (int d = CV < 32 ? CV : 32; d >= 1; --d)
+    if (CV % d == 0) return d >= 4 || CV <= 32 ? d : 16;
+  return 1;
+}
+
+bool strip_ok(const pb_dwconv_shape& s) {
+  return s.kt == 1 && s.kh == s.kw && (s.kh == 3 || s.kh == 5) && s.sh == s.sw && (s.sh == 1 || s.sh == 2) &&
+         s.ph == s.pw && s.C % 4 == 0;
+}
+
+template <typename T, int K, int S, int CH>
+void launch_strip_fwd(StripArgs a, hipStream_t st) {
+  a.CV = a.C / CH;
+  a.CVB = pick_cvb(a.CV);
+  a.P = 256 / a.CVB;
+  a.HB = (int)pb_cdiv(a.Hd, TH);
+  a.xblocks = (int)pb_cdiv((int64_t)a.HB * a.Wd, a.P);
+  // a workgroup loads its filter chunk once and then walks several pixel blocks of its frame;
+  // keep >= ~8 workgroups per CU in the whole launch
+  const int64_t chunks = pb_cdiv(a.CV, a.CVB), frames = (int64_t)a.N * a.Tdst;
+  int64_t gx = pb_cdiv(2048, chunks * frames);
+  if (gx < pb_cdiv(a.xblocks, 8)) gx = pb_cdiv(a.xblocks, 8);
+  if (gx > a.xblocks) gx = a.xblocks;
+  dim3 grid((unsigned)gx, (unsigned)chunks, (unsigned)frames);
+  hipLaunchKernelGGL((dw_strip_fwd_kernel<T, K, S, CH>), grid, dim3(256), 0, st, a);
+}
+template <typename T, int K, int S, int CH>
+void launch_strip_wgrad(StripArgs a, hipStream_t st) {
+  a.CV = a.C / CH;
+  a.CVB = pick_cvb(a.CV);
+  a.P = 256 / a.CVB;
+  a.HB = (int)pb_cdiv(a.Hd, TH);
+  a.xblocks = (int)pb_cdiv((int64_t)a.HB * a.Wd, a.P);
+  a.items = (int64_t)a.N * a.Tdst * a.xblocks;
+  const int chunks = (int)pb_cdiv(a.CV, a.CVB);
+  int64_t gx = pb_cdiv(2048, chunks);
+  if (gx > a.items) gx = a.items;
+  if (gx < 1) gx = 1;
+  dim3 grid((unsigned)gx, (unsigned)chunks);
+  hipLaunchKernelGGL((dw_strip_wgrad_kernel<T, K, S, CH>), grid, dim3(256), 0, st, a);
+}
+
+// bf16: 8 channels/thread for k=3 (16 B), 4 for k=5 (taps live in registers: 25*4 = 100 VGPRs);
+// f32: 4 channels/thread (16 B).
+template <typename T, bool WGRAD>
+int dispatch_strip(const StripArgs& a, int K, int S, hipStream_t st) {
+  constexpr bool BF = sizeof(T) == 2;
+#define PB_STRIP(KK, SS, CC)                                                          \
+  do {                                                                                \
+    if (WGRAD) launch_strip_wgrad<T, KK, SS, CC>(a, st);                              \
+    else launch_strip_fwd<T, KK, SS, CC>(a, st);                                      \
+    return 0;                                                                         \
+  } while (0)
+  if (K == 3 && S == 1) { if (BF && a.C % 8 == 0) PB_STRIP(3, 1, 8); else PB_STRIP(3, 1, 4); }
+  if (K == 3 && S == 2) { if (BF && a.C % 8 == 0) PB_STRIP(3, 2, 8); else PB_STRIP(3, 2, 4); }
+  if (K == 5 && S == 1) PB_STRIP(5, 1, 4);
+  if (K == 5 && S == 2) PB_STRIP(5, 2, 4);
+#undef PB_STRIP
+  pb_set_error("dwconv strip: unsupported k=%d s=%d", K, S);
+  return 1;
+}
+
+int check_shape(const pb_dwconv_shape* s, const char* who) {
+  PB_CHECK_ARG(s, "%s: null shape", who);
+  PB_CHECK_ARG((int64_t)s->N * s->To <= 65535 && (int64_t)s->N * s->Ti <= 65535, "%s: N*T exceeds the grid limit", who);
+  PB_CHECK_ARG(s->N > 0 && s->C > 0 && s->Ti > 0 && s->Hi > 0 && s->Wi > 0 && s->To > 0 && s->Ho > 0 && s->Wo > 0,
+               "%s: non-positive dimension", who);
+  PB_CHECK_ARG(s->kt > 0 && s->kh > 0 && s->kw > 0 && s->st > 0 && s->sh > 0 && s->sw > 0 && s->pt >= 0 &&
+               s->ph >= 0 && s->pw >= 0, "%s: bad kernel/stride/padding", who);
+  // the output extents must be reachable: last output's first tap must start inside the padded input
+  PB_CHECK_ARG((s->To - 1) * s->st - s->pt < s->Ti && (s->Ho - 1) * s->sh - s->ph < s->Hi &&
+               (s->Wo - 1) * s->sw - s->pw < s->Wi, "%s: output extent inconsistent with input/stride/padding", who);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int pb_dwconv3d_fwd(const void* x, const float* w, void* y, const pb_dwconv_shape* s, pb_dtype dtype,
+                               float* pool, int device, void* stream) {
+  PB_CHECK_ARG(x && w && y, "pb_dwconv3d_fwd: null pointer");
+  if (int rc = check_shape(s, "pb_dwconv3d_fwd")) return rc;
+  PB_CHECK_ARG(dtype == PB_F32 || dtype == PB_BF16, "pb_dwconv3d_fwd: bad dtype");
+  PB_ENTER(device);
+  hipStream_t st = (hipStream_t)stream;
+  if (strip_ok(*s)) {
+    StripArgs a = {};
+    a.src = x; a.w = w; a.dst = y; a.N = s->N; a.C = s->C;
+    a.Tsrc = s->Ti; a.Hs = s->Hi; a.Ws = s->Wi; a.Tdst = s->To; a.Hd = s->Ho; a.Wd = s->Wo;
+    a.pad = s->ph; a.t_mul = s->st; a.t_off = -s->pt; a.flip = 0; a.pool = pool;
+    int rc = dtype == PB_BF16 ? dispatch_strip<bf16_t, false>(a, s->kh, s->sh, st)
+                              : dispatch_strip<float, false>(a, s->kh, s->sh, st);
+    if (rc) return rc;
+  } else {
+    GenArgs a = {};
+    a.src = x; a.w = w; a.dst = y; a.s = *s; a.pool = pool;
+    const int ch = s->C % 4 == 0 ? 4 : 1;
+    a.CV = s->C / ch;
+    a.total = (int64_t)s->N * s->To * s->Ho * s->Wo * a.CV;
+    dim3 grid((unsigned)pb_cdiv(a.total, 256));
+    if (dtype == PB_BF16) {
+      if (ch == 4) hipLaunchKernelGGL((dw_gen_fwd_kernel<bf16_t, 4>), grid, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((dw_gen_fwd_kernel<bf16_t, 1>), grid, dim3(256), 0, st, a);
+    } else {
+      if (ch == 4) hipLaunchKernelGGL((dw_gen_fwd_kernel<float, 4>), grid, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((dw_gen_fwd_kernel<float, 1>), grid, dim3(256), 0, st, a);
+    }
+  }
+  PB_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pb_dwconv3d_bwd_data(const void* dy, const float* w, void* dx, const pb_dwconv_shape* s,
+                                    pb_dtype dtype, const float* g_scale, const float* g_shift, int device,
+                                    void* stream) {
+  PB_CHECK_ARG(dy && w && dx, "pb_dwconv3d_bwd_data: null pointer");
+  if (int rc = check_shape(s, "pb_dwconv3d_bwd_data")) return rc;
+  PB_CHECK_ARG(dtype == PB_F32 || dtype == PB_BF16, "pb_dwconv3d_bwd_data: bad dtype");
+  PB_ENTER(device);
+  hipStream_t st = (hipStream_t)stream;
+  // stride-1 spatial + temporal: correlation of dy with the flipped filter, padding k-1-p
+  if (strip_ok(*s) && s->sh == 1 && s->st == 1 && s->Ho == s->Hi + 2 * s->ph - s->kh + 1 &&
+      s->Wo == s->Wi + 2 * s->pw - s->kw + 1) {
+    StripArgs a = {};
+    a.src = dy; a.w = w; a.dst = dx; a.N = s->N; a.C = s->C;
+    a.Tsrc = s->To; a.Hs = s->Ho; a.Ws = s->Wo; a.Tdst = s->Ti; a.Hd = s->Hi; a.Wd = s->Wi;
+    a.pad = s->kh - 1 - s->ph; a.t_mul = 1; a.t_off = s->pt; a.flip = 1;
+    a.g_scale = g_scale; a.g_shift = g_shift;
+    int rc = dtype == PB_BF16 ? dispatch_strip<bf16_t, false>(a, s->kh, 1, st) : dispatch_strip<float, false>(a, s->kh, 1, st);
+    if (rc) return rc;
+  } else {
+    GenArgs a = {};
+    a.src = dy; a.w = w; a.dst = dx; a.s = *s; a.g_scale = g_scale; a.g_shift = g_shift;
+    const int ch = s->C % 4 == 0 ? 4 : 1;
+    a.CV = s->C / ch;
+    a.total = (int64_t)s->N * s->Ti * s->Hi * s->Wi * a.CV;
+    dim3 grid((unsigned)pb_cdiv(a.total, 256));
+    if (dtype == PB_BF16) {
+      if (ch == 4) hipLaunchKernelGGL((dw_gen_bwd_data_kernel<bf16_t, 4>), grid, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((dw_gen_bwd_data_kernel<bf16_t, 1>), grid, dim3(256), 0, st, a);
+    } else {
+      if (ch == 4) hipLaunchKernelGGL((dw_gen_bwd_data_kernel<float, 4>), grid, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((dw_gen_bwd_data_kernel<float, 1>), grid, dim3(256), 0, st, a);
+    }
+  }
+  PB_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pb_dwconv3d_bwd_weight(const void* dy, const void* x, float* dw, const pb_dwconv_shape* s,
+                                      pb_dtype dtype, const float* g_scale, const float* g_shift, int device,
+                                      void* stream) {
+  PB_CHECK_ARG(dy && x && dw, "pb_dwconv3d_bwd_weight: null pointer");
+  if (int rc = check_shape(s, "pb_dwconv3d_bwd_weight")) return rc;
+  PB_CHECK_ARG(dtype == PB_F32 || dtype == PB_BF16, "pb_dwconv3d_bwd_weight: bad dtype");
+  PB_ENTER(device);
+  hipStream_t st = (hipStream_t)stream;
+  if (strip_ok(*s)) {
+    StripArgs a = {};
+    a.dst = const_cast<void*>(dy); a.x = x; a.dw = dw; a.N = s->N; a.C = s->C;
+    a.Tsrc = s->Ti; a.Hs = s->Hi; a.Ws = s->Wi; a.Tdst = s->To; a.Hd = s->Ho; a.Wd = s->Wo;
+    a.pad = s->ph; a.t_mul = s->st; a.t_off = -s->pt;
+    a.g_scale = g_scale; a.g_shift = g_shift;
+    int rc = dtype == PB_BF16 ? dispatch_strip<bf16_t, true>(a, s->kh, s->sh, st) : dispatch_strip<float, true>(a, s->kh, s->sh, st);
+    if (rc) return rc;
+  } else {
+    GenArgs a = {};
+    a.src = dy; a.x = x; a.dw = dw; a.s = *s; a.g_scale = g_scale; a.g_shift = g_shift;
+    const int ch = s->C % 4 == 0 ? 4 : 1;
+    a.CV = s->C / ch;
+    const int cvb = pick_cvb(a.CV), P = 256 / cvb, cchunks = (int)pb_cdiv(a.CV, cvb);
+    const int taps = s->kt * s->kh * s->kw;
+    const int64_t nvox = (int64_t)s->N * s->To * s->Ho * s->Wo;
+    int64_t gx = pb_cdiv(nvox, P);
+    const int64_t cap = pb_cdiv(4096, (int64_t)taps * cchunks);
+    if (gx > cap) gx = cap;
+    if (gx < 1) gx = 1;
+    dim3 grid((unsigned)gx, (unsigned)(taps * cchunks));
+    if (dtype == PB_BF16) {
+      if (ch == 4) hipLaunchKernelGGL((dw_gen_wgrad_kernel<bf16_t, 4>), grid, dim3(256), 0, st, a, cvb, P, cchunks);
+      else hipLaunchKernelGGL((dw_gen_wgrad_kernel<bf16_t, 1>), grid, dim3(256), 0, st, a, cvb, P, cchunks);
+    } else {
+      if (ch == 4) hipLaunchKernelGGL((dw_gen_wgrad_kernel<float, 4>), grid, dim3(256), 0, st, a, cvb, P, cchunks);
+      else hipLaunchKernelGGL((dw_gen_wgrad_kernel<float, 1>), grid, dim3(256), 0, st, a, cvb, P, cchunks);
+    }
+  }
+  PB_LAUNCH_CHECK();
+  return 0;
+}

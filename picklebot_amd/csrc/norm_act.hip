@@ -1,0 +1,447 @@
+// Per-channel statistics, BatchNorm finalisation, fused affine+activation(+dropout/SE row scale)
+// forward and backward, row-group reductions.  All are single-pass streaming kernels over the
+// [M rows][C channels] NDHWC matrix: lanes run along (channel-vector, then row) so a wave's access
+// is one contiguous span; per-channel sums are reduced thread -> LDS -> one atomic per workgroup
+// and channel.
+#include "pb_common.h"
+
+namespace {
+
+struct RowMap {       // thread -> (channel vector, row lane)
+  int CV, CVB, P, chunks;
+};
+
+template <int CH>
+RowMap make_map(int C) {
+  RowMap m;
+  m.CV = C / CH;
+  int d = m.CV < 32 ? m.CV : 32;
+  for (; d >= 1; --d)
+    if (m.CV % d == 0) break;
+  m.CVB = (d >= 4 || m.CV <= 32) ? d : 16;
+  m.P = 256 / m.CVB;
+  m.chunks = (int)pb_cdiv(m.CV, m.CVB);
+  return m;
+}
+
+template <typename T, int CH>
+__device__ __forceinline__ void ld(const T* p, float (&o)[CH]) {
+  if constexpr (CH == ElemTraits<T>::VEC) {
+    Vec16<T> v = vec_load<T>(p);
+#pragma unroll
+    for (int i = 0; i < CH; ++i) o[i] = v.get(i);
+  } else {
+#pragma unroll
+    for (int i = 0; i < CH; ++i) o[i] = to_f32(p[i]);
+  }
+}
+template <typename T, int CH>
+__device__ __forceinline__ void stv(T* p, const float (&o)[CH]) {
+  if constexpr (CH == ElemTraits<T>::VEC) {
+    Vec16<T> v;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) v.set(i, o[i]);
+    vec_store<T>(p, v);
+  } else {
+#pragma unroll
+    for (int i = 0; i < CH; ++i) p[i] = from_f32<T>(o[i]);
+  }
+}
+
+// block-level reduction of NRED per-thread channel vectors, then global atomics.
+// red must hold NRED * CVB*CH floats and be zeroed (and synced) by the caller.
+template <int CH, int NRED>
+__device__ __forceinline__ void block_chan_reduce(float* red, const float (&v)[NRED][CH], bool lane_ok, int cvl,
+                                                  int CW, int cbase, int C, float* const (&out)[NRED]) {
+  if (lane_ok) {
+#pragma unroll
+    for (int r = 0; r < NRED; ++r)
+#pragma unroll
+      for (int i = 0; i < CH; ++i) atomicAdd(&red[r * CW + cvl * CH + i], v[r][i]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < NRED * CW; i += 256) {
+    const int r = i / CW, cl = i - r * CW;
+    const int c = cbase + cl;
+    if (c < C) atomicAdd(out[r] + c, red[i]);
+  }
+}
+
+struct EwArgs {
+  const void* a;        // primary input (x / dy / g)
+  const void* b;        // secondary input (z)
+  void* out;
+  int64_t M;
+  int C;
+  const float* scale;
+  const float* shift;
+  int act;
+  float slope;
+  const float* row_scale;
+  const float* row_shift;
+  int64_t rows_per_group;
+  int64_t dy_rows_per_group;
+  float dy_mul;
+  const float* mean;
+  const float* rstd;
+  const float* cA;
+  const float* cB;
+  const float* cC;
+  float* sums;          // [2][C]
+  RowMap map;
+};
+
+constexpr int RED_MAX = 2 * 32 * 8;
+
+// MODE 0: chan_stats   sums += (sum a, sum a^2)
+// MODE 1: affine_act   out = act(a*scale+shift)*row_scale ; optional sums of out
+// MODE 2: act_bwd      g = dy*row_scale*act'(z*scale+shift) ; out = g (optional) ; sums += (sum g, sum g*xhat)
+// MODE 3: affine2      out = cA*a + cB*b + cC
+template <typename T, int CH, int MODE>
+__global__ __launch_bounds__(256) void ew_kernel(EwArgs a) {
+  __shared__ float red[RED_MAX];
+  const int tid = threadIdx.x;
+  const RowMap& mp = a.map;
+  const int cvl = tid % mp.CVB, p = tid / mp.CVB;
+  const int cv = blockIdx.y * mp.CVB + cvl;
+  const bool lane_ok = p < mp.P && cv < mp.CV;
+  const int c0 = cv * CH;
+  const int CW = mp.CVB * CH;
+  const bool want_sums = a.sums != nullptr;
+  if (want_sums) {
+    for (int i = tid; i < 2 * CW; i += 256) red[i] = 0.f;
+    __syncthreads();
+  }
+  float acc[2][CH];
+  float sc[CH], sh[CH], mu[CH], rs[CH], kA[CH], kB[CH], kC[CH];
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    acc[0][i] = acc[1][i] = 0.f;
+    const bool ok = lane_ok;
+    sc[i] = (a.scale && ok) ? a.scale[c0 + i] : 1.f;
+    sh[i] = (a.shift && ok) ? a.shift[c0 + i] : 0.f;
+    mu[i] = (a.mean && ok) ? a.mean[c0 + i] : 0.f;
+    rs[i] = (a.rstd && ok) ? a.rstd[c0 + i] : 1.f;
+    kA[i] = (a.cA && ok) ? a.cA[c0 + i] : 1.f;
+    kB[i] = (a.cB && ok) ? a.cB[c0 + i] : 0.f;
+    kC[i] = (a.cC && ok) ? a.cC[c0 + i] : 0.f;
+  }
+  const T* A = (const T*)a.a;
+  const T* B = (const T*)a.b;
+  T* O = (T*)a.out;
+  if (lane_ok) {
+    for (int64_t m = (int64_t)blockIdx.x * mp.P + p; m < a.M; m += (int64_t)gridDim.x * mp.P) {
+      float va[CH], vb[CH], vo[CH], rsc[CH], rsh[CH];
+      const int64_t off = m * a.C + c0;
+      if constexpr (MODE == 2) {
+        if (a.dy_rows_per_group > 0) {
+          ld<T, CH>(A + (m / a.dy_rows_per_group) * a.C + c0, va);
+        } else {
+          ld<T, CH>(A + off, va);
+        }
+      } else {
+        ld<T, CH>(A + off, va);
+      }
+      if constexpr (MODE == 2 || MODE == 3) {
+        if (B) ld<T, CH>(B + off, vb);
+        else {
+#pragma unroll
+          for (int i = 0; i < CH; ++i) vb[i] = 0.f;
+        }
+      }
+      if constexpr (MODE == 1 || MODE == 2) {
+        const float* rp = a.row_scale ? a.row_scale + (m / a.rows_per_group) * a.C + c0 : nullptr;
+        const float* rq = a.row_shift ? a.row_shift + (m / a.rows_per_group) * a.C + c0 : nullptr;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+          rsc[i] = rp ? rp[i] : 1.f;
+          rsh[i] = rq ? rq[i] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        if constexpr (MODE == 0) {
+          acc[0][i] += va[i];
+          acc[1][i] += va[i] * va[i];
+        } else if constexpr (MODE == 1) {
+          const float y = act_fwd(va[i] * sc[i] + sh[i], a.act, a.slope) * rsc[i] + rsh[i];
+          vo[i] = y;
+          const float yr = to_f32(from_f32<T>(y));
+          acc[0][i] += yr;
+          acc[1][i] += yr * yr;
+        } else if constexpr (MODE == 2) {
+          const float pre = vb[i] * sc[i] + sh[i];
+          const float g = va[i] * a.dy_mul * rsc[i] * act_bwd(pre, a.act, a.slope);
+          vo[i] = g;
+          const float gr = O ? to_f32(from_f32<T>(g)) : g;
+          acc[0][i] += gr;
+          acc[1][i] += gr * (vb[i] - mu[i]) * rs[i];
+        } else {
+          vo[i] = kA[i] * va[i] + kB[i] * vb[i] + kC[i];
+        }
+      }
+      if constexpr (MODE != 0) {
+        if (O) stv<T, CH>(O + off, vo);
+      }
+    }
+  }
+  if constexpr (MODE != 3) {
+    if (want_sums) {
+      float* const outs[2] = {a.sums, a.sums + a.C};
+      block_chan_reduce<CH, 2>(red, acc, lane_ok, cvl, CW, blockIdx.y * CW, a.C, outs);
+    }
+  }
+}
+
+template <typename T, int MODE>
+int launch_ew(EwArgs a, hipStream_t st) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  const bool vec = (a.C % VEC) == 0;
+  a.map = vec ? make_map<VEC>(a.C) : make_map<1>(a.C);
+  int64_t gx = pb_cdiv(a.M, a.map.P);
+  const int64_t cap = pb_cdiv(4096, a.map.chunks);
+  if (gx > cap) gx = cap;
+  if (gx < 1) gx = 1;
+  dim3 grid((unsigned)gx, (unsigned)a.map.chunks);
+  if (vec) hipLaunchKernelGGL((ew_kernel<T, VEC, MODE>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((ew_kernel<T, 1, MODE>), grid, dim3(256), 0, st, a);
+  return 0;
+}
+
+template <int MODE>
+int launch_ew_dt(const EwArgs& a, pb_dtype dtype, hipStream_t st) {
+  return dtype == PB_BF16 ? launch_ew<bf16_t, MODE>(a, st) : launch_ew<float, MODE>(a, st);
+}
+
+// ------------------------------------------------------------------ row-group reduce (pool / SE dot)
+struct RgArgs {
+  const void* a;
+  const void* b;
+  float* out;
+  int64_t R;
+  int C;
+  RowMap map;
+};
+
+template <typename T, int CH>
+__global__ __launch_bounds__(256) void rowgroup_kernel(RgArgs a) {
+  __shared__ float red[32 * 8];
+  const int tid = threadIdx.x;
+  const RowMap& mp = a.map;
+  const int cvl = tid % mp.CVB, p = tid / mp.CVB;
+  const int cv = blockIdx.y * mp.CVB + cvl;
+  const bool lane_ok = p < mp.P && cv < mp.CV;
+  const int c0 = cv * CH, CW = mp.CVB * CH;
+  const int64_t g = blockIdx.z;
+  for (int i = tid; i < CW; i += 256) red[i] = 0.f;
+  __syncthreads();
+  float acc[1][CH];
+#pragma unroll
+  for (int i = 0; i < CH; ++i) acc[0][i] = 0.f;
+  const T* A = (const T*)a.a + g * a.R * a.C;
+  const T* B = a.b ? (const T*)a.b + g * a.R * a.C : nullptr;
+  if (lane_ok) {
+    for (int64_t r = (int64_t)blockIdx.x * mp.P + p; r < a.R; r += (int64_t)gridDim.x * mp.P) {
+      float va[CH], vb[CH];
+      ld<T, CH>(A + r * a.C + c0, va);
+      if (B) {
+        ld<T, CH>(B + r * a.C + c0, vb);
+#pragma unroll
+        for (int i = 0; i < CH; ++i) acc[0][i] += va[i] * vb[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < CH; ++i) acc[0][i] += va[i];
+      }
+    }
+  }
+  float* const outs[1] = {a.out + g * a.C};
+  block_chan_reduce<CH, 1>(red, acc, lane_ok, cvl, CW, blockIdx.y * CW, a.C, outs);
+}
+
+__global__ void bn_finalize_kernel(const float* stats, double count, const float* gamma, const float* beta,
+                                   float eps, float momentum, float* running_mean, float* running_var,
+                                   int use_running, float* scale, float* shift, float* mean_o, float* rstd_o, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double mean, var;
+  if (use_running) {
+    mean = running_mean[c];
+    var = running_var[c];
+  } else {
+    mean = (double)stats[c] / count;
+    var = (double)stats[C + c] / count - mean * mean;
+    if (var < 0) var = 0;
+    if (running_mean) running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+    if (running_var) {
+      const double unb = count > 1 ? var * count / (count - 1) : var;
+      running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+    }
+  }
+  const double rstd = 1.0 / sqrt(var + (double)eps);
+  const double g = gamma ? gamma[c] : 1.0, b = beta ? beta[c] : 0.0;
+  scale[c] = (float)(g * rstd);
+  shift[c] = (float)(b - mean * g * rstd);
+  if (mean_o) mean_o[c] = (float)mean;
+  if (rstd_o) rstd_o[c] = (float)rstd;
+}
+
+__global__ void bn_bwd_finalize_kernel(const float* sums, double count, const float* gamma, const float* mean,
+                                       const float* rstd, int training, float* cA, float* cB, float* cC,
+                                       float* dgamma, float* dbeta, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double sg = sums[c], sgx = sums[C + c];
+  const double g = gamma ? gamma[c] : 1.0, r = rstd[c], mu = mean[c];
+  if (training) {
+    const double B = -g * r * r * (sgx / count);
+    cA[c] = (float)(g * r);
+    cB[c] = (float)B;
+    cC[c] = (float)(-B * mu - g * r * (sg / count));
+  } else {
+    cA[c] = (float)(g * r);
+    cB[c] = 0.f;
+    cC[c] = 0.f;
+  }
+  if (dgamma) dgamma[c] = (float)sgx;
+  if (dbeta) dbeta[c] = (float)sg;
+}
+
+__global__ void transpose_f32_kernel(const float* in, float* out, int R, int C) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)R * C) return;
+  const int r = (int)(i / C), c = (int)(i - (int64_t)r * C);
+  out[(int64_t)c * R + r] = in[i];
+}
+
+int check_mc(int64_t M, int C, pb_dtype dtype, const char* who) {
+  PB_CHECK_ARG(M >= 0 && C > 0, "%s: bad sizes M=%lld C=%d", who, (long long)M, C);
+  PB_CHECK_ARG(dtype == PB_F32 || dtype == PB_BF16, "%s: bad dtype %d", who, (int)dtype);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int pb_chan_stats(const void* x, int64_t M, int C, pb_dtype dtype, float* stats, int device, void* stream) {
+  PB_CHECK_ARG(x && stats, "pb_chan_stats: null pointer");
+  if (int rc = check_mc(M, C, dtype, "pb_chan_stats")) return rc;
+  if (M == 0) return 0;
+  PB_ENTER(device);
+  EwArgs a = {};
+  a.a = x; a.M = M; a.C = C; a.sums = stats; a.rows_per_group = 1; a.dy_mul = 1.f;
+  launch_ew_dt<0>(a, dtype, (hipStream_t)stream);
+  PB_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pb_bn_finalize(const float* stats, double count, const float* gamma, const float* beta, float eps,
+                              float momentum, float* running_mean, float* running_var, int use_running,
+                              float* scale, float* shift, float* mean, float* rstd, int C, int device, void* stream) {
+  PB_CHECK_ARG(scale && shift && C > 0, "pb_bn_finalize: null output / bad C");
+  PB_CHECK_ARG(use_running ? (running_mean && running_var) : (stats && count > 0),
+               "pb_bn_finalize: missing statistics (use_running=%d)", use_running);
+  PB_ENTER(device);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)pb_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, stats,
+                     count, gamma, beta, eps, momentum, running_mean, running_var, use_running, scale, shift, mean,
+                     rstd, C);
+  PB_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pb_affine_act_fwd(const void* x, void* y, int64_t M, int C, pb_dtype dtype, const float* scale,
+                                 const float* shift, pb_act act, float slope, const float* row_scale,
+                                 const float* row_shift, int64_t rows_per_group, float* stats, int device,
+                                 void* stream) {
+  PB_CHECK_ARG(x && y, "pb_affine_act_fwd: null pointer");
+  if (int rc = check_mc(M, C, dtype, "pb_affine_act_fwd")) return rc;
+  PB_CHECK_ARG(!(row_scale || row_shift) || rows_per_group > 0, "pb_affine_act_fwd: row_scale/shift need rows_per_group > 0");
+  if (M == 0) return 0;
+  PB_ENTER(device);
+  EwArgs a = {};
+  a.a = x; a.out = y; a.M = M; a.C = C; a.scale = scale; a.shift = shift; a.act = (int)act; a.slope = slope;
+  a.row_scale = row_scale; a.row_shift = row_shift; a.rows_per_group = rows_per_group > 0 ? rows_per_group : 1;
+  a.sums = stats; a.dy_mul = 1.f;
+  launch_ew_dt<1>(a, dtype, (hipStream_t)stream);
+  PB_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pb_act_bwd_reduce(const void* dy, const void* z, void* g_out, int64_t M, int C, pb_dtype dtype,
+                                 const float* scale, const float* shift, pb_act act, float slope,
+                                 const float* row_scale, int64_t rows_per_group, int64_t dy_rows_per_group,
+                                 float dy_mul, const float* mean, const float* rstd, float* sums, int device,
+                                 void* stream) {
+  PB_CHECK_ARG(dy && z, "pb_act_bwd_reduce: null pointer");
+  if (int rc = check_mc(M, C, dtype, "pb_act_bwd_reduce")) return rc;
+  PB_CHECK_ARG(!row_scale || rows_per_group > 0, "pb_act_bwd_reduce: row_scale needs rows_per_group > 0");
+  if (M == 0) return 0;
+  PB_ENTER(device);
+  EwArgs a = {};
+  a.a = dy; a.b = z; a.out = g_out; a.M = M; a.C = C; a.scale = scale; a.shift = shift; a.act = (int)act;
+  a.slope = slope; a.row_scale = row_scale; a.rows_per_group = rows_per_group > 0 ? rows_per_group : 1;
+  a.dy_rows_per_group = dy_rows_per_group; a.dy_mul = dy_mul; a.mean = mean; a.rstd = rstd; a.sums = sums;
+  launch_ew_dt<2>(a, dtype, (hipStream_t)stream);
+  PB_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pb_bn_bwd_finalize(const float* sums, double count, const float* gamma, const float* mean,
+                                  const float* rstd, int training, float* coefA, float* coefB, float* coefC,
+                                  float* dgamma, float* dbeta, int C, int device, void* stream) {
+  PB_CHECK_ARG(sums && mean && rstd && coefA && coefB && coefC && C > 0 && count > 0, "pb_bn_bwd_finalize: bad args");
+  PB_ENTER(device);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)pb_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream,
+                     sums, count, gamma, mean, rstd, training, coefA, coefB, coefC, dgamma, dbeta, C);
+  PB_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pb_affine2(const void* g, const void* z, void* out, int64_t M, int C, pb_dtype dtype, const float* A,
+                          const float* B, const float* Cc, int device, void* stream) {
+  PB_CHECK_ARG(g && out && A, "pb_affine2: null pointer");
+  PB_CHECK_ARG(z || !B, "pb_affine2: B given without z");
+  if (int rc = check_mc(M, C, dtype, "pb_affine2")) return rc;
+  if (M == 0) return 0;
+  PB_ENTER(device);
+  EwArgs a = {};
+  a.a = g; a.b = z; a.out = out; a.M = M; a.C = C; a.cA = A; a.cB = B; a.cC = Cc; a.rows_per_group = 1; a.dy_mul = 1.f;
+  launch_ew_dt<3>(a, dtype, (hipStream_t)stream);
+  PB_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pb_rowgroup_reduce(const void* a_, const void* b_, float* out, int64_t G, int64_t rows_per_group,
+                                  int C, pb_dtype dtype, int device, void* stream) {
+  PB_CHECK_ARG(a_ && out, "pb_rowgroup_reduce: null pointer");
+  PB_CHECK_ARG(G > 0 && G <= 65535 && rows_per_group > 0 && C > 0, "pb_rowgroup_reduce: bad sizes");
+  PB_CHECK_ARG(dtype == PB_F32 || dtype == PB_BF16, "pb_rowgroup_reduce: bad dtype");
+  PB_ENTER(device);
+  RgArgs a;
+  a.a = a_; a.b = b_; a.out = out; a.R = rows_per_group; a.C = C;
+  const int vec = dtype == PB_BF16 ? 8 : 4;
+  const bool v = (C % vec) == 0;
+  a.map = v ? (vec == 8 ? make_map<8>(C) : make_map<4>(C)) : make_map<1>(C);
+  int64_t gx = pb_cdiv(rows_per_group, a.map.P);
+  const int64_t cap = pb_cdiv(2048, (int64_t)a.map.chunks * G);
+  if (gx > cap) gx = cap;
+  if (gx < 1) gx = 1;
+  dim3 grid((unsigned)gx, (unsigned)a.map.chunks, (unsigned)G);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == PB_BF16) {
+    if (v) hipLaunchKernelGGL((rowgroup_kernel<bf16_t, 8>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((rowgroup_kernel<bf16_t, 1>), grid, dim3(256), 0, st, a);
+  } else {
+    if (v) hipLaunchKernelGGL((rowgroup_kernel<float, 4>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((rowgroup_kernel<float, 1>), grid, dim3(256), 0, st, a);
+  }
+  PB_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pb_transpose_f32(const float* in, float* out, int R, int C, int device, void* stream) {
+  PB_CHECK_ARG(in && out && R > 0 && C > 0, "pb_transpose_f32: bad args");
+  PB_ENTER(device);
+  hipLaunchKernelGGL(transpose_f32_kernel, dim3((unsigned)pb_cdiv((int64_t)R * C, 256)), dim3(256), 0,
+                     (hipStream_t)stream, in, out, R, C);
+  PB_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,348 @@
+"""Tensor-level wrappers over the C-ABI (one function per entry point of include/picklebot_amd.h).
+
+Each wrapper validates shapes/dtypes/contiguity on the host (a wrong shape must never reach a
+hand-written kernel), allocates outputs with torch (plumbing) and launches on the current HIP
+stream of the tensor's device.  Activations are 2-D row matrices [M, C] or 5-D NDHWC tensors.
+"""
+import ctypes
+
+import torch
+
+from . import _C
+
+ACT = {"none": _C.ACT_NONE, "relu": _C.ACT_RELU, "leaky_relu": _C.ACT_LEAKY_RELU, "hardswish": _C.ACT_HSWISH,
+       "hardsigmoid": _C.ACT_HSIGMOID, "silu": _C.ACT_SILU}
+
+
+def _dt(t):
+    if t.dtype == torch.float32:
+        return _C.PB_F32
+    if t.dtype == torch.bfloat16:
+        return _C.PB_BF16
+    raise TypeError(f"picklebot_amd: unsupported activation dtype {t.dtype} (float32 or bfloat16)")
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _dev_stream(t):
+    if not t.is_cuda:
+        raise RuntimeError("picklebot_amd kernels need tensors on a HIP device (no CPU fallback exists)")
+    idx = t.device.index if t.device.index is not None else torch.cuda.current_device()
+    return idx, ctypes.c_void_p(torch.cuda.current_stream(idx).cuda_stream)
+
+
+def _f32(t, shape=None, name="tensor"):
+    if t is None:
+        return None
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise TypeError(f"{name}: expected contiguous float32, got {t.dtype} contiguous={t.is_contiguous()}")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+    return t
+
+
+def _rows(t, name="activation"):
+    if t.dim() != 2 or not t.is_contiguous():
+        raise ValueError(f"{name}: expected a contiguous [M, C] matrix, got shape {tuple(t.shape)} strides {t.stride()}")
+    return t
+
+
+# ------------------------------------------------------------------------------ pointwise conv
+def pw_fwd(x, w, *, w_transposed=False, in_scale=None, in_shift=None, in_act="none", in_slope=0.0, row_scale=None,
+           rows_per_group=0, out_scale=None, out_shift=None, out_act="none", out_slope=0.0, stats=None):
+    """y[M,N] = P(x)[M,K] @ Wl[N,K]^T with fused prologue/epilogue (see pb_pwconv_fwd).
+    w: fp32 [N,K], or [K,N] with w_transposed (backward-data)."""
+    _rows(x, "x")
+    M, K = x.shape
+    _f32(w, name="w")
+    if w.dim() != 2:
+        raise ValueError("w must be 2-D")
+    N = w.shape[1] if w_transposed else w.shape[0]
+    if (w.shape[0] if w_transposed else w.shape[1]) != K:
+        raise ValueError(f"pw_fwd: K mismatch x {tuple(x.shape)} w {tuple(w.shape)} transposed={w_transposed}")
+    _f32(in_scale, (K,), "in_scale"); _f32(in_shift, (K,), "in_shift")
+    _f32(out_scale, (N,), "out_scale"); _f32(out_shift, (N,), "out_shift")
+    _f32(stats, (2, N), "stats")
+    if row_scale is not None:
+        if rows_per_group <= 0 or M % rows_per_group:
+            raise ValueError("pw_fwd: rows_per_group must divide M")
+        _f32(row_scale, (M // rows_per_group, K), "row_scale")
+    y = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    dev, st = _dev_stream(x)
+    _C.call("pb_pwconv_fwd", _p(x), _p(w), _p(y), M, K, N, w.shape[1], int(w_transposed), _dt(x), _p(in_scale),
+            _p(in_shift), ACT[in_act], float(in_slope), _p(row_scale), int(rows_per_group), _p(out_scale),
+            _p(out_shift), ACT[out_act], float(out_slope), _p(stats), dev, st)
+    return y
+
+
+def pw_bwd_weight(dy, x, dw, *, in_scale=None, in_shift=None, in_act="none", in_slope=0.0, row_scale=None,
+                  rows_per_group=0):
+    """dw[N,K] += dy[M,N]^T @ P(x)[M,K]."""
+    _rows(dy, "dy"); _rows(x, "x")
+    M, N = dy.shape
+    if x.shape[0] != M or x.dtype != dy.dtype:
+        raise ValueError("pw_bwd_weight: dy/x mismatch")
+    K = x.shape[1]
+    _f32(dw, (N, K), "dw")
+    _f32(in_scale, (K,), "in_scale"); _f32(in_shift, (K,), "in_shift")
+    if row_scale is not None:
+        if rows_per_group <= 0 or M % rows_per_group:
+            raise ValueError("pw_bwd_weight: rows_per_group must divide M")
+        _f32(row_scale, (M // rows_per_group, K), "row_scale")
+    dev, st = _dev_stream(x)
+    _C.call("pb_pwconv_bwd_weight", _p(dy), _p(x), _p(dw), M, K, N, _dt(x), _p(in_scale), _p(in_shift),
+            ACT[in_act], float(in_slope), _p(row_scale), int(rows_per_group), dev, st)
+    return dw
+
+
+# ------------------------------------------------------------------------------ depthwise conv
+def dw_out_shape(in_thw, kernel, stride, pad_front, pad_back=None):
+    pad_back = pad_front if pad_back is None else pad_back
+    return tuple((i + pf + pb - k) // s + 1 for i, k, s, pf, pb in zip(in_thw, kernel, stride, pad_front, pad_back))
+
+
+def _dw_shape(N, C, in_thw, out_thw, kernel, stride, pad):
+    s = _C.DwShape()
+    s.N, s.C = N, C
+    s.Ti, s.Hi, s.Wi = in_thw
+    s.To, s.Ho, s.Wo = out_thw
+    s.kt, s.kh, s.kw = kernel
+    s.st, s.sh, s.sw = stride
+    s.pt, s.ph, s.pw = pad
+    return s
+
+
+def _ndhwc(t, name):
+    if t.dim() != 5 or not t.is_contiguous():
+        raise ValueError(f"{name}: expected contiguous [N,T,H,W,C], got {tuple(t.shape)} strides {t.stride()}")
+    return t
+
+
+def dw_fwd(x, w, kernel, stride, pad_front, pad_back=None, pool=None):
+    """x [N,T,H,W,C] -> y [N,To,Ho,Wo,C]; w fp32 [C, kt*kh*kw]; pool fp32 [N,C] += sum_THW(y)."""
+    _ndhwc(x, "x")
+    N, T, H, W, C = x.shape
+    taps = kernel[0] * kernel[1] * kernel[2]
+    _f32(w, (C, taps), "w")
+    out = dw_out_shape((T, H, W), kernel, stride, pad_front, pad_back)
+    if min(out) <= 0:
+        raise ValueError(f"dw_fwd: empty output {out}")
+    _f32(pool, (N, C), "pool")
+    y = torch.empty((N,) + out + (C,), dtype=x.dtype, device=x.device)
+    s = _dw_shape(N, C, (T, H, W), out, kernel, stride, pad_front)
+    dev, st = _dev_stream(x)
+    _C.call("pb_dwconv3d_fwd", _p(x), _p(w), _p(y), ctypes.byref(s), _dt(x), _p(pool), dev, st)
+    return y
+
+
+def dw_bwd_data(dy, w, in_thw, kernel, stride, pad_front, g_scale=None, g_shift=None):
+    _ndhwc(dy, "dy")
+    N, To, Ho, Wo, C = dy.shape
+    _f32(w, (C, kernel[0] * kernel[1] * kernel[2]), "w")
+    _f32(g_scale, (N, C), "g_scale"); _f32(g_shift, (N, C), "g_shift")
+    dx = torch.empty((N,) + tuple(in_thw) + (C,), dtype=dy.dtype, device=dy.device)
+    s = _dw_shape(N, C, in_thw, (To, Ho, Wo), kernel, stride, pad_front)
+    dev, st = _dev_stream(dy)
+    _C.call("pb_dwconv3d_bwd_data", _p(dy), _p(w), _p(dx), ctypes.byref(s), _dt(dy), _p(g_scale), _p(g_shift), dev, st)
+    return dx
+
+
+def dw_bwd_weight(dy, x, dw, kernel, stride, pad_front, g_scale=None, g_shift=None):
+    _ndhwc(dy, "dy"); _ndhwc(x, "x")
+    N, To, Ho, Wo, C = dy.shape
+    if x.shape[0] != N or x.shape[4] != C or x.dtype != dy.dtype:
+        raise ValueError("dw_bwd_weight: dy/x mismatch")
+    _f32(dw, (C, kernel[0] * kernel[1] * kernel[2]), "dw")
+    _f32(g_scale, (N, C), "g_scale"); _f32(g_shift, (N, C), "g_shift")
+    s = _dw_shape(N, C, tuple(x.shape[1:4]), (To, Ho, Wo), kernel, stride, pad_front)
+    dev, st = _dev_stream(dy)
+    _C.call("pb_dwconv3d_bwd_weight", _p(dy), _p(x), _p(dw), ctypes.byref(s), _dt(dy), _p(g_scale), _p(g_shift), dev, st)
+    return dw
+
+
+# ------------------------------------------------------------------------------ stem conv
+_XDT = {torch.float32: 0, torch.bfloat16: 1, torch.uint8: 2}
+
+
+def _stem_shape(x, cout, out_thw, kernel, stride, pad):
+    """x: logical (N,Cin,T,H,W) with arbitrary strides."""
+    s = _C.StemShape()
+    s.N, s.Cin, s.Ti, s.Hi, s.Wi = x.shape
+    s.Cout = cout
+    s.To, s.Ho, s.Wo = out_thw
+    s.kt, s.kh, s.kw = kernel
+    s.st, s.sh, s.sw = stride
+    s.pt, s.ph, s.pw = pad
+    s.xs_n, s.xs_c, s.xs_t, s.xs_h, s.xs_w = x.stride()
+    return s
+
+
+def stem_fwd(x, w, bias, kernel, stride, pad, out_dtype, x_scale=1.0, stats=None):
+    """x logical (N,Cin,T,H,W), any strides, float32/bfloat16/uint8 -> y [N,To,Ho,Wo,Cout] in out_dtype."""
+    if x.dim() != 5 or x.dtype not in _XDT:
+        raise ValueError(f"stem_fwd: bad input {tuple(x.shape)} {x.dtype}")
+    cout = w.shape[0]
+    _f32(w, (cout, x.shape[1], *kernel), "w"); _f32(bias, (cout,), "bias"); _f32(stats, (2, cout), "stats")
+    out = dw_out_shape(tuple(x.shape[2:]), kernel, stride, pad)
+    y = torch.empty((x.shape[0],) + out + (cout,), dtype=out_dtype, device=x.device)
+    s = _stem_shape(x, cout, out, kernel, stride, pad)
+    dev, st = _dev_stream(x)
+    _C.call("pb_stem_conv3d_fwd", _p(x), _XDT[x.dtype], float(x_scale), _p(w), _p(bias), _p(y), ctypes.byref(s),
+            _dt(y), _p(stats), dev, st)
+    return y
+
+
+def stem_bwd_weight(dy, x, dw, dbias, kernel, stride, pad, x_scale=1.0):
+    _ndhwc(dy, "dy")
+    cout = dy.shape[4]
+    _f32(dw, (cout, x.shape[1], *kernel), "dw"); _f32(dbias, (cout,), "dbias")
+    s = _stem_shape(x, cout, tuple(dy.shape[1:4]), kernel, stride, pad)
+    dev, st = _dev_stream(dy)
+    _C.call("pb_stem_conv3d_bwd_weight", _p(dy), _p(x), _XDT[x.dtype], float(x_scale), _p(dw), _p(dbias),
+            ctypes.byref(s), _dt(dy), dev, st)
+    return dw
+
+
+# ------------------------------------------------------------------------------ statistics / norm / activation
+def chan_stats(x, stats):
+    _rows(x, "x")
+    _f32(stats, (2, x.shape[1]), "stats")
+    dev, st = _dev_stream(x)
+    _C.call("pb_chan_stats", _p(x), x.shape[0], x.shape[1], _dt(x), _p(stats), dev, st)
+    return stats
+
+
+def bn_finalize(stats, count, gamma, beta, eps, momentum, running_mean, running_var, use_running, C, device):
+    """-> (scale, shift, mean, rstd), each fp32 [C]; running stats updated in place when training."""
+    _f32(stats, (2, C), "stats"); _f32(gamma, (C,), "gamma"); _f32(beta, (C,), "beta")
+    _f32(running_mean, (C,), "running_mean"); _f32(running_var, (C,), "running_var")
+    out = torch.empty((4, C), dtype=torch.float32, device=device)
+    ref = stats if stats is not None else running_mean
+    dev, st = _dev_stream(ref)
+    _C.call("pb_bn_finalize", _p(stats), float(count), _p(gamma), _p(beta), float(eps), float(momentum),
+            _p(running_mean), _p(running_var), int(use_running), _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]),
+            C, dev, st)
+    return out[0], out[1], out[2], out[3]
+
+
+def affine_act_fwd(x, scale=None, shift=None, act="none", slope=0.0, row_scale=None, rows_per_group=0, stats=None,
+                   row_shift=None):
+    """y = act(x*scale+shift) * row_scale[g] + row_shift[g]; stats[2,C] += (sum y, sum y^2)."""
+    _rows(x, "x")
+    M, C = x.shape
+    _f32(scale, (C,), "scale"); _f32(shift, (C,), "shift"); _f32(stats, (2, C), "stats")
+    if row_scale is not None or row_shift is not None:
+        if rows_per_group <= 0 or M % rows_per_group:
+            raise ValueError("affine_act_fwd: rows_per_group must divide M")
+        _f32(row_scale, (M // rows_per_group, C), "row_scale")
+        _f32(row_shift, (M // rows_per_group, C), "row_shift")
+    y = torch.empty_like(x)
+    dev, st = _dev_stream(x)
+    _C.call("pb_affine_act_fwd", _p(x), _p(y), M, C, _dt(x), _p(scale), _p(shift), ACT[act], float(slope),
+            _p(row_scale), _p(row_shift), int(rows_per_group), _p(stats), dev, st)
+    return y
+
+
+def act_bwd_reduce(dy, z, *, scale=None, shift=None, act="none", slope=0.0, row_scale=None, rows_per_group=0,
+                   dy_rows_per_group=0, dy_mul=1.0, mean=None, rstd=None, sums=None, want_g=True):
+    """g = dy*row_scale*act'(z*scale+shift) (returned when want_g); sums[2,C] += (sum g, sum g*xhat)."""
+    _rows(z, "z"); _rows(dy, "dy")
+    M, C = z.shape
+    if dy_rows_per_group > 0:
+        if M % dy_rows_per_group or tuple(dy.shape) != (M // dy_rows_per_group, C):
+            raise ValueError("act_bwd_reduce: broadcast dy shape mismatch")
+    elif tuple(dy.shape) != (M, C):
+        raise ValueError("act_bwd_reduce: dy/z shape mismatch")
+    if dy.dtype != z.dtype:
+        raise TypeError("act_bwd_reduce: dy/z dtype mismatch")
+    for t, n in ((scale, "scale"), (shift, "shift"), (mean, "mean"), (rstd, "rstd")):
+        _f32(t, (C,), n)
+    _f32(sums, (2, C), "sums")
+    if row_scale is not None:
+        if rows_per_group <= 0 or M % rows_per_group:
+            raise ValueError("act_bwd_reduce: rows_per_group must divide M")
+        _f32(row_scale, (M // rows_per_group, C), "row_scale")
+    g = torch.empty_like(z) if want_g else None
+    dev, st = _dev_stream(z)
+    _C.call("pb_act_bwd_reduce", _p(dy), _p(z), _p(g), M, C, _dt(z), _p(scale), _p(shift), ACT[act], float(slope),
+            _p(row_scale), int(rows_per_group), int(dy_rows_per_group), float(dy_mul), _p(mean), _p(rstd), _p(sums),
+            dev, st)
+    return g
+
+
+def bn_bwd_finalize(sums, count, gamma, mean, rstd, training, want_affine_grads):
+    """-> (A, B, Cc, dgamma, dbeta); dz = A*g + B*z + Cc."""
+    C = mean.shape[0]
+    _f32(sums, (2, C), "sums"); _f32(gamma, (C,), "gamma"); _f32(mean, (C,), "mean"); _f32(rstd, (C,), "rstd")
+    out = torch.empty((5, C), dtype=torch.float32, device=mean.device)
+    dev, st = _dev_stream(mean)
+    _C.call("pb_bn_bwd_finalize", _p(sums), float(count), _p(gamma), _p(mean), _p(rstd), int(training), _p(out[0]),
+            _p(out[1]), _p(out[2]), _p(out[3]) if want_affine_grads else None,
+            _p(out[4]) if want_affine_grads else None, C, dev, st)
+    return out[0], out[1], out[2], (out[3] if want_affine_grads else None), (out[4] if want_affine_grads else None)
+
+
+def affine2(g, z, A, B=None, Cc=None):
+    _rows(g, "g")
+    M, C = g.shape
+    if z is not None:
+        _rows(z, "z")
+        if z.shape != g.shape or z.dtype != g.dtype:
+            raise ValueError("affine2: g/z mismatch")
+    _f32(A, (C,), "A"); _f32(B, (C,), "B"); _f32(Cc, (C,), "Cc")
+    out = torch.empty_like(g)
+    dev, st = _dev_stream(g)
+    _C.call("pb_affine2", _p(g), _p(z), _p(out), M, C, _dt(g), _p(A), _p(B), _p(Cc), dev, st)
+    return out
+
+
+def rowgroup_reduce(a, b, G):
+    """out[G,C] = per-group sum over rows of a (b None) or a*b; a is [G*R, C]."""
+    _rows(a, "a")
+    M, C = a.shape
+    if M % G:
+        raise ValueError("rowgroup_reduce: G must divide M")
+    if b is not None:
+        _rows(b, "b")
+        if b.shape != a.shape or b.dtype != a.dtype:
+            raise ValueError("rowgroup_reduce: a/b mismatch")
+    out = torch.zeros((G, C), dtype=torch.float32, device=a.device)
+    dev, st = _dev_stream(a)
+    _C.call("pb_rowgroup_reduce", _p(a), _p(b), _p(out), G, M // G, C, _dt(a), dev, st)
+    return out
+
+
+# ------------------------------------------------------------------------------ squeeze-excite
+def se_fc_fwd(pool, inv_count, w1, b1, w2, b2):
+    """pool fp32 [G,C] (sums) -> (scale [G,C], hidden [G,Cm])."""
+    G, C = pool.shape
+    Cm = w1.shape[0]
+    _f32(pool, name="pool"); _f32(w1, (Cm, C), "w1"); _f32(w2, (C, Cm), "w2"); _f32(b1, (Cm,), "b1"); _f32(b2, (C,), "b2")
+    scale = torch.empty((G, C), dtype=torch.float32, device=pool.device)
+    hidden = torch.empty((G, Cm), dtype=torch.float32, device=pool.device)
+    dev, st = _dev_stream(pool)
+    _C.call("pb_se_fc_fwd", _p(pool), float(inv_count), _p(w1), _p(b1), _p(w2), _p(b2), _p(scale), _p(hidden), G, C,
+            Cm, dev, st)
+    return scale, hidden
+
+
+def se_fc_bwd(dscale, pool, inv_count, scale, hidden, w1, w2, want_bias=True):
+    """-> (g_shift [G,C], dw1 [Cm,C], db1 [Cm], dw2 [C,Cm], db2 [C])."""
+    G, C = pool.shape
+    Cm = w1.shape[0]
+    for t, shp, n in ((dscale, (G, C), "dscale"), (pool, (G, C), "pool"), (scale, (G, C), "scale"),
+                      (hidden, (G, Cm), "hidden"), (w1, (Cm, C), "w1"), (w2, (C, Cm), "w2")):
+        _f32(t, shp, n)
+    dev_t = pool.device
+    g_shift = torch.empty((G, C), dtype=torch.float32, device=dev_t)
+    flat = torch.zeros(2 * C * Cm + C + Cm, dtype=torch.float32, device=dev_t)
+    dw1, dw2 = flat[:C * Cm].view(Cm, C), flat[C * Cm:2 * C * Cm].view(C, Cm)
+    db1, db2 = flat[2 * C * Cm:2 * C * Cm + Cm], flat[2 * C * Cm + Cm:]
+    work = torch.empty(G * (C + Cm), dtype=torch.float32, device=dev_t)
+    dev, st = _dev_stream(pool)
+    _C.call("pb_se_fc_bwd", _p(dscale), _p(pool), float(inv_count), _p(scale), _p(hidden), _p(w1), _p(w2),
+            _p(g_shift), _p(dw1), _p(db1) if want_bias else None, _p(dw2), _p(db2) if want_bias else None, _p(work),
+            G, C, Cm, dev, st)
+    return g_shift, dw1, (db1 if want_bias else None), dw2, (db2 if want_bias else None)

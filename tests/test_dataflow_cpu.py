@@ -1,0 +1,53 @@
+"""CPU: picklebot_amd's fused forward/backward DATAFLOW (functional.py + modules) checked against
+the reference goldens with the HIP kernels replaced by their CPU mirrors (oracle/kernel_ref.py).
+This is a test-only substitution (monkeypatch); the product has no such switch.  It pins the
+math of the fused backward (BatchNorm / squeeze-excite / dropout-mask algebra, the temporal
+growth quirk) before any GPU time is spent; the -m gpu tests then pin each HIP kernel to its
+mirror and the whole model to the same goldens."""
+import contextlib
+import io
+
+import pytest
+import torch
+
+import picklebot_amd
+import picklebot_amd.functional as PF
+from conftest import check_model_result, compare_full
+from oracle import kernel_ref, protocol
+
+
+@pytest.fixture
+def cpu_kernels(monkeypatch):
+    monkeypatch.setattr(PF, "K", kernel_ref)
+
+
+BLOCKS = [c for c, (cls, _, _) in protocol.BLOCK_CASES.items() if hasattr(picklebot_amd, cls)]
+MODELS = [c for c, (cls, _, _, _) in protocol.MODEL_CASES.items() if hasattr(picklebot_amd, cls)]
+
+
+@pytest.mark.parametrize("case", BLOCKS)
+def test_block_dataflow(case, golden, cpu_kernels):
+    with contextlib.redirect_stdout(io.StringIO()):
+        res = protocol.run_block_case(picklebot_amd, case)
+    bad, worst = compare_full(res, golden("blocks"), case + "/", 1e-5, 1e-5)
+    assert not bad, f"{bad[:5]} worst {worst}"
+
+
+@pytest.mark.parametrize("case", MODELS)
+def test_model_dataflow(case, golden, cpu_kernels):
+    with contextlib.redirect_stdout(io.StringIO()):
+        res = protocol.run_model_case(picklebot_amd, case)
+    gold = golden("model_" + case)
+    bad, worst = check_model_result(res, gold, 1e-5, 1e-5)
+    assert not bad, f"{len(bad)} keys off, first {bad[:5]}, worst {worst}"
+
+
+def test_eval_fold_equals_train_path(cpu_kernels):
+    """Inference folds BN+act into the projection GEMM epilogue; it must equal the unfused path."""
+    from oracle import formula
+    blk = protocol.build_block(picklebot_amd, "bneck_s1_k3_se1").eval()
+    x = formula.tensor("x:fold", (2, 8, 3, 6, 6))
+    with torch.no_grad():
+        y_fold = blk(x)
+    y_full = blk(x.clone().requires_grad_(True))
+    assert torch.allclose(y_fold, y_full, atol=1e-5, rtol=1e-5)
