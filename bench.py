@@ -1,0 +1,168 @@
+"""bench.py - clips/sec of the MobileNetLarge3D training step on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+A step = one pass of the hot path over one batch of synthetic clips: uint8-valued clips already
+resident in HBM as the bf16 channels-last tensor train.py:106 produces, forward under
+autocast(bf16), CrossEntropyLoss, backward, gradient all-reduce over RCCL (N > 1), optimizer step
+(torch fused AdamW - the reference's bitsandbytes AdamW8bit is outside the path).
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the dominant
+kernel family and `cpu_baseline` (the CPU oracle timed on this host, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable copy)
+T, H, W, NCLS = 16, 224, 224, 13
+
+
+def synthetic_batch(batch, device, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    u8 = torch.randint(0, 256, (batch, T, H, W, 3), dtype=torch.uint8, generator=g)
+    labels = torch.randint(0, NCLS, (batch,), generator=g)
+    x = (u8.to(device).permute(0, -1, 1, 2, 3).to(torch.bfloat16) / 255)      # train.py:102-108
+    return x, labels.to(device)
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """The CPU oracle (oracle/torch_ref.py, parity-locked to the reference goldens) on this host:
+    fp32 train-mode fwd+bwd of MobileNetLarge3D, batch 4, same synthetic recipe."""
+    from oracle import torch_ref
+    torch.manual_seed(1234)
+    cores = torch.get_num_threads()
+    m = torch_ref.MobileNetLarge3D(NCLS).train()
+    B = 4
+    g = torch.Generator().manual_seed(1234)
+    x = (torch.randint(0, 256, (B, T, H, W, 3), dtype=torch.uint8, generator=g).permute(0, -1, 1, 2, 3).float() / 255)
+    y = torch.randint(0, NCLS, (B,), generator=g)
+    best, iters, t_start = float("inf"), 0, time.time()
+    while iters < 2 or (time.time() - t_start < seconds_budget and iters < 12):
+        t0 = time.time()
+        m.zero_grad(set_to_none=True)
+        torch.nn.functional.cross_entropy(m(x), y).backward()
+        dt = time.time() - t0
+        if iters > 0:
+            best = min(best, dt)
+        iters += 1
+    return {"value": round(B / best, 3), "unit": "clips/s", "cores": cores, "kind": "port",
+            "sample": f"MobileNetLarge3D fp32 train fwd+bwd, batch {B} x 16x224x224, best of {iters - 1} iterations, "
+                      f"torch {torch.__version__} CPU, os.cpu_count()={os.cpu_count()}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="clips per GPU (BASELINE config: 32)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import picklebot_amd
+    from picklebot_amd import kernels as K
+    from picklebot_amd.parallel import GradReducer, setup_distributed
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    local_rank, rank, _ = setup_distributed("nccl") if world > 1 else (0, 0, 1)
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    torch.manual_seed(1234)                                   # train.py:196
+    model = picklebot_amd.MobileNetLarge3D(NCLS).to(device)
+    model.initialize_weights()                                # train.py:177 (a no-op for this model)
+    model.train()
+    reducer = GradReducer(model) if world > 1 else None
+    opt = torch.optim.AdamW(model.parameters(), lr=3e-4, weight_decay=5e-4, fused=True)
+    x, y = synthetic_batch(args.batch, device, 1234 + rank)
+
+    def step():
+        if reducer is not None:
+            reducer.zero_grad()
+        else:
+            opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):    # train.py:264
+            loss = torch.nn.functional.cross_entropy(model(x).float(), y)
+        loss.backward()
+        if reducer is not None:
+            reducer.finish()
+        opt.step()
+        return loss
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = args.batch * world * args.steps / elapsed
+
+    # ---- per-kernel roofline: the same K steps again with HIP events around every launch --------
+    roofline, families = None, {}
+    if rank == 0:
+        K.start_profile()
+        for _ in range(args.steps):
+            step()
+        prof = K.stop_profile()
+        tot_ms = sum(d["ms"] for d in prof.values())
+        for name, d in sorted(prof.items(), key=lambda kv: -kv[1]["ms"]):
+            gbs = d["bytes"] / 1e9 / (d["ms"] / 1e3) if d["ms"] > 0 else 0.0
+            families[name] = {"launches_per_step": d["launches"] // args.steps, "ms_per_step": round(d["ms"] / args.steps, 4),
+                              "GBps": round(gbs, 1), "frac_hbm": round(gbs / HBM_PEAK_GBS, 4),
+                              "share_of_kernel_time": round(d["ms"] / tot_ms, 4)}
+        dom = next(iter(families))
+        d = prof[dom]
+        ach = d["bytes"] / 1e9 / (d["ms"] / 1e3)
+        roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                    "bytes_per_launch": int(d["bytes"] / d["launches"]), "avg_launch_us": round(d["ms"] / d["launches"] * 1e3, 2),
+                    "launches": d["launches"], "measured_over": f"{args.steps} steps re-run with HIP events around every launch"}
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        out = {
+            "metric": "clips/sec fwd+bwd, MobileNetLarge3D 16x224x224 bf16", "value": round(value, 2), "unit": "clips/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "MobileNetLarge3D (mobilenet_large.json) training step, synthetic 16x224x224 clips",
+                       "clips_per_gpu": args.batch, "global_batch": args.batch * world, "num_classes": NCLS,
+                       "precision": "fp32 params, bf16 activations (autocast)", "parallelism": f"dp{world}",
+                       "step": "fwd + CE loss + bwd + RCCL grad all-reduce (n>1) + fused AdamW",
+                       "weights": "random init (seed 1234)", "loss": round(float(loss.item()), 4)},
+            "roofline": roofline,
+            "kernel_families": families,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -14,6 +14,46 @@ ACT = {"none": _C.ACT_NONE, "relu": _C.ACT_RELU, "leaky_relu": _C.ACT_LEAKY_RELU
        "hardsigmoid": _C.ACT_HSIGMOID, "silu": _C.ACT_SILU}
 
 
+# ---- optional per-launch profiling (bench.py): HIP events recorded on the launch stream -------
+_spans = None
+
+
+def start_profile():
+    """Record (family, algorithmic bytes, start event, end event) for every kernel launch."""
+    global _spans
+    _spans = []
+
+
+def stop_profile():
+    """-> {family: dict(launches, ms, bytes)}; synchronises the device once."""
+    global _spans
+    spans, _spans = _spans, None
+    torch.cuda.synchronize()
+    out = {}
+    for name, nbytes, e0, e1 in spans or []:
+        d = out.setdefault(name, dict(launches=0, ms=0.0, bytes=0))
+        d["launches"] += 1
+        d["ms"] += e0.elapsed_time(e1)
+        d["bytes"] += nbytes
+    return out
+
+
+def _nb(*ts):
+    return sum(t.numel() * t.element_size() for t in ts if t is not None)
+
+
+def _launch(family, nbytes, fn, *args):
+    """Algorithmic bytes = every external input/output tensor once at its stored dtype."""
+    if _spans is None:
+        _C.call(fn, *args)
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    _C.call(fn, *args)
+    e1.record()
+    _spans.append((family, nbytes, e0, e1))
+
+
 def _dt(t):
     if t.dtype == torch.float32:
         return _C.PB_F32
@@ -71,7 +111,7 @@ def pw_fwd(x, w, *, w_transposed=False, in_scale=None, in_shift=None, in_act="no
         _f32(row_scale, (M // rows_per_group, K), "row_scale")
     y = torch.empty((M, N), dtype=x.dtype, device=x.device)
     dev, st = _dev_stream(x)
-    _C.call("pb_pwconv_fwd", _p(x), _p(w), _p(y), M, K, N, w.shape[1], int(w_transposed), _dt(x), _p(in_scale),
+    _launch("pw_gemm_bwd_data" if w_transposed else "pw_gemm_fwd", _nb(x, y, w), "pb_pwconv_fwd", _p(x), _p(w), _p(y), M, K, N, w.shape[1], int(w_transposed), _dt(x), _p(in_scale),
             _p(in_shift), ACT[in_act], float(in_slope), _p(row_scale), int(rows_per_group), _p(out_scale),
             _p(out_shift), ACT[out_act], float(out_slope), _p(stats), dev, st)
     return y
@@ -92,7 +132,7 @@ def pw_bwd_weight(dy, x, dw, *, in_scale=None, in_shift=None, in_act="none", in_
             raise ValueError("pw_bwd_weight: rows_per_group must divide M")
         _f32(row_scale, (M // rows_per_group, K), "row_scale")
     dev, st = _dev_stream(x)
-    _C.call("pb_pwconv_bwd_weight", _p(dy), _p(x), _p(dw), M, K, N, _dt(x), _p(in_scale), _p(in_shift),
+    _launch("pw_wgrad", _nb(dy, x, dw), "pb_pwconv_bwd_weight", _p(dy), _p(x), _p(dw), M, K, N, _dt(x), _p(in_scale), _p(in_shift),
             ACT[in_act], float(in_slope), _p(row_scale), int(rows_per_group), dev, st)
     return dw
 
@@ -133,7 +173,7 @@ def dw_fwd(x, w, kernel, stride, pad_front, pad_back=None, pool=None):
     y = torch.empty((N,) + out + (C,), dtype=x.dtype, device=x.device)
     s = _dw_shape(N, C, (T, H, W), out, kernel, stride, pad_front)
     dev, st = _dev_stream(x)
-    _C.call("pb_dwconv3d_fwd", _p(x), _p(w), _p(y), ctypes.byref(s), _dt(x), _p(pool), dev, st)
+    _launch("dw_fwd", _nb(x, y, w), "pb_dwconv3d_fwd", _p(x), _p(w), _p(y), ctypes.byref(s), _dt(x), _p(pool), dev, st)
     return y
 
 
@@ -145,7 +185,7 @@ def dw_bwd_data(dy, w, in_thw, kernel, stride, pad_front, g_scale=None, g_shift=
     dx = torch.empty((N,) + tuple(in_thw) + (C,), dtype=dy.dtype, device=dy.device)
     s = _dw_shape(N, C, in_thw, (To, Ho, Wo), kernel, stride, pad_front)
     dev, st = _dev_stream(dy)
-    _C.call("pb_dwconv3d_bwd_data", _p(dy), _p(w), _p(dx), ctypes.byref(s), _dt(dy), _p(g_scale), _p(g_shift), dev, st)
+    _launch("dw_bwd_data", _nb(dy, dx, w), "pb_dwconv3d_bwd_data", _p(dy), _p(w), _p(dx), ctypes.byref(s), _dt(dy), _p(g_scale), _p(g_shift), dev, st)
     return dx
 
 
@@ -158,7 +198,7 @@ def dw_bwd_weight(dy, x, dw, kernel, stride, pad_front, g_scale=None, g_shift=No
     _f32(g_scale, (N, C), "g_scale"); _f32(g_shift, (N, C), "g_shift")
     s = _dw_shape(N, C, tuple(x.shape[1:4]), (To, Ho, Wo), kernel, stride, pad_front)
     dev, st = _dev_stream(dy)
-    _C.call("pb_dwconv3d_bwd_weight", _p(dy), _p(x), _p(dw), ctypes.byref(s), _dt(dy), _p(g_scale), _p(g_shift), dev, st)
+    _launch("dw_bwd_weight", _nb(dy, x, dw), "pb_dwconv3d_bwd_weight", _p(dy), _p(x), _p(dw), ctypes.byref(s), _dt(dy), _p(g_scale), _p(g_shift), dev, st)
     return dw
 
 
@@ -189,7 +229,7 @@ def stem_fwd(x, w, bias, kernel, stride, pad, out_dtype, x_scale=1.0, stats=None
     y = torch.empty((x.shape[0],) + out + (cout,), dtype=out_dtype, device=x.device)
     s = _stem_shape(x, cout, out, kernel, stride, pad)
     dev, st = _dev_stream(x)
-    _C.call("pb_stem_conv3d_fwd", _p(x), _XDT[x.dtype], float(x_scale), _p(w), _p(bias), _p(y), ctypes.byref(s),
+    _launch("stem_fwd", _nb(x, y, w), "pb_stem_conv3d_fwd", _p(x), _XDT[x.dtype], float(x_scale), _p(w), _p(bias), _p(y), ctypes.byref(s),
             _dt(y), _p(stats), dev, st)
     return y
 
@@ -200,7 +240,7 @@ def stem_bwd_weight(dy, x, dw, dbias, kernel, stride, pad, x_scale=1.0):
     _f32(dw, (cout, x.shape[1], *kernel), "dw"); _f32(dbias, (cout,), "dbias")
     s = _stem_shape(x, cout, tuple(dy.shape[1:4]), kernel, stride, pad)
     dev, st = _dev_stream(dy)
-    _C.call("pb_stem_conv3d_bwd_weight", _p(dy), _p(x), _XDT[x.dtype], float(x_scale), _p(dw), _p(dbias),
+    _launch("stem_wgrad", _nb(dy, x, dw), "pb_stem_conv3d_bwd_weight", _p(dy), _p(x), _XDT[x.dtype], float(x_scale), _p(dw), _p(dbias),
             ctypes.byref(s), _dt(dy), dev, st)
     return dw
 
@@ -210,7 +250,7 @@ def chan_stats(x, stats):
     _rows(x, "x")
     _f32(stats, (2, x.shape[1]), "stats")
     dev, st = _dev_stream(x)
-    _C.call("pb_chan_stats", _p(x), x.shape[0], x.shape[1], _dt(x), _p(stats), dev, st)
+    _launch("chan_stats", _nb(x), "pb_chan_stats", _p(x), x.shape[0], x.shape[1], _dt(x), _p(stats), dev, st)
     return stats
 
 
@@ -221,7 +261,7 @@ def bn_finalize(stats, count, gamma, beta, eps, momentum, running_mean, running_
     out = torch.empty((4, C), dtype=torch.float32, device=device)
     ref = stats if stats is not None else running_mean
     dev, st = _dev_stream(ref)
-    _C.call("pb_bn_finalize", _p(stats), float(count), _p(gamma), _p(beta), float(eps), float(momentum),
+    _launch("bn_finalize", _nb(out), "pb_bn_finalize", _p(stats), float(count), _p(gamma), _p(beta), float(eps), float(momentum),
             _p(running_mean), _p(running_var), int(use_running), _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]),
             C, dev, st)
     return out[0], out[1], out[2], out[3]
@@ -240,7 +280,7 @@ def affine_act_fwd(x, scale=None, shift=None, act="none", slope=0.0, row_scale=N
         _f32(row_shift, (M // rows_per_group, C), "row_shift")
     y = torch.empty_like(x)
     dev, st = _dev_stream(x)
-    _C.call("pb_affine_act_fwd", _p(x), _p(y), M, C, _dt(x), _p(scale), _p(shift), ACT[act], float(slope),
+    _launch("affine_act_fwd", _nb(x, y), "pb_affine_act_fwd", _p(x), _p(y), M, C, _dt(x), _p(scale), _p(shift), ACT[act], float(slope),
             _p(row_scale), _p(row_shift), int(rows_per_group), _p(stats), dev, st)
     return y
 
@@ -266,7 +306,7 @@ def act_bwd_reduce(dy, z, *, scale=None, shift=None, act="none", slope=0.0, row_
         _f32(row_scale, (M // rows_per_group, C), "row_scale")
     g = torch.empty_like(z) if want_g else None
     dev, st = _dev_stream(z)
-    _C.call("pb_act_bwd_reduce", _p(dy), _p(z), _p(g), M, C, _dt(z), _p(scale), _p(shift), ACT[act], float(slope),
+    _launch("act_bwd_reduce", _nb(dy, z, g), "pb_act_bwd_reduce", _p(dy), _p(z), _p(g), M, C, _dt(z), _p(scale), _p(shift), ACT[act], float(slope),
             _p(row_scale), int(rows_per_group), int(dy_rows_per_group), float(dy_mul), _p(mean), _p(rstd), _p(sums),
             dev, st)
     return g
@@ -278,7 +318,7 @@ def bn_bwd_finalize(sums, count, gamma, mean, rstd, training, want_affine_grads)
     _f32(sums, (2, C), "sums"); _f32(gamma, (C,), "gamma"); _f32(mean, (C,), "mean"); _f32(rstd, (C,), "rstd")
     out = torch.empty((5, C), dtype=torch.float32, device=mean.device)
     dev, st = _dev_stream(mean)
-    _C.call("pb_bn_bwd_finalize", _p(sums), float(count), _p(gamma), _p(mean), _p(rstd), int(training), _p(out[0]),
+    _launch("bn_bwd_finalize", _nb(out), "pb_bn_bwd_finalize", _p(sums), float(count), _p(gamma), _p(mean), _p(rstd), int(training), _p(out[0]),
             _p(out[1]), _p(out[2]), _p(out[3]) if want_affine_grads else None,
             _p(out[4]) if want_affine_grads else None, C, dev, st)
     return out[0], out[1], out[2], (out[3] if want_affine_grads else None), (out[4] if want_affine_grads else None)
@@ -294,7 +334,7 @@ def affine2(g, z, A, B=None, Cc=None):
     _f32(A, (C,), "A"); _f32(B, (C,), "B"); _f32(Cc, (C,), "Cc")
     out = torch.empty_like(g)
     dev, st = _dev_stream(g)
-    _C.call("pb_affine2", _p(g), _p(z), _p(out), M, C, _dt(g), _p(A), _p(B), _p(Cc), dev, st)
+    _launch("affine2", _nb(g, z, out), "pb_affine2", _p(g), _p(z), _p(out), M, C, _dt(g), _p(A), _p(B), _p(Cc), dev, st)
     return out
 
 
@@ -310,7 +350,7 @@ def rowgroup_reduce(a, b, G):
             raise ValueError("rowgroup_reduce: a/b mismatch")
     out = torch.zeros((G, C), dtype=torch.float32, device=a.device)
     dev, st = _dev_stream(a)
-    _C.call("pb_rowgroup_reduce", _p(a), _p(b), _p(out), G, M // G, C, _dt(a), dev, st)
+    _launch("rowgroup_reduce", _nb(a, b, out), "pb_rowgroup_reduce", _p(a), _p(b), _p(out), G, M // G, C, _dt(a), dev, st)
     return out
 
 
@@ -323,7 +363,7 @@ def se_fc_fwd(pool, inv_count, w1, b1, w2, b2):
     scale = torch.empty((G, C), dtype=torch.float32, device=pool.device)
     hidden = torch.empty((G, Cm), dtype=torch.float32, device=pool.device)
     dev, st = _dev_stream(pool)
-    _C.call("pb_se_fc_fwd", _p(pool), float(inv_count), _p(w1), _p(b1), _p(w2), _p(b2), _p(scale), _p(hidden), G, C,
+    _launch("se_fc_fwd", _nb(pool, w1, w2, scale), "pb_se_fc_fwd", _p(pool), float(inv_count), _p(w1), _p(b1), _p(w2), _p(b2), _p(scale), _p(hidden), G, C,
             Cm, dev, st)
     return scale, hidden
 
@@ -342,7 +382,7 @@ def se_fc_bwd(dscale, pool, inv_count, scale, hidden, w1, w2, want_bias=True):
     db1, db2 = flat[2 * C * Cm:2 * C * Cm + Cm], flat[2 * C * Cm + Cm:]
     work = torch.empty(G * (C + Cm), dtype=torch.float32, device=dev_t)
     dev, st = _dev_stream(pool)
-    _C.call("pb_se_fc_bwd", _p(dscale), _p(pool), float(inv_count), _p(scale), _p(hidden), _p(w1), _p(w2),
+    _launch("se_fc_bwd", _nb(pool, w1, w2, dw1, dw2), "pb_se_fc_bwd", _p(dscale), _p(pool), float(inv_count), _p(scale), _p(hidden), _p(w1), _p(w2),
             _p(g_shift), _p(dw1), _p(db1) if want_bias else None, _p(dw2), _p(db2) if want_bias else None, _p(work),
             G, C, Cm, dev, st)
     return g_shift, dw1, (db1 if want_bias else None), dw2, (db2 if want_bias else None)

