@@ -39,6 +39,8 @@ def cpu_baseline(seconds_budget=20.0):
     fp32 train-mode fwd+bwd of MobileNetLarge3D, batch 4, same synthetic recipe."""
     from oracle import torch_ref
     torch.manual_seed(1234)
+    # the GPU box gives one GPU a share of 16 host cores; more threads than that only oversubscribe
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
     cores = torch.get_num_threads()
     m = torch_ref.MobileNetLarge3D(NCLS).train()
     B = 4
@@ -128,6 +130,13 @@ def main():
         for _ in range(args.steps):
             step()
         prof = K.stop_profile()
+        detail = {k: v for k, v in prof.items() if " | " in k}
+        prof = {k: v for k, v in prof.items() if " | " not in k}
+        if os.environ.get("PB_BENCH_DETAIL"):
+            with open(os.environ["PB_BENCH_DETAIL"], "w") as f:
+                for k, d in sorted(detail.items(), key=lambda kv: -kv[1]["ms"]):
+                    f.write("%-90s n=%3d  %8.1f us/launch  %7.1f GB/s\n" % (
+                        k, d["launches"] // args.steps, d["ms"] / d["launches"] * 1e3, d["bytes"] / 1e6 / max(d["ms"], 1e-9)))
         tot_ms = sum(d["ms"] for d in prof.values())
         for name, d in sorted(prof.items(), key=lambda kv: -kv[1]["ms"]):
             gbs = d["bytes"] / 1e9 / (d["ms"] / 1e3) if d["ms"] > 0 else 0.0

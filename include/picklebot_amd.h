@@ -34,7 +34,14 @@ typedef enum {
   PB_ACT_HSIGMOID = 4, PB_ACT_SILU = 5
 } pb_act;
 
-#define PB_ABI_VERSION 1
+#define PB_ABI_VERSION 2
+
+/* Per-channel statistics buffers (`stats`, `sums` below) are PB_STAT_REPLICAS replicas of [2][C]
+ * fp32, layout [replica][2][C], zero-filled by the caller.  A workgroup adds its partial sums into
+ * replica (workgroup id % PB_STAT_REPLICAS): same-address float atomics serialise at the memory side
+ * (~25 ns each on MI355X), so no address may see more than a few dozen of them per launch.
+ * pb_bn_finalize / pb_bn_bwd_finalize sum the replicas. */
+#define PB_STAT_REPLICAS 16
 int pb_abi_version(void);
 /* Last error message of the calling thread ("" if none). */
 const char* pb_last_error(void);

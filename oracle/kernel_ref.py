@@ -11,6 +11,8 @@ Each mirror is itself pinned by tests/test_kernel_ref_cpu.py against torch.nn.fu
 import torch
 import torch.nn.functional as F
 
+REPL = 16   # PB_STAT_REPLICAS: stats buffers are [REPL, 2, C]; the mirror adds into replica 0
+
 
 def _act(x, act, slope=0.0):
     if act == "none":
@@ -69,8 +71,8 @@ def pw_fwd(x, w, *, w_transposed=False, in_scale=None, in_shift=None, in_act="no
         acc = acc + out_shift
     y = _act(acc, out_act, out_slope).to(x.dtype)
     if stats is not None:
-        stats[0] += y.float().sum(0)
-        stats[1] += (y.float() ** 2).sum(0)
+        stats[0, 0] += y.float().sum(0)
+        stats[0, 1] += (y.float() ** 2).sum(0)
     return y
 
 
@@ -143,8 +145,8 @@ def stem_fwd(x, w, bias, kernel, stride, pad, out_dtype, x_scale=1.0, stats=None
     y = F.conv3d(xf, w, bias, stride=stride, padding=pad).permute(0, 2, 3, 4, 1).contiguous().to(out_dtype)
     if stats is not None:
         yf = y.float().reshape(-1, y.shape[-1])
-        stats[0] += yf.sum(0)
-        stats[1] += (yf ** 2).sum(0)
+        stats[0, 0] += yf.sum(0)
+        stats[0, 1] += (yf ** 2).sum(0)
     return y
 
 
@@ -160,8 +162,8 @@ def stem_bwd_weight(dy, x, dw, dbias, kernel, stride, pad, x_scale=1.0):
 
 
 def chan_stats(x, stats):
-    stats[0] += x.float().sum(0)
-    stats[1] += (x.float() ** 2).sum(0)
+    stats[0, 0] += x.float().sum(0)
+    stats[0, 1] += (x.float() ** 2).sum(0)
     return stats
 
 
@@ -169,8 +171,9 @@ def bn_finalize(stats, count, gamma, beta, eps, momentum, running_mean, running_
     if use_running:
         mean, var = running_mean.double(), running_var.double()
     else:
-        mean = stats[0].double() / count
-        var = (stats[1].double() / count - mean * mean).clamp_min(0)
+        st = stats.double().sum(0)
+        mean = st[0] / count
+        var = (st[1] / count - mean * mean).clamp_min(0)
         if running_mean is not None:
             running_mean.copy_(((1 - momentum) * running_mean.double() + momentum * mean).float())
         if running_var is not None:
@@ -196,8 +199,8 @@ def affine_act_fwd(x, scale=None, shift=None, act="none", slope=0.0, row_scale=N
         y = y + row_shift.repeat_interleave(rows_per_group, 0)
     y = y.to(x.dtype)
     if stats is not None:
-        stats[0] += y.float().sum(0)
-        stats[1] += (y.float() ** 2).sum(0)
+        stats[0, 0] += y.float().sum(0)
+        stats[0, 1] += (y.float() ** 2).sum(0)
     return y
 
 
@@ -223,8 +226,8 @@ def act_bwd_reduce(dy, z, *, scale=None, shift=None, act="none", slope=0.0, row_
             xhat = xhat - mean
         if rstd is not None:
             xhat = xhat * rstd
-        sums[0] += gr.sum(0)
-        sums[1] += (gr * xhat).sum(0)
+        sums[0, 0] += gr.sum(0)
+        sums[0, 1] += (gr * xhat).sum(0)
     return g.to(z.dtype) if want_g else None
 
 
@@ -232,7 +235,7 @@ def bn_bwd_finalize(sums, count, gamma, mean, rstd, training, want_affine_grads)
     C = mean.shape[0]
     g = gamma.double() if gamma is not None else torch.ones(C, dtype=torch.float64)
     r, mu = rstd.double(), mean.double()
-    sg, sgx = sums[0].double(), sums[1].double()
+    sg, sgx = sums.double().sum(0)
     A = g * r
     if training:
         B = -g * r * r * (sgx / count)

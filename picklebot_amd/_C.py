@@ -12,7 +12,8 @@ LIB_PATH = os.path.join(_HERE, "lib", "libpicklebot_amd.so")
 
 PB_F32, PB_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY_RELU, ACT_HSWISH, ACT_HSIGMOID, ACT_SILU = range(6)
-ABI_VERSION = 1
+ABI_VERSION = 2
+STAT_REPLICAS = 16
 
 
 class DwShape(Structure):

@@ -2,9 +2,9 @@
 //
 // Fast path ("strip" kernels) for Bottleneck3D's (1,k,k) filters, k in {3,5}, spatial stride
 // s in {1,2} (mobilenet.py:67-75).  A thread owns CH channels (16 B or 8 B per access) of one
-// output column and TH=4 vertically adjacent outputs, keeps the k*k*CH filter taps in registers
+// output column and TH=4 vertically adjacent outputs, keeps the k*k*CH filter taps of its channel chunk in
 // and walks the (TH-1)*s+k input rows once: each row it loads feeds up to k/s outputs from
-// registers.  Lanes run along (channel-vector, then x), so every access of a wave is one
+// LDS.  Lanes run along (channel-vector, then x), so every access of a wave is one
 // contiguous span of the NDHWC row.  The temporal axis is only an index map (kernel extent 1):
 // frame t_in = t_out*t_mul + t_off; output frames that map outside the clip are the reference's
 // zero frames (stride/padding applied to T, SURVEY "temporal growth quirk") and are written as
@@ -71,11 +71,45 @@ struct StripArgs {
 };
 
 constexpr int TH = 4;
+constexpr int GR = 3;          // input rows fetched per batch of loads
+
+// CH elements of T as one register block (16 B / 8 B / 32 B load)
+template <typename T, int CH> using RawVec = T __attribute__((ext_vector_type(CH)));
+
+template <typename T, int CH>
+__device__ __forceinline__ RawVec<T, CH> raw_load(const T* p) {
+  return *reinterpret_cast<const RawVec<T, CH>*>(p);
+}
+
+// One batch of input rows [R0, R0+GR) of a strip: K clamped, unconditional loads per row, so the
+// whole batch is in flight at once (no branch between a load and the next); validity is applied
+// as a select when the values are consumed.
+template <typename T, int K, int S, int CH>
+struct RowBatch {
+  RawVec<T, CH> v[GR][K];
+  template <int R0>
+  __device__ __forceinline__ void load(const T* fbase, int hs0, int ws0, int Hs, int Ws, int C) {
+    constexpr int RH = (TH - 1) * S + K;
+#pragma unroll
+    for (int g = 0; g < GR; ++g) {
+      if (R0 + g < RH) {
+        const int hs = min(max(hs0 + R0 + g, 0), Hs - 1);
+#pragma unroll
+        for (int kw = 0; kw < K; ++kw) {
+          const int ws = min(max(ws0 + kw, 0), Ws - 1);
+          v[g][kw] = raw_load<T, CH>(fbase + ((int64_t)hs * Ws + ws) * C);
+        }
+      }
+    }
+  }
+};
 
 template <typename T, int K, int S, int CH>
 __global__ __launch_bounds__(256) void dw_strip_fwd_kernel(StripArgs a) {
   __shared__ __attribute__((aligned(16))) float wl[K * K * 32 * CH];   // [tap][CVB*CH] filter taps of this channel chunk
   __shared__ float red[32 * 8];
+  constexpr int RH = (TH - 1) * S + K;
+  constexpr int NB = (RH + GR - 1) / GR;
   const int tid = threadIdx.x;
   const int cvl = tid % a.CVB, p = tid / a.CVB;
   const int cv = blockIdx.y * a.CVB + cvl;
@@ -84,7 +118,7 @@ __global__ __launch_bounds__(256) void dw_strip_fwd_kernel(StripArgs a) {
   const int n = z / a.Tdst, td = z - n * a.Tdst;
   const int ts = td * a.t_mul + a.t_off;
   const bool frame_ok = ts >= 0 && ts < a.Tsrc;
-  const int c0 = cv * CH;
+  const int c0 = lane_ok ? cv * CH : 0;
   const int CW = a.CVB * CH;                 // channels of this chunk
   const T* src = (const T*)a.src;
   T* dst = (T*)a.dst;
@@ -103,60 +137,76 @@ __global__ __launch_bounds__(256) void dw_strip_fwd_kernel(StripArgs a) {
 
   float gs[CH], gh[CH], psum[CH];
 #pragma unroll
-  for (int i = 0; i < CH; ++i) {
-    gs[i] = (a.g_scale && lane_ok) ? a.g_scale[(int64_t)n * a.C + c0 + i] : 1.f;
-    gh[i] = (a.g_shift && lane_ok) ? a.g_shift[(int64_t)n * a.C + c0 + i] : 0.f;
-    psum[i] = 0.f;
+  for (int i = 0; i < CH; ++i) { gs[i] = 1.f; gh[i] = 0.f; psum[i] = 0.f; }
+  if (a.g_scale) {
+#pragma unroll
+    for (int q = 0; q < CH / 4; ++q) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(a.g_scale + (int64_t)n * a.C + c0 + 4 * q);
+      gs[4 * q] = t[0]; gs[4 * q + 1] = t[1]; gs[4 * q + 2] = t[2]; gs[4 * q + 3] = t[3];
+    }
   }
-  const bool has_g = a.g_scale || a.g_shift;
+  if (a.g_shift) {
+#pragma unroll
+    for (int q = 0; q < CH / 4; ++q) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(a.g_shift + (int64_t)n * a.C + c0 + 4 * q);
+      gh[4 * q] = t[0]; gh[4 * q + 1] = t[1]; gh[4 * q + 2] = t[2]; gh[4 * q + 3] = t[3];
+    }
+  }
   const T* fbase = src + ((int64_t)n * a.Tsrc + (frame_ok ? ts : 0)) * a.Hs * a.Ws * a.C + c0;
+  const int npix = a.HB * a.Wd;
 
   for (int xb = blockIdx.x; xb < a.xblocks; xb += gridDim.x) {
     const int pix = xb * a.P + p;
-    const bool active = lane_ok && pix < a.HB * a.Wd;
-    const int hb = pix / a.Wd, wd = pix - hb * a.Wd;
+    const bool active = lane_ok && pix < npix;
+    const int pixc = min(pix, npix - 1);                 // inactive lanes shadow a valid strip
+    const int hb = pixc / a.Wd, wd = pixc - hb * a.Wd;
     const int hd0 = hb * TH;
+    const int hs0 = hd0 * S - a.pad, ws0 = wd * S - a.pad;
     float acc[TH][CH];
 #pragma unroll
     for (int j = 0; j < TH; ++j)
 #pragma unroll
       for (int i = 0; i < CH; ++i) acc[j][i] = 0.f;
 
-    if (active && frame_ok) {
-      constexpr int RH = (TH - 1) * S + K;
+    if (frame_ok) {
+      RowBatch<T, K, S, CH> bat[2];
+      bat[0].template load<0>(fbase, hs0, ws0, a.Hs, a.Ws, a.C);
 #pragma unroll
-      for (int r = 0; r < RH; ++r) {
-        const int hs = hd0 * S - a.pad + r;
-        if (hs < 0 || hs >= a.Hs) continue;
-        float in[K][CH];
-#pragma unroll
-        for (int kw = 0; kw < K; ++kw) {
-          const int ws = wd * S - a.pad + kw;
-          if (ws >= 0 && ws < a.Ws) {
-            load_ch<T, CH>(fbase + ((int64_t)hs * a.Ws + ws) * a.C, in[kw]);
-            if (has_g) {
-#pragma unroll
-              for (int i = 0; i < CH; ++i) in[kw][i] = in[kw][i] * gs[i] + gh[i];
-            }
-          } else {
-#pragma unroll
-            for (int i = 0; i < CH; ++i) in[kw][i] = 0.f;
-          }
+      for (int b = 0; b < NB; ++b) {
+        // issue the next batch before consuming this one
+        if (b + 1 < NB) {
+          if (b == 0) bat[1].template load<GR>(fbase, hs0, ws0, a.Hs, a.Ws, a.C);
+          if (b == 1) bat[0].template load<2 * GR>(fbase, hs0, ws0, a.Hs, a.Ws, a.C);
+          if (b == 2) bat[1].template load<3 * GR>(fbase, hs0, ws0, a.Hs, a.Ws, a.C);
         }
 #pragma unroll
-        for (int j = 0; j < TH; ++j) {
-          const int kh = r - j * S;            // compile-time after unrolling
-          if (kh >= 0 && kh < K) {
+        for (int g = 0; g < GR; ++g) {
+          const int r = b * GR + g;
+          if (r < RH) {
+            const bool row_ok = (hs0 + r >= 0) && (hs0 + r < a.Hs);
+            float in[K][CH];
 #pragma unroll
             for (int kw = 0; kw < K; ++kw) {
-              float wv[CH];
+              const bool ok = row_ok && (ws0 + kw >= 0) && (ws0 + kw < a.Ws);
 #pragma unroll
-              for (int q = 0; q < CH / 4; ++q) {
-                const f32x4 t = *reinterpret_cast<const f32x4*>(&wl[(kh * K + kw) * CW + cvl * CH + 4 * q]);
-                wv[4 * q] = t[0]; wv[4 * q + 1] = t[1]; wv[4 * q + 2] = t[2]; wv[4 * q + 3] = t[3];
+              for (int i = 0; i < CH; ++i) in[kw][i] = ok ? (to_f32(bat[b & 1].v[g][kw][i]) * gs[i] + gh[i]) : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < TH; ++j) {
+              const int kh = r - j * S;            // compile-time after unrolling
+              if (kh >= 0 && kh < K) {
+#pragma unroll
+                for (int kw = 0; kw < K; ++kw) {
+                  float wv[CH];
+#pragma unroll
+                  for (int q = 0; q < CH / 4; ++q) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(&wl[(kh * K + kw) * CW + cvl * CH + 4 * q]);
+                    wv[4 * q] = t[0]; wv[4 * q + 1] = t[1]; wv[4 * q + 2] = t[2]; wv[4 * q + 3] = t[3];
+                  }
+#pragma unroll
+                  for (int i = 0; i < CH; ++i) acc[j][i] += in[kw][i] * wv[i];
+                }
               }
-#pragma unroll
-              for (int i = 0; i < CH; ++i) acc[j][i] += in[kw][i] * wv[i];
             }
           }
         }
@@ -195,14 +245,17 @@ __global__ __launch_bounds__(256) void dw_strip_fwd_kernel(StripArgs a) {
 template <typename T, int K, int S, int CH>
 __global__ __launch_bounds__(256) void dw_strip_wgrad_kernel(StripArgs a) {
   __shared__ float red[K * K * 32 * CH];
+  constexpr int RH = (TH - 1) * S + K;
+  constexpr int NB = (RH + GR - 1) / GR;
   const int tid = threadIdx.x;
   const int cvl = tid % a.CVB, p = tid / a.CVB;
   const int cv = blockIdx.y * a.CVB + cvl;
   const bool lane_ok = p < a.P && cv < a.CV;
-  const int c0 = cv * CH;
+  const int c0 = lane_ok ? cv * CH : 0;
+  const int CW = a.CVB * CH;
   const T* dy = (const T*)a.dst;
   const T* x = (const T*)a.x;
-  for (int i = tid; i < K * K * a.CVB * CH; i += 256) red[i] = 0.f;
+  for (int i = tid; i < K * K * CW; i += 256) red[i] = 0.f;
   __syncthreads();
 
   float acc[K][K][CH];
@@ -212,64 +265,84 @@ __global__ __launch_bounds__(256) void dw_strip_wgrad_kernel(StripArgs a) {
     for (int kw = 0; kw < K; ++kw)
 #pragma unroll
       for (int i = 0; i < CH; ++i) acc[kh][kw][i] = 0.f;
-  const bool has_g = a.g_scale || a.g_shift;
+  const int npix = a.HB * a.Wd;
 
   for (int64_t it = blockIdx.x; it < a.items; it += gridDim.x) {
     const int z = (int)(it / a.xblocks);
     const int xb = (int)(it - (int64_t)z * a.xblocks);
     const int n = z / a.Tdst, td = z - n * a.Tdst;
     const int ts = td * a.t_mul + a.t_off;
-    if (ts < 0 || ts >= a.Tsrc) continue;        // zero frame: no dependence on x
+    if (ts < 0 || ts >= a.Tsrc) continue;        // zero frame: no dependence on x (uniform branch)
     const int pix = xb * a.P + p;
-    if (!lane_ok || pix >= a.HB * a.Wd) continue;
-    const int hb = pix / a.Wd, wd = pix - hb * a.Wd;
+    const bool active = lane_ok && pix < npix;
+    const int pixc = min(pix, npix - 1);
+    const int hb = pixc / a.Wd, wd = pixc - hb * a.Wd;
     const int hd0 = hb * TH;
+    const int hs0 = hd0 * S - a.pad, ws0 = wd * S - a.pad;
+    const T* fbase = x + ((int64_t)n * a.Tsrc + ts) * a.Hs * a.Ws * a.C + c0;
+    RowBatch<T, K, S, CH> bat[2];
+    bat[0].template load<0>(fbase, hs0, ws0, a.Hs, a.Ws, a.C);
+    RawVec<T, CH> graw[TH];
+#pragma unroll
+    for (int j = 0; j < TH; ++j) {
+      const int hd = min(hd0 + j, a.Hd - 1);
+      graw[j] = raw_load<T, CH>(dy + (((int64_t)z * a.Hd + hd) * a.Wd + wd) * a.C + c0);
+    }
+    // squeeze-excite backward rides on the gradient load: g = dy*g_scale[n,c] + g_shift[n,c]
+    // (one vector read per item - never per element, that would serialise 2*TH*CH L2 round trips)
     float gs[CH], gh[CH];
 #pragma unroll
-    for (int i = 0; i < CH; ++i) {
-      gs[i] = a.g_scale ? a.g_scale[(int64_t)n * a.C + c0 + i] : 1.f;
-      gh[i] = a.g_shift ? a.g_shift[(int64_t)n * a.C + c0 + i] : 0.f;
+    for (int i = 0; i < CH; ++i) { gs[i] = 1.f; gh[i] = 0.f; }
+    if (a.g_scale) {
+#pragma unroll
+      for (int q = 0; q < CH / 4; ++q) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(a.g_scale + (int64_t)n * a.C + c0 + 4 * q);
+        gs[4 * q] = t[0]; gs[4 * q + 1] = t[1]; gs[4 * q + 2] = t[2]; gs[4 * q + 3] = t[3];
+      }
+    }
+    if (a.g_shift) {
+#pragma unroll
+      for (int q = 0; q < CH / 4; ++q) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(a.g_shift + (int64_t)n * a.C + c0 + 4 * q);
+        gh[4 * q] = t[0]; gh[4 * q + 1] = t[1]; gh[4 * q + 2] = t[2]; gh[4 * q + 3] = t[3];
+      }
     }
     float g[TH][CH];
 #pragma unroll
     for (int j = 0; j < TH; ++j) {
-      const int hd = hd0 + j;
-      if (hd < a.Hd) {
-        load_ch<T, CH>(dy + (((int64_t)z * a.Hd + hd) * a.Wd + wd) * a.C + c0, g[j]);
-        if (has_g) {
+      const bool ok = active && (hd0 + j < a.Hd);
 #pragma unroll
-          for (int i = 0; i < CH; ++i) g[j][i] = g[j][i] * gs[i] + gh[i];
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < CH; ++i) g[j][i] = 0.f;
-      }
+      for (int i = 0; i < CH; ++i) g[j][i] = ok ? (to_f32(graw[j][i]) * gs[i] + gh[i]) : 0.f;
     }
-    const T* fbase = x + ((int64_t)n * a.Tsrc + ts) * a.Hs * a.Ws * a.C + c0;
-    constexpr int RH = (TH - 1) * S + K;
 #pragma unroll
-    for (int r = 0; r < RH; ++r) {
-      const int hs = hd0 * S - a.pad + r;
-      if (hs < 0 || hs >= a.Hs) continue;
-      float in[K][CH];
-#pragma unroll
-      for (int kw = 0; kw < K; ++kw) {
-        const int ws = wd * S - a.pad + kw;
-        if (ws >= 0 && ws < a.Ws) {
-          load_ch<T, CH>(fbase + ((int64_t)hs * a.Ws + ws) * a.C, in[kw]);
-        } else {
-#pragma unroll
-          for (int i = 0; i < CH; ++i) in[kw][i] = 0.f;
-        }
+    for (int b = 0; b < NB; ++b) {
+      if (b + 1 < NB) {
+        if (b == 0) bat[1].template load<GR>(fbase, hs0, ws0, a.Hs, a.Ws, a.C);
+        if (b == 1) bat[0].template load<2 * GR>(fbase, hs0, ws0, a.Hs, a.Ws, a.C);
+        if (b == 2) bat[1].template load<3 * GR>(fbase, hs0, ws0, a.Hs, a.Ws, a.C);
       }
 #pragma unroll
-      for (int j = 0; j < TH; ++j) {
-        const int kh = r - j * S;
-        if (kh >= 0 && kh < K) {
+      for (int gi = 0; gi < GR; ++gi) {
+        const int r = b * GR + gi;
+        if (r < RH) {
+          const bool row_ok = (hs0 + r >= 0) && (hs0 + r < a.Hs);
+          float in[K][CH];
 #pragma unroll
-          for (int kw = 0; kw < K; ++kw)
+          for (int kw = 0; kw < K; ++kw) {
+            const bool ok = row_ok && (ws0 + kw >= 0) && (ws0 + kw < a.Ws);
 #pragma unroll
-            for (int i = 0; i < CH; ++i) acc[kh][kw][i] += g[j][i] * in[kw][i];
+            for (int i = 0; i < CH; ++i) in[kw][i] = ok ? to_f32(bat[b & 1].v[gi][kw][i]) : 0.f;
+          }
+#pragma unroll
+          for (int j = 0; j < TH; ++j) {
+            const int kh = r - j * S;
+            if (kh >= 0 && kh < K) {
+#pragma unroll
+              for (int kw = 0; kw < K; ++kw)
+#pragma unroll
+                for (int i = 0; i < CH; ++i) acc[kh][kw][i] += g[j][i] * in[kw][i];
+            }
+          }
         }
       }
     }
@@ -280,13 +353,137 @@ __global__ __launch_bounds__(256) void dw_strip_wgrad_kernel(StripArgs a) {
 #pragma unroll
       for (int kw = 0; kw < K; ++kw)
 #pragma unroll
-        for (int i = 0; i < CH; ++i) atomicAdd(&red[(kh * K + kw) * (a.CVB * CH) + cvl * CH + i], acc[kh][kw][i]);
+        for (int i = 0; i < CH; ++i) atomicAdd(&red[(kh * K + kw) * CW + cvl * CH + i], acc[kh][kw][i]);
   }
   __syncthreads();
-  for (int i = tid; i < K * K * a.CVB * CH; i += 256) {
-    const int tap = i / (a.CVB * CH), cl = i - tap * (a.CVB * CH);
-    const int c = blockIdx.y * a.CVB * CH + cl;
-    if (c < a.C && red[i] != 0.f) atomicAdd(a.dw + (int64_t)c * (K * K) + tap, red[i]);
+  // the chunk's [channel][tap] block is contiguous in dw: consecutive threads -> consecutive floats
+  const int cbase = blockIdx.y * CW;
+  for (int i = tid; i < K * K * CW; i += 256) {
+    const int cl = i / (K * K), tap = i - cl * (K * K);
+    if (cbase + cl < a.C) atomicAdd(a.dw + (int64_t)cbase * (K * K) + i, red[tap * CW + cl]);
+  }
+}
+
+// Backward-data for spatial stride 2 (the four stride-2 bottlenecks): a thread owns CH channels of
+// a 2x2 block of dx.  Output parity fixes which taps contribute (compile-time after unrolling),
+// and the whole block reads one NRxNR patch of dy (2x2 for k=3, 3x3 for k=5): 1-2.25 loads per
+// output instead of k*k masked ones.  dx frames that no output frame reads (t+pt not a multiple of
+// the temporal stride) are written as zeros.
+template <typename T, int K, int CH>
+__global__ __launch_bounds__(256) void dw_strip_bwd_s2_kernel(StripArgs a) {
+  __shared__ __attribute__((aligned(16))) float wl[K * K * 32 * CH];
+  constexpr int P = K / 2;
+  constexpr int LO = (P - (K - 1)) / 2;       // ceil of a non-positive half (C++ truncates toward zero): 0 for k=3, -1 for k=5
+  constexpr int HI = (1 + P) / 2;
+  constexpr int NR = HI - LO + 1;
+  const int tid = threadIdx.x;
+  const int cvl = tid % a.CVB, p = tid / a.CVB;
+  const int cv = blockIdx.y * a.CVB + cvl;
+  const bool lane_ok = p < a.P && cv < a.CV;
+  const int c0 = lane_ok ? cv * CH : 0;
+  const int CW = a.CVB * CH;
+  const T* dy = (const T*)a.src;      // [N, Tsrc, Hs, Ws, C]  (gradient of the conv output)
+  T* dx = (T*)a.dst;                  // [N, Tdst, Hd, Wd, C]  (gradient of the conv input)
+  {
+    const int cbase = blockIdx.y * CW;
+    for (int i = tid; i < CW * K * K; i += 256) {
+      const int cl = i / (K * K), tap = i - cl * (K * K);
+      wl[tap * CW + cl] = (cbase + cl < a.C) ? a.w[(int64_t)(cbase + cl) * (K * K) + tap] : 0.f;
+    }
+  }
+  __syncthreads();
+  const int HA = (a.Hd + 1) / 2, WB = (a.Wd + 1) / 2;
+  const int nblk = HA * WB;
+  for (int64_t it = blockIdx.x; it < a.items; it += gridDim.x) {
+    const int z = (int)(it / a.xblocks);
+    const int xb = (int)(it - (int64_t)z * a.xblocks);
+    const int n = z / a.Tdst, td = z - n * a.Tdst;
+    // temporal map of the forward conv: t_in = t_out*t_mul - t_off  =>  t_out = (t_in + t_off)/t_mul
+    const int tn = td + a.t_off;
+    const bool frame_ok = tn >= 0 && (tn % a.t_mul) == 0 && (tn / a.t_mul) < a.Tsrc;
+    const int ts = frame_ok ? tn / a.t_mul : 0;
+    const int blk = xb * a.P + p;
+    const bool active = lane_ok && blk < nblk;
+    const int blkc = min(blk, nblk - 1);
+    const int ba = blkc / WB, bb = blkc - ba * WB;
+    float gs[CH], gh[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) { gs[i] = 1.f; gh[i] = 0.f; }
+    if (a.g_scale) {
+#pragma unroll
+      for (int q = 0; q < CH / 4; ++q) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(a.g_scale + (int64_t)n * a.C + c0 + 4 * q);
+        gs[4 * q] = t[0]; gs[4 * q + 1] = t[1]; gs[4 * q + 2] = t[2]; gs[4 * q + 3] = t[3];
+      }
+    }
+    if (a.g_shift) {
+#pragma unroll
+      for (int q = 0; q < CH / 4; ++q) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(a.g_shift + (int64_t)n * a.C + c0 + 4 * q);
+        gh[4 * q] = t[0]; gh[4 * q + 1] = t[1]; gh[4 * q + 2] = t[2]; gh[4 * q + 3] = t[3];
+      }
+    }
+    float out[2][2][CH];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int v = 0; v < 2; ++v)
+#pragma unroll
+        for (int i = 0; i < CH; ++i) out[u][v][i] = 0.f;
+    if (frame_ok) {
+      const T* fbase = dy + ((int64_t)n * a.Tsrc + ts) * a.Hs * a.Ws * a.C + c0;
+      RawVec<T, CH> raw[NR][NR];
+#pragma unroll
+      for (int dr = 0; dr < NR; ++dr) {
+        const int ho = min(max(ba + LO + dr, 0), a.Hs - 1);
+#pragma unroll
+        for (int dc = 0; dc < NR; ++dc) {
+          const int wo = min(max(bb + LO + dc, 0), a.Ws - 1);
+          raw[dr][dc] = raw_load<T, CH>(fbase + ((int64_t)ho * a.Ws + wo) * a.C);
+        }
+      }
+      float pt[NR][NR][CH];
+#pragma unroll
+      for (int dr = 0; dr < NR; ++dr)
+#pragma unroll
+        for (int dc = 0; dc < NR; ++dc) {
+          const bool ok = (ba + LO + dr >= 0) && (ba + LO + dr < a.Hs) && (bb + LO + dc >= 0) && (bb + LO + dc < a.Ws);
+#pragma unroll
+          for (int i = 0; i < CH; ++i) pt[dr][dc][i] = ok ? (to_f32(raw[dr][dc][i]) * gs[i] + gh[i]) : 0.f;
+        }
+#pragma unroll
+      for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+        for (int kh = 0; kh < K; ++kh) {
+          if (((ph + P + kh) & 1) != 0) continue;
+          const int dr = (ph + P - kh) / 2 - LO;          // exact: numerator is even
+#pragma unroll
+          for (int pw = 0; pw < 2; ++pw)
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw) {
+              if (((pw + P + kw) & 1) != 0) continue;
+              const int dc = (pw + P - kw) / 2 - LO;
+              float wv[CH];
+#pragma unroll
+              for (int q = 0; q < CH / 4; ++q) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(&wl[(kh * K + kw) * CW + cvl * CH + 4 * q]);
+                wv[4 * q] = t[0]; wv[4 * q + 1] = t[1]; wv[4 * q + 2] = t[2]; wv[4 * q + 3] = t[3];
+              }
+#pragma unroll
+              for (int i = 0; i < CH; ++i) out[ph][pw][i] += pt[dr][dc][i] * wv[i];
+            }
+        }
+    }
+    if (active) {
+#pragma unroll
+      for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+        for (int pw = 0; pw < 2; ++pw) {
+          const int hi = 2 * ba + ph, wi = 2 * bb + pw;
+          if (hi < a.Hd && wi < a.Wd)
+            store_ch<T, CH>(dx + (((int64_t)z * a.Hd + hi) * a.Wd + wi) * a.C + c0, out[ph][pw]);
+        }
+    }
   }
 }
 
@@ -484,8 +681,10 @@ void launch_strip_wgrad(StripArgs a, hipStream_t st) {
   a.xblocks = (int)pb_cdiv((int64_t)a.HB * a.Wd, a.P);
   a.items = (int64_t)a.N * a.Tdst * a.xblocks;
   const int chunks = (int)pb_cdiv(a.CV, a.CVB);
-  int64_t gx = pb_cdiv(2048, chunks);
-  if (gx > a.items) gx = a.items;
+  // persistent grid of ~1024 workgroups; gx is also the number of atomic writers per dw element
+  int64_t gx = pb_cdiv(1024, chunks);
+  // every workgroup pays a fixed flush (k*k*CW LDS + global atomics): give it >= 8 items
+  if (gx > pb_cdiv(a.items, 8)) gx = pb_cdiv(a.items, 8);
   if (gx < 1) gx = 1;
   dim3 grid((unsigned)gx, (unsigned)chunks);
   hipLaunchKernelGGL((dw_strip_wgrad_kernel<T, K, S, CH>), grid, dim3(256), 0, st, a);
@@ -518,9 +717,10 @@ int check_shape(const pb_dwconv_shape* s, const char* who) {
                "%s: non-positive dimension", who);
   PB_CHECK_ARG(s->kt > 0 && s->kh > 0 && s->kw > 0 && s->st > 0 && s->sh > 0 && s->sw > 0 && s->pt >= 0 &&
                s->ph >= 0 && s->pw >= 0, "%s: bad kernel/stride/padding", who);
-  // the output extents must be reachable: last output's first tap must start inside the padded input
-  PB_CHECK_ARG((s->To - 1) * s->st - s->pt < s->Ti && (s->Ho - 1) * s->sh - s->ph < s->Hi &&
-               (s->Wo - 1) * s->sw - s->pw < s->Wi, "%s: output extent inconsistent with input/stride/padding", who);
+  // the last output's first tap must start inside the input padded by at most `front` at the back
+  // (the reference's (1,k,k) filters with padding on T produce whole zero frames there)
+  PB_CHECK_ARG((s->To - 1) * s->st - s->pt < s->Ti + s->pt && (s->Ho - 1) * s->sh - s->ph < s->Hi + s->ph &&
+               (s->Wo - 1) * s->sw - s->pw < s->Wi + s->pw, "%s: output extent inconsistent with input/stride/padding", who);
   return 0;
 }
 
@@ -578,6 +778,31 @@ extern "C" int pb_dwconv3d_bwd_data(const void* dy, const float* w, void* dx, co
     a.g_scale = g_scale; a.g_shift = g_shift;
     int rc = dtype == PB_BF16 ? dispatch_strip<bf16_t, false>(a, s->kh, 1, st) : dispatch_strip<float, false>(a, s->kh, 1, st);
     if (rc) return rc;
+  } else if (strip_ok(*s) && s->sh == 2 && s->ph == s->kh / 2) {
+    StripArgs a = {};
+    a.src = dy; a.w = w; a.dst = dx; a.N = s->N; a.C = s->C;
+    a.Tsrc = s->To; a.Hs = s->Ho; a.Ws = s->Wo; a.Tdst = s->Ti; a.Hd = s->Hi; a.Wd = s->Wi;
+    a.t_mul = s->st; a.t_off = s->pt; a.g_scale = g_scale; a.g_shift = g_shift;
+    const bool bf = dtype == PB_BF16;
+    const int ch = (bf && s->kh == 3 && s->C % 8 == 0) ? 8 : 4;
+    a.CV = a.C / ch;
+    a.CVB = pick_cvb(a.CV);
+    a.P = 256 / a.CVB;
+    const int64_t nblk = (int64_t)((s->Hi + 1) / 2) * ((s->Wi + 1) / 2);
+    a.xblocks = (int)pb_cdiv(nblk, a.P);
+    a.items = (int64_t)s->N * s->Ti * a.xblocks;
+    const int chunks = (int)pb_cdiv(a.CV, a.CVB);
+    int64_t gx = pb_cdiv(2048, chunks);
+    if (gx > a.items) gx = a.items;
+    dim3 grid((unsigned)gx, (unsigned)chunks);
+    if (bf) {
+      if (s->kh == 3 && ch == 8) hipLaunchKernelGGL((dw_strip_bwd_s2_kernel<bf16_t, 3, 8>), grid, dim3(256), 0, st, a);
+      else if (s->kh == 3) hipLaunchKernelGGL((dw_strip_bwd_s2_kernel<bf16_t, 3, 4>), grid, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((dw_strip_bwd_s2_kernel<bf16_t, 5, 4>), grid, dim3(256), 0, st, a);
+    } else {
+      if (s->kh == 3) hipLaunchKernelGGL((dw_strip_bwd_s2_kernel<float, 3, 4>), grid, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((dw_strip_bwd_s2_kernel<float, 5, 4>), grid, dim3(256), 0, st, a);
+    }
   } else {
     GenArgs a = {};
     a.src = dy; a.w = w; a.dst = dx; a.s = *s; a.g_scale = g_scale; a.g_shift = g_shift;

@@ -130,12 +130,29 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs a) {
   const T* B = (const T*)a.b;
   T* O = (T*)a.out;
   if (lane_ok) {
-    for (int64_t m = (int64_t)blockIdx.x * mp.P + p; m < a.M; m += (int64_t)gridDim.x * mp.P) {
+    // each workgroup owns a contiguous row range (row groups change rarely inside it, so the
+    // clip index is tracked incrementally instead of a 64-bit division per row)
+    const int64_t rows_wg = (a.M + gridDim.x - 1) / gridDim.x;
+    const int64_t mlo = (int64_t)blockIdx.x * rows_wg, mhi = min(a.M, mlo + rows_wg);
+    int64_t m = mlo + p;
+    int64_t grp = (a.row_scale || a.row_shift) ? m / a.rows_per_group : 0;
+    int64_t grp_end = (grp + 1) * a.rows_per_group;
+    int64_t dgrp = a.dy_rows_per_group > 0 ? m / a.dy_rows_per_group : 0;
+    int64_t dgrp_end = (dgrp + 1) * a.dy_rows_per_group;
+    for (; m < mhi; m += mp.P) {
+      if (a.row_scale || a.row_shift) {
+        while (m >= grp_end) { ++grp; grp_end += a.rows_per_group; }
+      }
+      if constexpr (MODE == 2) {
+        if (a.dy_rows_per_group > 0) {
+          while (m >= dgrp_end) { ++dgrp; dgrp_end += a.dy_rows_per_group; }
+        }
+      }
       float va[CH], vb[CH], vo[CH], rsc[CH], rsh[CH];
       const int64_t off = m * a.C + c0;
       if constexpr (MODE == 2) {
         if (a.dy_rows_per_group > 0) {
-          ld<T, CH>(A + (m / a.dy_rows_per_group) * a.C + c0, va);
+          ld<T, CH>(A + dgrp * a.C + c0, va);
         } else {
           ld<T, CH>(A + off, va);
         }
@@ -150,8 +167,8 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs a) {
         }
       }
       if constexpr (MODE == 1 || MODE == 2) {
-        const float* rp = a.row_scale ? a.row_scale + (m / a.rows_per_group) * a.C + c0 : nullptr;
-        const float* rq = a.row_shift ? a.row_shift + (m / a.rows_per_group) * a.C + c0 : nullptr;
+        const float* rp = a.row_scale ? a.row_scale + grp * a.C + c0 : nullptr;
+        const float* rq = a.row_shift ? a.row_shift + grp * a.C + c0 : nullptr;
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
           rsc[i] = rp ? rp[i] : 1.f;
@@ -187,7 +204,8 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs a) {
   }
   if constexpr (MODE != 3) {
     if (want_sums) {
-      float* const outs[2] = {a.sums, a.sums + a.C};
+      float* rep = a.sums + (size_t)((blockIdx.x + blockIdx.y) % PB_STAT_REPLICAS) * 2 * a.C;
+      float* const outs[2] = {rep, rep + a.C};
       block_chan_reduce<CH, 2>(red, acc, lane_ok, cvl, CW, blockIdx.y * CW, a.C, outs);
     }
   }
@@ -198,8 +216,10 @@ int launch_ew(EwArgs a, hipStream_t st) {
   constexpr int VEC = ElemTraits<T>::VEC;
   const bool vec = (a.C % VEC) == 0;
   a.map = vec ? make_map<VEC>(a.C) : make_map<1>(a.C);
-  int64_t gx = pb_cdiv(a.M, a.map.P);
-  const int64_t cap = pb_cdiv(4096, a.map.chunks);
+  // >= 4 rows per thread; reducing launches stay <= ~512 workgroups per channel chunk so that, with the
+  // 16 stats replicas, an address sees <= 32 same-address atomics
+  int64_t gx = pb_cdiv(a.M, (int64_t)a.map.P * 4);
+  const int64_t cap = a.sums ? pb_cdiv(512, 1) : pb_cdiv(8192, a.map.chunks);
   if (gx > cap) gx = cap;
   if (gx < 1) gx = 1;
   dim3 grid((unsigned)gx, (unsigned)a.map.chunks);
@@ -268,8 +288,13 @@ __global__ void bn_finalize_kernel(const float* stats, double count, const float
     mean = running_mean[c];
     var = running_var[c];
   } else {
-    mean = (double)stats[c] / count;
-    var = (double)stats[C + c] / count - mean * mean;
+    double s1 = 0, s2 = 0;
+    for (int r = 0; r < PB_STAT_REPLICAS; ++r) {
+      s1 += stats[(size_t)r * 2 * C + c];
+      s2 += stats[(size_t)r * 2 * C + C + c];
+    }
+    mean = s1 / count;
+    var = s2 / count - mean * mean;
     if (var < 0) var = 0;
     if (running_mean) running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
     if (running_var) {
@@ -290,7 +315,11 @@ __global__ void bn_bwd_finalize_kernel(const float* sums, double count, const fl
                                        float* dgamma, float* dbeta, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  const double sg = sums[c], sgx = sums[C + c];
+  double sg = 0, sgx = 0;
+  for (int r = 0; r < PB_STAT_REPLICAS; ++r) {
+    sg += sums[(size_t)r * 2 * C + c];
+    sgx += sums[(size_t)r * 2 * C + C + c];
+  }
   const double g = gamma ? gamma[c] : 1.0, r = rstd[c], mu = mean[c];
   if (training) {
     const double B = -g * r * r * (sgx / count);

@@ -116,6 +116,15 @@ __device__ __forceinline__ float act_bwd(float x, int act, float slope) {
   }
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt(0): it would
+// wait for every outstanding global store (and prefetched load) at each barrier - in the GEMM that
+// serialises the epilogue stores and kills the register prefetch.  Here only the wave's LDS
+// operations are waited for before the barrier; the "memory" clobber keeps the compiler from moving
+// LDS accesses across it.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -42,24 +42,61 @@ struct PwArgs {
   int64_t m_tiles;
 };
 
-template <typename T>
-__device__ __forceinline__ Vec16<T> prologue(Vec16<T> v, const PwArgs& a, int64_t m, int k) {
-  constexpr int VEC = ElemTraits<T>::VEC;
-  if (a.in_scale || a.in_shift || a.in_act != PB_ACT_NONE || a.row_scale) {
-    const float* rs = a.row_scale ? a.row_scale + (m / a.rows_per_group) * a.K : nullptr;
+// Prologue on the X operand, split so that a prefetch only ISSUES loads: `RowScale` carries the
+// chunk's per-(clip, channel) squeeze-excite factors fetched next to the chunk; the arithmetic
+// (affine, activation, scale) runs when the chunk is committed to LDS, a stage later.
+template <typename T> struct RowScale {
+  float v[ElemTraits<T>::VEC];
+  __device__ __forceinline__ void ones() {
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-      float x = v.get(i);
-      if (k + i < a.K) {
-        if (a.in_scale) x *= a.in_scale[k + i];
-        if (a.in_shift) x += a.in_shift[k + i];
-        x = act_fwd(x, a.in_act, a.in_slope);
-        if (rs) x *= rs[k + i];
+    for (int i = 0; i < ElemTraits<T>::VEC; ++i) v[i] = 1.f;
+  }
+};
+
+template <typename T>
+__device__ __forceinline__ RowScale<T> fetch_rowscale(const PwArgs& a, int64_t group, int k) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  RowScale<T> r;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) r.v[i] = 1.f;
+  if (a.row_scale) {
+    const float* rs = a.row_scale + group * a.K + k;
+    if ((a.K & 3) == 0 && k + VEC <= a.K) {
+#pragma unroll
+      for (int q = 0; q < VEC / 4; ++q) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(rs + 4 * q);
+        r.v[4 * q] = t[0]; r.v[4 * q + 1] = t[1]; r.v[4 * q + 2] = t[2]; r.v[4 * q + 3] = t[3];
       }
-      v.set(i, x);
+    } else {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i)
+        if (k + i < a.K) r.v[i] = rs[i];
     }
   }
+  return r;
+}
+
+template <typename T>
+__device__ __forceinline__ Vec16<T> apply_prologue(Vec16<T> v, const RowScale<T>& rs, const PwArgs& a, int k) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  const bool affine = a.in_scale || a.in_shift || a.in_act != PB_ACT_NONE;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    float x = v.get(i);
+    if (affine && k + i < a.K) {
+      if (a.in_scale) x *= a.in_scale[k + i];
+      if (a.in_shift) x += a.in_shift[k + i];
+      x = act_fwd(x, a.in_act, a.in_slope);
+    }
+    v.set(i, x * rs.v[i]);
+  }
   return v;
+}
+
+// clip index of row m (64-bit division kept out of the per-chunk path: rows of a 128-row panel span at
+// most two clips when rows_per_group >= 128)
+__device__ __forceinline__ int64_t row_group(int64_t m, int64_t m0, int64_t g0, int64_t g0_end, int64_t rpg) {
+  return rpg >= 128 ? (m >= g0_end ? g0 + 1 : g0) : m / rpg;
 }
 
 // Load VEC consecutive elements X[m][k..k+VEC) (zero beyond K); vector access when aligned.
@@ -74,104 +111,255 @@ __device__ __forceinline__ Vec16<T> load_row_chunk(const T* X, int64_t m, int k,
   return v;
 }
 
-template <typename T, int NT>
+// Persistent workgroups walk (row panel, column tile) pairs; the global loads of the NEXT K stage
+// (or of the next tile's first stage) are issued into registers before the MFMAs of the current
+// stage, so HBM/L2 latency hides behind compute and the epilogue.  When K fits one stage and there
+// is a single column tile, the converted weight tile stays resident in LDS for the whole launch.
+// ALIGNED: K % VEC == 0, N % VEC == 0, ldw % 4 == 0 -> every access is a 16-byte vector and the
+// scalar fallbacks are compiled out of the hot path.  PRO: a prologue (affine / activation / row
+// scale) is applied to X while staging.
+template <typename T, int NT, bool TRANS, bool ALIGNED, bool PRO>
 __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
   constexpr int VEC = ElemTraits<T>::VEC;
   constexpr int KS = 128 / (int)sizeof(T);     // K elements staged per step (64 bf16 / 32 f32)
   constexpr int MK = 128 / (int)sizeof(T) / 2; // K consumed per fragment read (32 bf16 / 16 f32)
   constexpr int BN = NT * 16;
   constexpr int EPI_LD = BN + VEC;
-  constexpr int TILE_BYTES = (BM + BN) * LDB;
   constexpr int EPI_BYTES = 4 * 16 * EPI_LD * (int)sizeof(T);
-  constexpr int MAIN_BYTES = TILE_BYTES > EPI_BYTES ? TILE_BYTES : EPI_BYTES;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[MAIN_BYTES + 4 * BN * 2 * 4];
-
-  // block id -> (row panel, column tile); blocks b and b+8 share an XCD, so all column tiles of
-  // a row panel are given ids with equal b % 8 (speed only; placement is never relied upon).
-  const int64_t b = blockIdx.x;
-  const int xcd = (int)(b & 7);
-  const int64_t jj = b >> 3;
-  const int nt = (int)(jj % a.n_tiles);
-  const int64_t mt = (jj / a.n_tiles) * 8 + xcd;
-  if (mt >= a.m_tiles) return;
-  const int64_t m0 = mt * BM;
-  const int n0 = nt * BN;
+  constexpr int A_BYTES = BM * LDB > EPI_BYTES ? BM * LDB : EPI_BYTES;   // A tile, reused by the epilogue
+  constexpr int W_BYTES = BN * LDB;
+  constexpr int ACH = 4;                               // BM * 8 chunks / 256 threads
+  constexpr int WCH = (BN * 8 + 255) / 256;            // weight chunks per thread (row-major W)
+  constexpr int NQ = BN / 4;
+  constexpr int WTQ = (KS * NQ + 255) / 256;           // float4 loads per thread (transposed W)
+  __shared__ __attribute__((aligned(16))) unsigned char smem[A_BYTES + W_BYTES + 4 * BN * 2 * 4];
+  unsigned char* As = smem;
+  unsigned char* Ws = smem + A_BYTES;
+  float* sred = (float*)(smem + A_BYTES + W_BYTES);   // [4 waves][BN][2]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const T* X = (const T*)a.X;
   T* Y = (T*)a.Y;
-  unsigned char* As = smem;
-  unsigned char* Ws = smem + BM * LDB;
-  const bool xvec = (a.K % VEC) == 0;
-  const bool wvec = (a.ldw % 4) == 0;
+  const bool xvec = ALIGNED || (a.K % VEC) == 0;
+  const bool wvec = ALIGNED || (a.ldw % 4) == 0;
+  const bool yvec = ALIGNED || (a.N % VEC) == 0;
+  const int nk = (a.K + KS - 1) / KS;
+  const bool w_cached = nk == 1 && a.n_tiles == 1;
+  // all tile arithmetic in 32 bits (the host checks the tile count), single-column-tile fast path
+  const int n_tiles = a.n_tiles, m_tiles = (int)a.m_tiles;
+  const int total = n_tiles == 1 ? m_tiles : ((m_tiles + 7) / 8) * 8 * n_tiles;
 
-  f32x4 acc[2][NT];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // tile id -> (row panel, column tile): ids with equal t % 8 run on blocks with equal blockIdx % 8
+  // (gridDim is a multiple of 8), i.e. on one XCD: all column tiles of a row panel share its L2.
+  auto tile_mt = [&](int t) { return n_tiles == 1 ? t : ((t >> 3) / n_tiles) * 8 + (t & 7); };
+  auto tile_nt = [&](int t) { return n_tiles == 1 ? 0 : (t >> 3) % n_tiles; };
+  auto next_valid = [&](int t) {
+    while (t < total && tile_mt(t) >= m_tiles) t += gridDim.x;
+    return t;
+  };
 
-  for (int k0 = 0; k0 < a.K; k0 += KS) {
+  Vec16<T> ra[ACH];
+  RowScale<T> rsa[PRO ? ACH : 1];
+  Vec16<T> rw[TRANS ? 1 : WCH];
+  f32x4 rt[TRANS ? WTQ : 1];
+
+  // a stage holds kpad = MK or 2*MK (= KS) columns, i.e. 4 or 8 16-byte chunks per row: chunk ->
+  // (row, col) is a shift and a mask
+  auto stage_dims = [&](int k0, int& kpad, int& csh) {
     const int kc = min(KS, a.K - k0);
-    const int kpad = (kc + MK - 1) / MK * MK;
-    const int cprp = kpad / VEC;
-    // ---- stage the activation panel chunk (prologue fused)
-    for (int f = tid; f < BM * cprp; f += 256) {
-      const int r = f / cprp, c = f - r * cprp;
-      const int64_t m = m0 + r;
-      const int k = k0 + c * VEC;
-      Vec16<T> v = vec_zero<T>();
-      if (m < a.M && k < a.K) v = prologue<T>(load_row_chunk<T>(X, m, k, a.K, xvec), a, m, k);
-      vec_store<T>((T*)(As + r * LDB) + c * VEC, v);
+    kpad = kc > MK ? KS : MK;
+    csh = kc > MK ? 3 : 2;
+  };
+  auto fetch_a = [&](int t, int ks) {
+    const int k0 = ks * KS;
+    int kpad, csh;
+    stage_dims(k0, kpad, csh);
+    const int64_t m0 = (int64_t)tile_mt(t) * BM;
+    int64_t g0 = 0, g0_end = 0;
+    if constexpr (PRO) {
+      if (a.row_scale) {
+        g0 = m0 / a.rows_per_group;
+        g0_end = (g0 + 1) * a.rows_per_group;
+      }
     }
-    // ---- stage the weight tile, fp32 -> T
-    if (!a.w_transposed) {
-      for (int f = tid; f < BN * cprp; f += 256) {
-        const int r = f / cprp, c = f - r * cprp;
-        const int n = n0 + r, k = k0 + c * VEC;
-        Vec16<T> v = vec_zero<T>();
-        if (n < a.N) {
-          const float* src = a.W + (int64_t)n * a.ldw + k;
-          if (wvec && k + VEC <= a.K) {
 #pragma unroll
-            for (int q = 0; q < VEC / 4; ++q) {
-              f32x4 t = *reinterpret_cast<const f32x4*>(src + 4 * q);
+    for (int i = 0; i < ACH; ++i) {
+      const int f = tid + i * 256;
+      ra[i] = vec_zero<T>();
+      if constexpr (PRO) rsa[i].ones();
+      if (f < (BM << csh)) {
+        const int r = f >> csh, c = f & ((1 << csh) - 1);
+        const int64_t m = m0 + r;
+        const int k = k0 + c * VEC;
+        if (m < a.M && k < a.K) {
+          if constexpr (ALIGNED) ra[i] = vec_load<T>(X + m * a.K + k);
+          else ra[i] = load_row_chunk<T>(X, m, k, a.K, xvec);
+          if constexpr (PRO) rsa[i] = fetch_rowscale<T>(a, row_group(m, m0, g0, g0_end, a.rows_per_group), k);
+        }
+      }
+    }
+  };
+  auto commit_a = [&](int ks) {
+    int kpad, csh;
+    stage_dims(ks * KS, kpad, csh);
 #pragma unroll
-              for (int i = 0; i < 4; ++i) v.set(4 * q + i, t[i]);
+    for (int i = 0; i < ACH; ++i) {
+      const int f = tid + i * 256;
+      if (f < (BM << csh)) {
+        const int r = f >> csh, c = f & ((1 << csh) - 1);
+        if constexpr (PRO) ra[i] = apply_prologue<T>(ra[i], rsa[i], a, ks * KS + c * VEC);
+        vec_store<T>((T*)(As + r * LDB) + c * VEC, ra[i]);
+      }
+    }
+  };
+  auto fetch_w = [&](int t, int ks) {
+    const int k0 = ks * KS, n0 = tile_nt(t) * BN;
+    int kpad, csh;
+    stage_dims(k0, kpad, csh);
+    if constexpr (!TRANS) {
+#pragma unroll
+      for (int i = 0; i < WCH; ++i) {
+        const int f = tid + i * 256;
+        rw[i] = vec_zero<T>();
+        if (f < (BN << csh)) {
+          const int r = f >> csh, c = f & ((1 << csh) - 1);
+          const int n = n0 + r, k = k0 + c * VEC;
+          if (n < a.N && k < a.K) {
+            const float* src = a.W + (int64_t)n * a.ldw + k;
+            if (ALIGNED || (wvec && k + VEC <= a.K)) {
+#pragma unroll
+              for (int q = 0; q < VEC / 4; ++q) {
+                const f32x4 tq = *reinterpret_cast<const f32x4*>(src + 4 * q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rw[i].set(4 * q + e, tq[e]);
+              }
+            } else if constexpr (!ALIGNED) {
+#pragma unroll
+              for (int e = 0; e < VEC; ++e)
+                if (k + e < a.K) rw[i].set(e, src[e]);
             }
-          } else {
-#pragma unroll
-            for (int i = 0; i < VEC; ++i)
-              if (k + i < a.K) v.set(i, src[i]);
           }
         }
-        vec_store<T>((T*)(Ws + r * LDB) + c * VEC, v);
       }
     } else {
-      // Wl[n][k] = w[k*ldw + n]: read 4 consecutive n per thread (coalesced along n), scatter to LDS
-      constexpr int NQ = BN / 4;
-      for (int f = tid; f < kpad * NQ; f += 256) {
-        const int kl = f / NQ, nq = f - kl * NQ;
-        const int n = n0 + nq * 4, k = k0 + kl;
-        float t[4] = {0.f, 0.f, 0.f, 0.f};
-        if (k < a.K) {
-          const float* src = a.W + (int64_t)k * a.ldw + n;
-          if (wvec && n + 4 <= a.N) {
-            f32x4 q = *reinterpret_cast<const f32x4*>(src);
-            t[0] = q[0]; t[1] = q[1]; t[2] = q[2]; t[3] = q[3];
-          } else {
+      // Wl[n][k] = w[k*ldw + n]: 4 consecutive n per load (coalesced along n)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-              if (n + i < a.N) t[i] = src[i];
+      for (int i = 0; i < WTQ; ++i) {
+        const int f = tid + i * 256;
+        rt[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (f < kpad * NQ) {
+          const int kl = f / NQ, nq = f - kl * NQ;
+          const int n = n0 + nq * 4, k = k0 + kl;
+          if (k < a.K && n < a.N) {
+            const float* src = a.W + (int64_t)k * a.ldw + n;
+            if (ALIGNED || (wvec && n + 4 <= a.N)) {
+              rt[i] = *reinterpret_cast<const f32x4*>(src);
+            } else if constexpr (!ALIGNED) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (n + e < a.N) rt[i][e] = src[e];
+            }
           }
         }
+      }
+    }
+  };
+  auto commit_w = [&](int ks) {
+    int kpad, csh;
+    stage_dims(ks * KS, kpad, csh);
+    if constexpr (!TRANS) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ((T*)(Ws + (nq * 4 + i) * LDB))[kl] = from_f32<T>(t[i]);
+      for (int i = 0; i < WCH; ++i) {
+        const int f = tid + i * 256;
+        if (f < (BN << csh)) {
+          const int r = f >> csh, c = f & ((1 << csh) - 1);
+          vec_store<T>((T*)(Ws + r * LDB) + c * VEC, rw[i]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < WTQ; ++i) {
+        const int f = tid + i * 256;
+        if (f < kpad * NQ) {
+          const int kl = f / NQ, nq = f - kl * NQ;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ((T*)(Ws + (nq * 4 + e) * LDB))[kl] = from_f32<T>(rt[i][e]);
+        }
+      }
+    }
+  };
+
+  f32x4 acc[2][NT];
+  float csum[NT], csq[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    csum[j] = csq[j] = 0.f;
+    acc[0][j] = acc[1][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int frow = lane & 15, fk = lane >> 4;
+  const int ccol = lane & 15, rgrp = lane >> 4;
+  const bool plain = !a.out_scale && !a.out_shift && a.out_act == PB_ACT_NONE;
+  float osc[NT], osh[NT];
+  int osc_n0 = -1;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) { osc[j] = 1.f; osh[j] = 0.f; }
+
+  auto flush_stats = [&](int n0) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      float s = csum[j], q = csq[j];
+      s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+      q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+      if (lane < 16) {
+        sred[(wave * BN + j * 16 + lane) * 2 + 0] = s;
+        sred[(wave * BN + j * 16 + lane) * 2 + 1] = q;
+      }
+      csum[j] = csq[j] = 0.f;
+    }
+    __syncthreads();
+    float* st = a.stats + (size_t)(blockIdx.x % PB_STAT_REPLICAS) * 2 * a.N;
+    for (int c = tid; c < BN; c += 256) {
+      const int n = n0 + c;
+      if (n < a.N) {
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          s += sred[(w * BN + c) * 2 + 0];
+          q += sred[(w * BN + c) * 2 + 1];
+        }
+        atomicAdd(st + n, s);
+        atomicAdd(st + a.N + n, q);
       }
     }
     __syncthreads();
-    // ---- MFMA over the staged chunk
-    const int frow = lane & 15, fk = lane >> 4;
+  };
+
+  int t = next_valid((int)blockIdx.x);
+  if (t >= total) return;
+  if (w_cached) {
+    fetch_w(t, 0);
+    commit_w(0);
+  }
+  int ks = 0;
+  fetch_a(t, 0);
+  if (!w_cached) fetch_w(t, 0);
+  while (t < total) {
+    commit_a(ks);
+    if (!w_cached) commit_w(ks);
+    lds_barrier();
+    // issue the next stage's (or next tile's) global loads; they complete under the MFMAs below
+    int tn = t;
+    int ksn = ks + 1;
+    if (ksn == nk) {
+      ksn = 0;
+      tn = next_valid(t + gridDim.x);
+    }
+    if (tn < total) {
+      fetch_a(tn, ksn);
+      if (!w_cached) fetch_w(tn, ksn);
+    }
+    int kpad, csh;
+    stage_dims(ks * KS, kpad, csh);
     for (int kk = 0; kk < kpad; kk += MK) {
       if constexpr (sizeof(T) == 2) {
         const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(As + (wave * 32 + frow) * LDB + (kk + 8 * fk) * 2);
@@ -197,82 +385,87 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
         }
       }
     }
-    __syncthreads();
-  }
-
-  // ---- epilogue: affine/bias + activation, optional per-column statistics, LDS-transposed store
-  T* epi = (T*)smem + wave * 16 * EPI_LD;
-  float* sred = (float*)(smem + MAIN_BYTES);   // [4 waves][BN][2]
-  float csum[NT], csq[NT];
+    lds_barrier();
+    if (ks == nk - 1) {
+      // ---- epilogue: affine/bias + activation, per-column statistics, LDS-transposed store
+      const int64_t m0 = (int64_t)tile_mt(t) * BM;
+      const int n0 = tile_nt(t) * BN;
+      T* epi = (T*)smem + wave * 16 * EPI_LD;
+      if (!plain) {
+        if (n0 != osc_n0) {
+        // per-column epilogue parameters, fetched once per column tile (never inside the element loops:
+        // a load there costs a vmcnt(0) drain of the prefetch and of the previous stores)
+        osc_n0 = n0;
 #pragma unroll
-  for (int j = 0; j < NT; ++j) csum[j] = csq[j] = 0.f;
-  const int ccol = lane & 15, rgrp = lane >> 4;
-  const bool yvec = (a.N % VEC) == 0;
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int n = n0 + j * 16 + ccol;
-      const bool nok = n < a.N;
-      const float osc = (a.out_scale && nok) ? a.out_scale[n] : 1.f;
-      const float osh = (a.out_shift && nok) ? a.out_shift[n] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int rl = rgrp * 4 + r;
-        const int64_t m = m0 + wave * 32 + i * 16 + rl;
-        const float v = act_fwd(acc[i][j][r] * osc + osh, a.out_act, a.out_slope);
-        const T tv = from_f32<T>(v);
-        epi[rl * EPI_LD + j * 16 + ccol] = tv;
-        if (a.stats && nok && m < a.M) {
-          const float fv = to_f32(tv);
-          csum[j] += fv;
-          csq[j] += fv * fv;
+        for (int j = 0; j < NT; ++j) {
+          const int n = n0 + j * 16 + ccol;
+          osc[j] = (a.out_scale && n < a.N) ? a.out_scale[n] : 1.f;
+          osh[j] = (a.out_shift && n < a.N) ? a.out_shift[n] : 0.f;
         }
-      }
-    }
-    __syncthreads();
-    constexpr int CPR = BN / VEC;
-    for (int f = lane; f < 16 * CPR; f += 64) {
-      const int r = f / CPR, c = f - r * CPR;
-      const int64_t m = m0 + wave * 32 + i * 16 + r;
-      const int n = n0 + c * VEC;
-      if (m < a.M && n < a.N) {
-        if (yvec && n + VEC <= a.N) {
-          vec_store<T>(Y + m * a.N + n, vec_load<T>(epi + r * EPI_LD + c * VEC));
-        } else {
-          for (int e = 0; e < VEC; ++e)
-            if (n + e < a.N) Y[m * a.N + n + e] = epi[r * EPI_LD + c * VEC + e];
         }
-      }
-    }
-    __syncthreads();
+        // affine + activation on the whole accumulator tile, activation switch OUTSIDE the element
+        // loops (one uniform branch per tile instead of one ladder per element)
+#define PB_EPI_LOOP(EXPR)                                             \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i)                       \
+  _Pragma("unroll") for (int j = 0; j < NT; ++j)                      \
+  _Pragma("unroll") for (int r = 0; r < 4; ++r) {                     \
+    const float x = acc[i][j][r] * osc[j] + osh[j];                   \
+    acc[i][j][r] = (EXPR);                                            \
   }
-  if (a.stats) {
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      float s = csum[j], q = csq[j];
-      s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
-      q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
-      if (lane < 16) {
-        sred[(wave * BN + j * 16 + lane) * 2 + 0] = s;
-        sred[(wave * BN + j * 16 + lane) * 2 + 1] = q;
-      }
-    }
-    __syncthreads();
-    for (int c = tid; c < BN; c += 256) {
-      const int n = n0 + c;
-      if (n < a.N) {
-        float s = 0.f, q = 0.f;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-          s += sred[(w * BN + c) * 2 + 0];
-          q += sred[(w * BN + c) * 2 + 1];
+        switch (a.out_act) {
+          case PB_ACT_RELU: PB_EPI_LOOP(x > 0.f ? x : 0.f) break;
+          case PB_ACT_LEAKY_RELU: PB_EPI_LOOP(x > 0.f ? x : x * a.out_slope) break;
+          case PB_ACT_HSWISH: PB_EPI_LOOP(x * fminf(fmaxf(x + 3.f, 0.f), 6.f) * (1.f / 6.f)) break;
+          case PB_ACT_HSIGMOID: PB_EPI_LOOP(fminf(fmaxf(x * (1.f / 6.f) + 0.5f, 0.f), 1.f)) break;
+          case PB_ACT_SILU: PB_EPI_LOOP(x / (1.f + __expf(-x))) break;
+          default: PB_EPI_LOOP(x) break;
         }
-        atomicAdd(a.stats + n, s);
-        atomicAdd(a.stats + a.N + n, q);
+#undef PB_EPI_LOOP
       }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int n = n0 + j * 16 + ccol;
+          const bool nok = n < a.N;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int rl = rgrp * 4 + r;
+            const int64_t m = m0 + wave * 32 + i * 16 + rl;
+            const T tv = from_f32<T>(acc[i][j][r]);
+            epi[rl * EPI_LD + j * 16 + ccol] = tv;
+            if (a.stats && nok && m < a.M) {
+              const float fv = to_f32(tv);
+              csum[j] += fv;
+              csq[j] += fv * fv;
+            }
+          }
+          acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        lds_barrier();
+        constexpr int CPR = BN / VEC;
+        for (int f = lane; f < 16 * CPR; f += 64) {
+          const int r = f / CPR, c = f - r * CPR;
+          const int64_t m = m0 + wave * 32 + i * 16 + r;
+          const int n = n0 + c * VEC;
+          if (m < a.M && n < a.N) {
+            if (ALIGNED || (yvec && n + VEC <= a.N)) {
+              vec_store<T>(Y + m * a.N + n, vec_load<T>(epi + r * EPI_LD + c * VEC));
+            } else if constexpr (!ALIGNED) {
+              for (int e = 0; e < VEC; ++e)
+                if (n + e < a.N) Y[m * a.N + n + e] = epi[r * EPI_LD + c * VEC + e];
+            }
+          }
+        }
+        lds_barrier();
+      }
+      // with several column tiles a workgroup's next tile may be another column range: flush now
+      if (a.stats && a.n_tiles > 1) flush_stats(n0);
     }
+    t = tn;
+    ks = ksn;
   }
+  if (a.stats && a.n_tiles == 1) flush_stats(0);
 }
 
 // ----------------------------------------------------------------------------- weight gradient
@@ -295,13 +488,18 @@ struct WgArgs {
 // Each wave streams 32-row blocks of dY[:, n-tile] and X[:, k-tile] through its private LDS
 // slab (row-major, exactly as loaded) and feeds MFMA with the reduction index m on the "k" axis:
 // bf16 fragments come from ds_read_b64_tr_b16 (the hardware transposing read), f32 from plain
-// 4-byte reads.  No workgroup barrier in the loop: waves are independent until the final atomics.
+// 4-byte reads.  No workgroup barrier in the loop (waves are independent); the next block's global
+// loads are issued before the current block's MFMAs.  At the end the four waves' tiles are summed
+// in LDS and added to dW with contiguous float atomics (one writer per workgroup and address).
 template <typename T, int TNW, int TKW>
 __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgArgs a) {
   constexpr int VEC = ElemTraits<T>::VEC;
   constexpr int TN = TNW * 16, TK = TKW * 16;
   constexpr int LDN = (TN + VEC) * (int)sizeof(T), LDK = (TK + VEC) * (int)sizeof(T);   // bytes
   constexpr int SLAB = 32 * (LDN + LDK);
+  constexpr int CN = TN / VEC, CK = TK / VEC;
+  constexpr int RN = 32 * CN / 64, RK = 32 * CK / 64;      // chunks per lane
+  static_assert(4 * SLAB >= TN * TK * 4, "reduction tile must fit the staging slabs");
   __shared__ __attribute__((aligned(16))) unsigned char smem[4 * SLAB];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -319,6 +517,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgArgs a) {
   PwArgs pa;
   pa.K = a.K; pa.in_scale = a.in_scale; pa.in_shift = a.in_shift; pa.in_act = a.in_act;
   pa.in_slope = a.in_slope; pa.row_scale = a.row_scale; pa.rows_per_group = a.rows_per_group;
+  pa.M = a.M;
 
   f32x4 acc[TNW][TKW];
 #pragma unroll
@@ -326,24 +525,53 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgArgs a) {
 #pragma unroll
     for (int j = 0; j < TKW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int64_t mb = mbeg + wave * 32; mb < mend; mb += 128) {
-    constexpr int CN = TN / VEC, CK = TK / VEC;
-    for (int f = lane; f < 32 * CN; f += 64) {
+  Vec16<T> rd[RN], rx[RK];
+  RowScale<T> rsx[RK];
+  const bool pro = a.in_scale || a.in_shift || a.in_act != PB_ACT_NONE || a.row_scale;
+  auto fetch = [&](int64_t mb) {
+    int64_t g0 = 0, g0_end = 0;
+    if (a.row_scale) {
+      g0 = mb / a.rows_per_group;
+      g0_end = (g0 + 1) * a.rows_per_group;
+    }
+#pragma unroll
+    for (int i = 0; i < RN; ++i) {
+      const int f = lane + i * 64;
       const int r = f / CN, c = f - r * CN;
       const int64_t m = mb + r;
       const int n = n0 + c * VEC;
-      Vec16<T> v = vec_zero<T>();
-      if (m < mend && n < a.N) v = load_row_chunk<T>(dY, m, n, a.N, nvec);
-      vec_store<T>((T*)(Ds + r * LDN) + c * VEC, v);
+      rd[i] = (m < mend && n < a.N) ? load_row_chunk<T>(dY, m, n, a.N, nvec) : vec_zero<T>();
     }
-    for (int f = lane; f < 32 * CK; f += 64) {
+#pragma unroll
+    for (int i = 0; i < RK; ++i) {
+      const int f = lane + i * 64;
       const int r = f / CK, c = f - r * CK;
       const int64_t m = mb + r;
       const int k = k0 + c * VEC;
-      Vec16<T> v = vec_zero<T>();
-      if (m < mend && k < a.K) v = prologue<T>(load_row_chunk<T>(X, m, k, a.K, kvec), pa, m, k);
-      vec_store<T>((T*)(Xs + r * LDK) + c * VEC, v);
+      const bool ok = m < mend && k < a.K;
+      rx[i] = ok ? load_row_chunk<T>(X, m, k, a.K, kvec) : vec_zero<T>();
+      rsx[i].ones();
+      if (pro && ok) rsx[i] = fetch_rowscale<T>(pa, row_group(m, mb, g0, g0_end, a.rows_per_group), k);
     }
+  };
+
+  int64_t mb = mbeg + wave * 32;
+  if (mb < mend) fetch(mb);
+  for (; mb < mend; mb += 128) {
+#pragma unroll
+    for (int i = 0; i < RN; ++i) {
+      const int f = lane + i * 64;
+      const int r = f / CN, c = f - r * CN;
+      vec_store<T>((T*)(Ds + r * LDN) + c * VEC, rd[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < RK; ++i) {
+      const int f = lane + i * 64;
+      const int r = f / CK, c = f - r * CK;
+      if (pro) rx[i] = apply_prologue<T>(rx[i], rsx[i], pa, k0 + c * VEC);
+      vec_store<T>((T*)(Xs + r * LDK) + c * VEC, rx[i]);
+    }
+    if (mb + 128 < mend) fetch(mb + 128);         // in flight during the MFMAs below
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
     if constexpr (sizeof(T) == 2) {
@@ -386,25 +614,38 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgArgs a) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
   }
-  // C/D map: row (= n) = (lane>>4)*4 + r, col (= k) = lane & 15
+  // cross-wave sum in LDS (C/D map: row (= n) = (lane>>4)*4 + r, col (= k) = lane & 15), then one
+  // contiguous atomic per element and workgroup
+  float* R = (float*)smem;    // [TN][TK]
+  __syncthreads();
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
 #pragma unroll
-  for (int i = 0; i < TNW; ++i)
+      for (int i = 0; i < TNW; ++i)
 #pragma unroll
-    for (int j = 0; j < TKW; ++j)
+        for (int j = 0; j < TKW; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int n = n0 + i * 16 + (lane >> 4) * 4 + r;
-        const int k = k0 + j * 16 + (lane & 15);
-        if (n < a.N && k < a.K) atomicAdd(a.dW + (int64_t)n * a.K + k, acc[i][j][r]);
-      }
+          for (int r = 0; r < 4; ++r) {
+            const int idx = (i * 16 + (lane >> 4) * 4 + r) * TK + j * 16 + (lane & 15);
+            if (w == 0) R[idx] = acc[i][j][r];
+            else R[idx] += acc[i][j][r];
+          }
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < TN * TK; e += 256) {
+    const int n = n0 + e / TK, k = k0 + e % TK;
+    if (n < a.N && k < a.K) atomicAdd(a.dW + (int64_t)n * a.K + k, R[e]);
+  }
 }
 
-int pick_nt(int N) {
+int pick_nt(int N, bool f32) {
   // cost = padded MFMA width + 16 per column tile (each extra tile re-reads the X panel through L2)
   const int cand[5] = {2, 4, 6, 8, 12};
   int best = 2;
   int64_t best_cost = INT64_MAX;
   for (int c : cand) {
+    if (f32 && c > 8) continue;          // f32 epilogue staging of a 192-wide tile exceeds 64 KB LDS
     const int bn = c * 16;
     const int64_t tiles = pb_cdiv(N, bn);
     const int64_t cost = tiles * bn + 16 * tiles;
@@ -413,21 +654,64 @@ int pick_nt(int N) {
   return best;
 }
 
+// Persistent grid = the workgroups that are actually co-resident (registers AND LDS): a grid
+// sized from LDS alone left a second, nearly empty round of workgroups (2x the time).
+template <typename T, int NT, bool TRANS, bool ALIGNED, bool PRO>
+void launch_one(const PwArgs& a, int64_t total, int device, hipStream_t st) {
+  // Persistent grid = the workgroups that are actually co-resident (registers AND LDS): a grid
+  // sized from LDS alone left a second, nearly empty round of workgroups (2x the time).
+  static int cached[16] = {0};
+  const int d = device & 15;
+  if (cached[d] == 0) {
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pw_gemm_kernel<T, NT, TRANS, ALIGNED, PRO>, 256, 0) != hipSuccess || per_cu < 1)
+      per_cu = 1;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) cus = 256;
+    cached[d] = per_cu * cus;
+  }
+  int64_t blocks = cached[d];
+  if (blocks > total) blocks = total;
+  blocks = pb_cdiv(blocks, 8) * 8;
+  hipLaunchKernelGGL((pw_gemm_kernel<T, NT, TRANS, ALIGNED, PRO>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+}
+
+template <typename T, int NT>
+void launch_nt(const PwArgs& a, int64_t total, bool pro, int device, hipStream_t st) {
+  if (a.w_transposed) {
+    if (pro) launch_one<T, NT, true, true, true>(a, total, device, st);
+    else launch_one<T, NT, true, true, false>(a, total, device, st);
+  } else {
+    if (pro) launch_one<T, NT, false, true, true>(a, total, device, st);
+    else launch_one<T, NT, false, true, false>(a, total, device, st);
+  }
+}
+
 template <typename T>
-int launch_gemm(const PwArgs& a0, hipStream_t st) {
+int launch_gemm(const PwArgs& a0, int device, hipStream_t st) {
   PwArgs a = a0;
-  const int nt = pick_nt(a.N);
+  constexpr int VEC = ElemTraits<T>::VEC;
+  const bool aligned = (a.K % VEC) == 0 && (a.N % VEC) == 0 && (a.ldw % 4) == 0;
+  const bool pro = a.in_scale || a.in_shift || a.in_act != PB_ACT_NONE || a.row_scale;
+  // the generic (unaligned) path exists for the tiny classifier-sized problems: one tile width only
+  const int nt = aligned ? pick_nt(a.N, sizeof(T) == 4) : 8;
   a.n_tiles = (int)pb_cdiv(a.N, nt * 16);
   a.m_tiles = pb_cdiv(a.M, BM);
-  const int64_t blocks = pb_cdiv(a.m_tiles, 8) * 8 * a.n_tiles;
-  if (blocks > 0x7fffffffLL) { pb_set_error("pb_pwconv_fwd: grid too large"); return 1; }
-  dim3 grid((unsigned)blocks), block(256);
+  const int64_t total = a.n_tiles == 1 ? a.m_tiles : pb_cdiv(a.m_tiles, 8) * 8 * a.n_tiles;
+  if (total > 0x3fffffffLL) { pb_set_error("pb_pwconv_fwd: too many tiles"); return 1; }
+  if (!aligned) {
+    if (a.w_transposed) launch_one<T, 8, true, false, true>(a, total, device, st);
+    else launch_one<T, 8, false, false, true>(a, total, device, st);
+    return 0;
+  }
   switch (nt) {
-    case 2: hipLaunchKernelGGL((pw_gemm_kernel<T, 2>), grid, block, 0, st, a); break;
-    case 4: hipLaunchKernelGGL((pw_gemm_kernel<T, 4>), grid, block, 0, st, a); break;
-    case 6: hipLaunchKernelGGL((pw_gemm_kernel<T, 6>), grid, block, 0, st, a); break;
-    case 8: hipLaunchKernelGGL((pw_gemm_kernel<T, 8>), grid, block, 0, st, a); break;
-    default: hipLaunchKernelGGL((pw_gemm_kernel<T, 12>), grid, block, 0, st, a); break;
+    case 2: launch_nt<T, 2>(a, total, pro, device, st); break;
+    case 4: launch_nt<T, 4>(a, total, pro, device, st); break;
+    case 6: launch_nt<T, 6>(a, total, pro, device, st); break;
+    case 8: launch_nt<T, 8>(a, total, pro, device, st); break;
+    default:
+      if constexpr (sizeof(T) == 2) launch_nt<T, 12>(a, total, pro, device, st);
+      else launch_nt<T, 8>(a, total, pro, device, st);
+      break;
   }
   return 0;
 }
@@ -454,7 +738,7 @@ extern "C" int pb_pwconv_fwd(const void* x, const float* w, void* y, int64_t M, 
   a.row_scale = row_scale; a.rows_per_group = rows_per_group > 0 ? rows_per_group : 1;
   a.out_scale = out_scale; a.out_shift = out_shift; a.out_act = (int)out_act; a.out_slope = out_slope;
   a.stats = stats; a.n_tiles = 0; a.m_tiles = 0;
-  int rc = dtype == PB_BF16 ? launch_gemm<bf16_t>(a, (hipStream_t)stream) : launch_gemm<float>(a, (hipStream_t)stream);
+  int rc = dtype == PB_BF16 ? launch_gemm<bf16_t>(a, device, (hipStream_t)stream) : launch_gemm<float>(a, device, (hipStream_t)stream);
   if (rc) return rc;
   PB_LAUNCH_CHECK();
   return 0;
@@ -479,7 +763,9 @@ extern "C" int pb_pwconv_bwd_weight(const void* dy, const void* x, float* dw, in
   a.n_tiles = (int)pb_cdiv(N, tile);
   a.k_tiles = (int)pb_cdiv(K, tile);
   const int64_t tiles = (int64_t)a.n_tiles * a.k_tiles;
-  int64_t msplit = pb_cdiv(2048, tiles);
+  // ~1024 workgroups (4 per CU is what the 36 KB of LDS admits); every workgroup is one atomic writer
+  // per address of its tile, so the M split is also capped for the atomics' sake
+  int64_t msplit = pb_cdiv(1024, tiles);
   const int64_t max_split = pb_cdiv(M, 128);
   if (msplit > max_split) msplit = max_split;
   if (msplit > 65535) msplit = 65535;

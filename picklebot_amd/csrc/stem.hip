@@ -102,53 +102,144 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemArgs a) {
     }
     __syncthreads();
     if (tid < OCB && oc0 + tid < s.Cout) {
-      atomicAdd(a.stats + oc0 + tid, red[tid]);
-      atomicAdd(a.stats + s.Cout + oc0 + tid, red[OCB + tid]);
+      float* st = a.stats + (size_t)(blockIdx.x % PB_STAT_REPLICAS) * 2 * s.Cout;
+      atomicAdd(st + oc0 + tid, red[tid]);
+      atomicAdd(st + s.Cout + oc0 + tid, red[OCB + tid]);
     }
   }
 }
 
-// Weight gradient: a 128-lane group owns the (ci,tap) columns (+1 lane for the bias) and walks
-// output pixels; dy's 16 channels are uniform over the group, x is one gather per lane.
+// Weight gradient as a small MFMA GEMM: dW[oc][col] = sum_pix dy[pix][oc] * patch[pix][col],
+// col = (ci, tap) (+ one virtual column of ones for the bias).  Each wave walks blocks of 32
+// consecutive output pixels of one output row: dy's [32][16] tile is one contiguous 1 KB read,
+// the input window those pixels see (kt x kh rows of 31*sw+kw pixels) is staged once in LDS, and
+// the MFMA "k" index is the pixel: A = dy^T (transposing LDS read for bf16), B = im2col gathers
+// from the LDS window.  Accumulators persist over the wave's whole walk.
+constexpr int SW_PIX = 32;          // pixels per wave step
+constexpr int SW_MAXWIN = 2048;     // LDS window elements per wave (kt*kh*(31*sw+kw)*Cin)
+constexpr int SW_NB = 8;            // column blocks of 16 (Cin*taps + 1 <= 128)
+
 template <typename XT, typename T>
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemArgs a) {
+  __shared__ __attribute__((aligned(16))) T win_s[4][SW_MAXWIN];
+  __shared__ __attribute__((aligned(16))) T dy_s[4][SW_PIX * OCB];
+  __shared__ float red[OCB * SW_NB * 16];
   const pb_stem_shape& s = a.s;
-  const int tid = threadIdx.x;
-  const int grp = tid >> 7, col = tid & 127;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int taps = s.kt * s.kh * s.kw, CT = s.Cin * taps;
+  const int nb = (CT + 1 + 15) / 16;
   const int oc0 = blockIdx.y * OCB;
-  const bool is_w = col < CT, is_b = col == CT;
-  const int ci = is_w ? col / taps : 0;
-  const int tap = is_w ? col - ci * taps : 0;
-  const int aw = tap % s.kw, ah = (tap / s.kw) % s.kh, at = tap / (s.kw * s.kh);
+  const int WL = (SW_PIX - 1) * s.sw + s.kw;             // window width in input pixels
+  const int win_elems = s.kt * s.kh * WL * s.Cin;
+  const int wblocks = (s.Wo + SW_PIX - 1) / SW_PIX;
+  const int64_t nitems = (int64_t)s.N * s.To * s.Ho * wblocks;
   const T* dy = (const T*)a.y;
-  float acc[OCB];
+  const XT* x = (const XT*)a.x;
+  T* win = win_s[wave];
+  T* dyt = dy_s[wave];
+
+  // this lane's im2col column for every column block: offset of (ci, at, ah, aw) inside the window
+  const int col = lane & 15, g = lane >> 4;
+  int coff[SW_NB];
+  bool cvalid[SW_NB], cbias[SW_NB];
 #pragma unroll
-  for (int oc = 0; oc < OCB; ++oc) acc[oc] = 0.f;
-  for (int64_t pix = (int64_t)blockIdx.x * 2 + grp; pix < a.npix; pix += (int64_t)gridDim.x * 2) {
-    int64_t r = pix;
-    const int wo = (int)(r % s.Wo); r /= s.Wo;
+  for (int b = 0; b < SW_NB; ++b) {
+    const int c = b * 16 + col;
+    cvalid[b] = c < CT;
+    cbias[b] = c == CT;
+    const int ci = cvalid[b] ? c / taps : 0;
+    const int tp = cvalid[b] ? c - ci * taps : 0;
+    const int aw = tp % s.kw, ah = (tp / s.kw) % s.kh, at = tp / (s.kw * s.kh);
+    coff[b] = ((at * s.kh + ah) * WL + aw) * s.Cin + ci;
+  }
+  f32x4 acc[SW_NB];
+#pragma unroll
+  for (int b = 0; b < SW_NB; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int64_t it = (int64_t)blockIdx.x * 4 + wave; it < nitems; it += (int64_t)gridDim.x * 4) {
+    int64_t r = it;
+    const int wb = (int)(r % wblocks); r /= wblocks;
     const int ho = (int)(r % s.Ho); r /= s.Ho;
     const int to = (int)(r % s.To);
     const int n = (int)(r / s.To);
-    float xv = is_b ? 1.f : 0.f;
-    if (is_w) {
-      const int ti = to * s.st - s.pt + at, hi = ho * s.sh - s.ph + ah, wi = wo * s.sw - s.pw + aw;
-      if (ti >= 0 && ti < s.Ti && hi >= 0 && hi < s.Hi && wi >= 0 && wi < s.Wi)
-        xv = ldx<XT>((const XT*)a.x + (int64_t)n * s.xs_n + ci * s.xs_c + ti * s.xs_t + hi * s.xs_h + wi * s.xs_w) * a.x_scale;
+    const int wo0 = wb * SW_PIX;
+    const int npx = min(SW_PIX, s.Wo - wo0);
+    // dy tile [32][16] (rows past the row end are zero: they then contribute nothing)
+    {
+      const int64_t pix0 = (((int64_t)n * s.To + to) * s.Ho + ho) * s.Wo + wo0;
+      for (int e = lane; e < SW_PIX * OCB; e += 64) {
+        const int p = e / OCB, oc = e - p * OCB;
+        dyt[e] = (p < npx && oc0 + oc < s.Cout) ? dy[(pix0 + p) * s.Cout + oc0 + oc] : from_f32<T>(0.f);
+      }
     }
-    const T* dp = dy + pix * s.Cout + oc0;
+    // input window: [at][ah][wl][ci], zero outside the clip
+    {
+      const int ti0 = to * s.st - s.pt, hi0 = ho * s.sh - s.ph, wi0 = wo0 * s.sw - s.pw;
+      const int rowlen = WL * s.Cin;
+      for (int e = lane; e < win_elems; e += 64) {
+        const int rr = e / rowlen, q = e - rr * rowlen;
+        const int at = rr / s.kh, ah = rr - at * s.kh;
+        const int wl = q / s.Cin, ci = q - wl * s.Cin;
+        const int ti = ti0 + at, hi = hi0 + ah, wi = wi0 + wl;
+        float v = 0.f;
+        if (ti >= 0 && ti < s.Ti && hi >= 0 && hi < s.Hi && wi >= 0 && wi < s.Wi)
+          v = ldx<XT>(x + (int64_t)n * s.xs_n + ci * s.xs_c + ti * s.xs_t + hi * s.xs_h + wi * s.xs_w) * a.x_scale;
+        win[e] = from_f32<T>(v);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    if constexpr (sizeof(T) == 2) {
+      // A = dy^T [oc][pixel]: lane (oc = lane&15, g) needs pixels 8g..8g+7 -> two transposing reads
+      const int q = (lane & 15) >> 2, p4 = lane & 3;
+      typedef __attribute__((address_space(3))) bf16x4* lds_p;
+      const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(dyt + (8 * g + q) * OCB + 4 * p4));
+      const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(dyt + (8 * g + 4 + q) * OCB + 4 * p4));
+      const bf16x8 fa = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
-    for (int oc = 0; oc < OCB; ++oc) {
-      const float g = (oc0 + oc < s.Cout) ? to_f32(dp[oc]) : 0.f;
-      acc[oc] += g * xv;
+      for (int b = 0; b < SW_NB; ++b) {
+        if (b < nb) {
+          bf16x8 fb;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int p = 8 * g + j;
+            fb[j] = cvalid[b] ? win[coff[b] + p * s.sw * s.Cin] : (cbias[b] ? (bf16_t)1.f : (bf16_t)0.f);
+          }
+          acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc[b], 0, 0, 0);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int ms = 0; ms < 8; ++ms) {
+        const int p = ms * 4 + g;
+        const float fa = dyt[p * OCB + col];
+#pragma unroll
+        for (int b = 0; b < SW_NB; ++b) {
+          if (b < nb) {
+            const float fb = cvalid[b] ? win[coff[b] + p * s.sw * s.Cin] : (cbias[b] ? 1.f : 0.f);
+            acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa, fb, acc[b], 0, 0, 0);
+          }
+        }
+      }
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
   }
+  // cross-wave sum (C/D map: row = oc = (lane>>4)*4 + r, col = lane & 15), then contiguous atomics
+  for (int i = tid; i < OCB * SW_NB * 16; i += 256) red[i] = 0.f;
+  __syncthreads();
 #pragma unroll
-  for (int oc = 0; oc < OCB; ++oc) {
+  for (int b = 0; b < SW_NB; ++b)
+    if (b < nb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) atomicAdd(&red[((lane >> 4) * 4 + r) * (SW_NB * 16) + b * 16 + (lane & 15)], acc[b][r]);
+  __syncthreads();
+  for (int i = tid; i < OCB * (CT + 1); i += 256) {
+    const int oc = i / (CT + 1), c = i - oc * (CT + 1);
     if (oc0 + oc >= s.Cout) continue;
-    if (is_w) atomicAdd(a.dw + ((int64_t)(oc0 + oc) * s.Cin + ci) * taps + tap, acc[oc]);
-    else if (is_b && a.dbias) atomicAdd(a.dbias + oc0 + oc, acc[oc]);
+    const float v = red[oc * (SW_NB * 16) + c];
+    if (c < CT) atomicAdd(a.dw + (int64_t)(oc0 + oc) * CT + c, v);
+    else if (a.dbias) atomicAdd(a.dbias + oc0 + oc, v);
   }
 }
 
@@ -158,8 +249,8 @@ int check_stem(const pb_stem_shape* s, int x_dtype, pb_dtype dtype, const char* 
                s->Ho > 0 && s->Wo > 0, "%s: non-positive dimension", who);
   PB_CHECK_ARG(s->Cin * s->kt * s->kh * s->kw <= MAX_CT, "%s: Cin*taps = %d exceeds %d", who,
                s->Cin * s->kt * s->kh * s->kw, MAX_CT);
-  PB_CHECK_ARG((s->To - 1) * s->st - s->pt < s->Ti && (s->Ho - 1) * s->sh - s->ph < s->Hi &&
-               (s->Wo - 1) * s->sw - s->pw < s->Wi, "%s: output extent inconsistent", who);
+  PB_CHECK_ARG((s->To - 1) * s->st - s->pt < s->Ti + s->pt && (s->Ho - 1) * s->sh - s->ph < s->Hi + s->ph &&
+               (s->Wo - 1) * s->sw - s->pw < s->Wi + s->pw, "%s: output extent inconsistent", who);
   PB_CHECK_ARG(x_dtype >= 0 && x_dtype <= 2, "%s: bad x_dtype %d", who, x_dtype);
   PB_CHECK_ARG(dtype == PB_F32 || dtype == PB_BF16, "%s: bad dtype", who);
   return 0;
@@ -206,8 +297,12 @@ extern "C" int pb_stem_conv3d_bwd_weight(const void* dy, const void* x, int x_dt
   StemArgs a = {};
   a.x = x; a.x_scale = x_scale; a.y = const_cast<void*>(dy); a.dw = dw; a.dbias = dbias; a.s = *s;
   a.npix = (int64_t)s->N * s->To * s->Ho * s->Wo;
-  int64_t gx = pb_cdiv(a.npix, 2);
-  if (gx > 2048) gx = 2048;
+  const int wl = 31 * s->sw + s->kw;
+  PB_CHECK_ARG(s->kt * s->kh * wl * s->Cin <= SW_MAXWIN, "pb_stem_conv3d_bwd_weight: window %d exceeds %d elements",
+               s->kt * s->kh * wl * s->Cin, SW_MAXWIN);
+  const int64_t items = (int64_t)s->N * s->To * s->Ho * pb_cdiv(s->Wo, SW_PIX);
+  int64_t gx = pb_cdiv(items, 4);
+  if (gx > 1024) gx = 1024;
   dim3 grid((unsigned)gx, (unsigned)pb_cdiv(s->Cout, OCB));
   PB_STEM_DISPATCH(stem_wgrad_kernel, grid);
   PB_LAUNCH_CHECK();

@@ -10,6 +10,8 @@ import torch
 
 from . import _C
 
+REPL = _C.STAT_REPLICAS     # stats buffers are [REPL, 2, C] (include/picklebot_amd.h)
+
 ACT = {"none": _C.ACT_NONE, "relu": _C.ACT_RELU, "leaky_relu": _C.ACT_LEAKY_RELU, "hardswish": _C.ACT_HSWISH,
        "hardsigmoid": _C.ACT_HSIGMOID, "silu": _C.ACT_SILU}
 
@@ -30,11 +32,13 @@ def stop_profile():
     spans, _spans = _spans, None
     torch.cuda.synchronize()
     out = {}
-    for name, nbytes, e0, e1 in spans or []:
-        d = out.setdefault(name, dict(launches=0, ms=0.0, bytes=0))
-        d["launches"] += 1
-        d["ms"] += e0.elapsed_time(e1)
-        d["bytes"] += nbytes
+    for name, nbytes, e0, e1, detail in spans or []:
+        ms = e0.elapsed_time(e1)
+        for key in (name, name + " | " + detail):
+            d = out.setdefault(key, dict(launches=0, ms=0.0, bytes=0))
+            d["launches"] += 1
+            d["ms"] += ms
+            d["bytes"] += nbytes
     return out
 
 
@@ -42,7 +46,7 @@ def _nb(*ts):
     return sum(t.numel() * t.element_size() for t in ts if t is not None)
 
 
-def _launch(family, nbytes, fn, *args):
+def _launch(family, nbytes, fn, *args, detail=""):
     """Algorithmic bytes = every external input/output tensor once at its stored dtype."""
     if _spans is None:
         _C.call(fn, *args)
@@ -51,7 +55,7 @@ def _launch(family, nbytes, fn, *args):
     e0.record()
     _C.call(fn, *args)
     e1.record()
-    _spans.append((family, nbytes, e0, e1))
+    _spans.append((family, nbytes, e0, e1, detail))
 
 
 def _dt(t):
@@ -104,7 +108,7 @@ def pw_fwd(x, w, *, w_transposed=False, in_scale=None, in_shift=None, in_act="no
         raise ValueError(f"pw_fwd: K mismatch x {tuple(x.shape)} w {tuple(w.shape)} transposed={w_transposed}")
     _f32(in_scale, (K,), "in_scale"); _f32(in_shift, (K,), "in_shift")
     _f32(out_scale, (N,), "out_scale"); _f32(out_shift, (N,), "out_shift")
-    _f32(stats, (2, N), "stats")
+    _f32(stats, (REPL, 2, N), "stats")
     if row_scale is not None:
         if rows_per_group <= 0 or M % rows_per_group:
             raise ValueError("pw_fwd: rows_per_group must divide M")
@@ -113,7 +117,7 @@ def pw_fwd(x, w, *, w_transposed=False, in_scale=None, in_shift=None, in_act="no
     dev, st = _dev_stream(x)
     _launch("pw_gemm_bwd_data" if w_transposed else "pw_gemm_fwd", _nb(x, y, w), "pb_pwconv_fwd", _p(x), _p(w), _p(y), M, K, N, w.shape[1], int(w_transposed), _dt(x), _p(in_scale),
             _p(in_shift), ACT[in_act], float(in_slope), _p(row_scale), int(rows_per_group), _p(out_scale),
-            _p(out_shift), ACT[out_act], float(out_slope), _p(stats), dev, st)
+            _p(out_shift), ACT[out_act], float(out_slope), _p(stats), dev, st, detail=f"M{M} K{K} N{N}")
     return y
 
 
@@ -133,7 +137,7 @@ def pw_bwd_weight(dy, x, dw, *, in_scale=None, in_shift=None, in_act="none", in_
         _f32(row_scale, (M // rows_per_group, K), "row_scale")
     dev, st = _dev_stream(x)
     _launch("pw_wgrad", _nb(dy, x, dw), "pb_pwconv_bwd_weight", _p(dy), _p(x), _p(dw), M, K, N, _dt(x), _p(in_scale), _p(in_shift),
-            ACT[in_act], float(in_slope), _p(row_scale), int(rows_per_group), dev, st)
+            ACT[in_act], float(in_slope), _p(row_scale), int(rows_per_group), dev, st, detail=f"M{M} K{K} N{N}")
     return dw
 
 
@@ -173,7 +177,8 @@ def dw_fwd(x, w, kernel, stride, pad_front, pad_back=None, pool=None):
     y = torch.empty((N,) + out + (C,), dtype=x.dtype, device=x.device)
     s = _dw_shape(N, C, (T, H, W), out, kernel, stride, pad_front)
     dev, st = _dev_stream(x)
-    _launch("dw_fwd", _nb(x, y, w), "pb_dwconv3d_fwd", _p(x), _p(w), _p(y), ctypes.byref(s), _dt(x), _p(pool), dev, st)
+    _launch("dw_fwd", _nb(x, y, w), "pb_dwconv3d_fwd", _p(x), _p(w), _p(y), ctypes.byref(s), _dt(x), _p(pool), dev, st,
+            detail=f"C{C} {T}x{H}x{W}->{out[0]}x{out[1]}x{out[2]} k{kernel} s{stride}")
     return y
 
 
@@ -185,7 +190,8 @@ def dw_bwd_data(dy, w, in_thw, kernel, stride, pad_front, g_scale=None, g_shift=
     dx = torch.empty((N,) + tuple(in_thw) + (C,), dtype=dy.dtype, device=dy.device)
     s = _dw_shape(N, C, in_thw, (To, Ho, Wo), kernel, stride, pad_front)
     dev, st = _dev_stream(dy)
-    _launch("dw_bwd_data", _nb(dy, dx, w), "pb_dwconv3d_bwd_data", _p(dy), _p(w), _p(dx), ctypes.byref(s), _dt(dy), _p(g_scale), _p(g_shift), dev, st)
+    _launch("dw_bwd_data", _nb(dy, dx, w), "pb_dwconv3d_bwd_data", _p(dy), _p(w), _p(dx), ctypes.byref(s), _dt(dy), _p(g_scale), _p(g_shift), dev, st,
+            detail=f"C{C} {To}x{Ho}x{Wo}->{tuple(in_thw)} k{kernel} s{stride}")
     return dx
 
 
@@ -198,7 +204,8 @@ def dw_bwd_weight(dy, x, dw, kernel, stride, pad_front, g_scale=None, g_shift=No
     _f32(g_scale, (N, C), "g_scale"); _f32(g_shift, (N, C), "g_shift")
     s = _dw_shape(N, C, tuple(x.shape[1:4]), (To, Ho, Wo), kernel, stride, pad_front)
     dev, st = _dev_stream(dy)
-    _launch("dw_bwd_weight", _nb(dy, x, dw), "pb_dwconv3d_bwd_weight", _p(dy), _p(x), _p(dw), ctypes.byref(s), _dt(dy), _p(g_scale), _p(g_shift), dev, st)
+    _launch("dw_bwd_weight", _nb(dy, x, dw), "pb_dwconv3d_bwd_weight", _p(dy), _p(x), _p(dw), ctypes.byref(s), _dt(dy), _p(g_scale), _p(g_shift), dev, st,
+            detail=f"C{C} {tuple(x.shape[1:4])}->{To}x{Ho}x{Wo} k{kernel} s{stride}")
     return dw
 
 
@@ -224,7 +231,7 @@ def stem_fwd(x, w, bias, kernel, stride, pad, out_dtype, x_scale=1.0, stats=None
     if x.dim() != 5 or x.dtype not in _XDT:
         raise ValueError(f"stem_fwd: bad input {tuple(x.shape)} {x.dtype}")
     cout = w.shape[0]
-    _f32(w, (cout, x.shape[1], *kernel), "w"); _f32(bias, (cout,), "bias"); _f32(stats, (2, cout), "stats")
+    _f32(w, (cout, x.shape[1], *kernel), "w"); _f32(bias, (cout,), "bias"); _f32(stats, (REPL, 2, cout), "stats")
     out = dw_out_shape(tuple(x.shape[2:]), kernel, stride, pad)
     y = torch.empty((x.shape[0],) + out + (cout,), dtype=out_dtype, device=x.device)
     s = _stem_shape(x, cout, out, kernel, stride, pad)
@@ -248,7 +255,7 @@ def stem_bwd_weight(dy, x, dw, dbias, kernel, stride, pad, x_scale=1.0):
 # ------------------------------------------------------------------------------ statistics / norm / activation
 def chan_stats(x, stats):
     _rows(x, "x")
-    _f32(stats, (2, x.shape[1]), "stats")
+    _f32(stats, (REPL, 2, x.shape[1]), "stats")
     dev, st = _dev_stream(x)
     _launch("chan_stats", _nb(x), "pb_chan_stats", _p(x), x.shape[0], x.shape[1], _dt(x), _p(stats), dev, st)
     return stats
@@ -256,7 +263,7 @@ def chan_stats(x, stats):
 
 def bn_finalize(stats, count, gamma, beta, eps, momentum, running_mean, running_var, use_running, C, device):
     """-> (scale, shift, mean, rstd), each fp32 [C]; running stats updated in place when training."""
-    _f32(stats, (2, C), "stats"); _f32(gamma, (C,), "gamma"); _f32(beta, (C,), "beta")
+    _f32(stats, (REPL, 2, C), "stats"); _f32(gamma, (C,), "gamma"); _f32(beta, (C,), "beta")
     _f32(running_mean, (C,), "running_mean"); _f32(running_var, (C,), "running_var")
     out = torch.empty((4, C), dtype=torch.float32, device=device)
     ref = stats if stats is not None else running_mean
@@ -272,7 +279,7 @@ def affine_act_fwd(x, scale=None, shift=None, act="none", slope=0.0, row_scale=N
     """y = act(x*scale+shift) * row_scale[g] + row_shift[g]; stats[2,C] += (sum y, sum y^2)."""
     _rows(x, "x")
     M, C = x.shape
-    _f32(scale, (C,), "scale"); _f32(shift, (C,), "shift"); _f32(stats, (2, C), "stats")
+    _f32(scale, (C,), "scale"); _f32(shift, (C,), "shift"); _f32(stats, (REPL, 2, C), "stats")
     if row_scale is not None or row_shift is not None:
         if rows_per_group <= 0 or M % rows_per_group:
             raise ValueError("affine_act_fwd: rows_per_group must divide M")
@@ -299,7 +306,7 @@ def act_bwd_reduce(dy, z, *, scale=None, shift=None, act="none", slope=0.0, row_
         raise TypeError("act_bwd_reduce: dy/z dtype mismatch")
     for t, n in ((scale, "scale"), (shift, "shift"), (mean, "mean"), (rstd, "rstd")):
         _f32(t, (C,), n)
-    _f32(sums, (2, C), "sums")
+    _f32(sums, (REPL, 2, C), "sums")
     if row_scale is not None:
         if rows_per_group <= 0 or M % rows_per_group:
             raise ValueError("act_bwd_reduce: rows_per_group must divide M")
@@ -315,7 +322,7 @@ def act_bwd_reduce(dy, z, *, scale=None, shift=None, act="none", slope=0.0, row_
 def bn_bwd_finalize(sums, count, gamma, mean, rstd, training, want_affine_grads):
     """-> (A, B, Cc, dgamma, dbeta); dz = A*g + B*z + Cc."""
     C = mean.shape[0]
-    _f32(sums, (2, C), "sums"); _f32(gamma, (C,), "gamma"); _f32(mean, (C,), "mean"); _f32(rstd, (C,), "rstd")
+    _f32(sums, (REPL, 2, C), "sums"); _f32(gamma, (C,), "gamma"); _f32(mean, (C,), "mean"); _f32(rstd, (C,), "rstd")
     out = torch.empty((5, C), dtype=torch.float32, device=mean.device)
     dev, st = _dev_stream(mean)
     _launch("bn_bwd_finalize", _nb(out), "pb_bn_bwd_finalize", _p(sums), float(count), _p(gamma), _p(mean), _p(rstd), int(training), _p(out[0]),

@@ -62,12 +62,12 @@ def test_pw_fwd_prologue_epilogue_stats(K, M, Kd, N, G, dtype):
     kw = dict(in_scale=rnd((Kd,), seed=5) * 0.2 + 1, in_shift=rnd((Kd,), seed=6) * 0.1, in_act="hardswish",
               row_scale=torch.rand(G, Kd), rows_per_group=M // G, out_scale=rnd((N,), seed=7) * 0.2 + 1,
               out_shift=rnd((N,), seed=8) * 0.1, out_act="relu")
-    st_ref = torch.zeros(2, N)
+    st_ref = torch.zeros(R.REPL, 2, N)
     want = R.pw_fwd(x, w, stats=st_ref, **kw)
-    st = torch.zeros(2, N, device=DEV)
+    st = torch.zeros(R.REPL, 2, N, device=DEV)
     got = K.pw_fwd(dev(x), dev(w), stats=st, **{k: (dev(v) if torch.is_tensor(v) else v) for k, v in kw.items()})
     check("pw_fwd_fused", got, want, dtype)
-    check("pw_fwd_stats", st, st_ref, dtype)
+    check("pw_fwd_stats", st.sum(0), st_ref.sum(0), dtype)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -149,14 +149,14 @@ def test_stem(K, dtype, xdtype, layout, kernel, stride, pad, bias):
         x = x.contiguous()
     w = rnd((Cout, 3, *kernel), seed=17, scale=0.2)
     b = rnd((Cout,), seed=18, scale=0.1) if bias else None
-    st_ref, st = torch.zeros(2, Cout), torch.zeros(2, Cout, device=DEV)
+    st_ref, st = torch.zeros(R.REPL, 2, Cout), torch.zeros(R.REPL, 2, Cout, device=DEV)
     y_ref = R.stem_fwd(x, w, b, kernel, stride, pad, dtype, scale, st_ref)
     xd = base.to(DEV).permute(0, 4, 1, 2, 3)
     if layout == "ncdhw":
         xd = xd.contiguous()
     y = K.stem_fwd(xd, dev(w), dev(b), kernel, stride, pad, dtype, scale, st)
     check("stem_fwd", y, y_ref, dtype)
-    check("stem_stats", st, st_ref, dtype)
+    check("stem_stats", st.sum(0), st_ref.sum(0), dtype)
     dy = rnd(tuple(y_ref.shape), dtype, 19)
     dw_ref, db_ref = torch.zeros_like(w), (torch.zeros(Cout) if bias else None)
     R.stem_bwd_weight(dy, x, dw_ref, db_ref, kernel, stride, pad, scale)
@@ -172,9 +172,9 @@ def test_stem(K, dtype, xdtype, layout, kernel, stride, pad, bias):
                                    (5 * 7, 2048, 5)])
 def test_norm_act_family(K, M, C, G, dtype):
     x = rnd((M, C), dtype, 20)
-    st_ref, st = torch.zeros(2, C), torch.zeros(2, C, device=DEV)
+    st_ref, st = torch.zeros(R.REPL, 2, C), torch.zeros(R.REPL, 2, C, device=DEV)
     R.chan_stats(x, st_ref); K.chan_stats(dev(x), st)
-    check("chan_stats", st, st_ref, dtype)
+    check("chan_stats", st.sum(0), st_ref.sum(0), dtype)
     gamma, beta = rnd((C,), seed=21) * 0.1 + 1, rnd((C,), seed=22) * 0.1
     rm_ref, rv_ref = rnd((C,), seed=23) * 0.1, torch.rand(C) + 0.5
     rm, rv = dev(rm_ref.clone()), dev(rv_ref.clone())
@@ -187,27 +187,27 @@ def test_norm_act_family(K, M, C, G, dtype):
     scale, shift, mean, rstd = out_ref
     rs, rsh = torch.rand(G, C) + 0.5, rnd((G, C), seed=24) * 0.1
     for act in ("none", "relu", "leaky_relu", "hardswish", "silu", "hardsigmoid"):
-        s2_ref, s2 = torch.zeros(2, C), torch.zeros(2, C, device=DEV)
+        s2_ref, s2 = torch.zeros(R.REPL, 2, C), torch.zeros(R.REPL, 2, C, device=DEV)
         y_ref = R.affine_act_fwd(x, scale, shift, act, 0.01, rs, M // G, s2_ref, rsh)
         y = K.affine_act_fwd(dev(x), dev(scale), dev(shift), act, 0.01, dev(rs), M // G, s2, dev(rsh))
         check("affine_act_" + act, y, y_ref, dtype)
-        check("affine_act_stats_" + act, s2, s2_ref, dtype, 2.0)
+        check("affine_act_stats_" + act, s2.sum(0), s2_ref.sum(0), dtype, 2.0)
         dy = rnd((M, C), dtype, 25)
-        sm_ref, sm = torch.zeros(2, C), torch.zeros(2, C, device=DEV)
+        sm_ref, sm = torch.zeros(R.REPL, 2, C), torch.zeros(R.REPL, 2, C, device=DEV)
         g_ref = R.act_bwd_reduce(dy, x, scale=scale, shift=shift, act=act, slope=0.01, row_scale=rs, rows_per_group=M // G,
                                  mean=mean, rstd=rstd, sums=sm_ref)
         g = K.act_bwd_reduce(dev(dy), dev(x), scale=dev(scale), shift=dev(shift), act=act, slope=0.01, row_scale=dev(rs),
                              rows_per_group=M // G, mean=dev(mean), rstd=dev(rstd), sums=sm)
         check("act_bwd_" + act, g, g_ref, dtype)
-        check("act_bwd_sums_" + act, sm, sm_ref, dtype, 3.0)
+        check("act_bwd_sums_" + act, sm.sum(0), sm_ref.sum(0), dtype, 3.0)
     # broadcast gradient (pool backward)
     dyb = rnd((G, C), dtype, 26)
-    sm_ref, sm = torch.zeros(2, C), torch.zeros(2, C, device=DEV)
+    sm_ref, sm = torch.zeros(R.REPL, 2, C), torch.zeros(R.REPL, 2, C, device=DEV)
     g_ref = R.act_bwd_reduce(dyb, x, scale=scale, shift=shift, act="hardswish", dy_rows_per_group=M // G, dy_mul=0.25,
                              mean=mean, rstd=rstd, sums=sm_ref)
     g = K.act_bwd_reduce(dev(dyb), dev(x), scale=dev(scale), shift=dev(shift), act="hardswish", dy_rows_per_group=M // G,
                          dy_mul=0.25, mean=dev(mean), rstd=dev(rstd), sums=sm)
-    check("act_bwd_bcast", g, g_ref, dtype); check("act_bwd_bcast_sums", sm, sm_ref, dtype, 3.0)
+    check("act_bwd_bcast", g, g_ref, dtype); check("act_bwd_bcast_sums", sm.sum(0), sm_ref.sum(0), dtype, 3.0)
     fin_ref = R.bn_bwd_finalize(sm_ref, M, gamma, mean, rstd, True, True)
     fin = K.bn_bwd_finalize(dev(sm_ref), M, dev(gamma), dev(mean), dev(rstd), True, True)
     for a, b, n in zip(fin, fin_ref, "ABCgb"):

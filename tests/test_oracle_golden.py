@@ -28,7 +28,7 @@ def test_model_matches_reference_golden(case, golden):
 def test_block_matches_reference_golden(case, golden):
     res = protocol.run_block_case(torch_ref, case)
     g = golden("blocks")
-    assert len([k for k in g if k.startswith(case + "/") and "/ref32_err/" not in k]) == len(res)
+    assert len([k for k in g if k.startswith(case + "/") and "_err/" not in k]) == len(res)
     bad, worst = compare_full(res, g, case + "/", TOL, TOL)
     assert not bad, f"{bad[:5]} worst {worst}"
 

@@ -17,7 +17,7 @@ for step in "$@"; do
     models) run models python -m pytest tests/test_models_gpu.py -q -m gpu -p no:cacheprovider ;;
     alltests) run alltests python -m pytest tests -q -m gpu -p no:cacheprovider ;;
     smoke) run smoke python -c "import __graft_entry__ as g; g.smoke()" ;;
-    bench) run bench python bench.py --steps ${BENCH_STEPS:-10} --warmup 3 ;;
+    bench) PB_BENCH_DETAIL=gpurun_out/bench_detail.txt run bench python bench.py --steps ${BENCH_STEPS:-10} --warmup 3 ;;
     bench_small) run bench_small python bench.py --steps 5 --warmup 2 --batch 8 --no-cpu-baseline ;;
     *) echo "unknown step $step" ;;
   esac
