@@ -130,75 +130,82 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs a) {
   const T* B = (const T*)a.b;
   T* O = (T*)a.out;
   if (lane_ok) {
-    // each workgroup owns a contiguous row range (row groups change rarely inside it, so the
-    // clip index is tracked incrementally instead of a 64-bit division per row)
+    // each workgroup owns a contiguous row range; UNR rows per thread are loaded before any is
+    // consumed (UNR x 1-2 x 16 B in flight per lane)
+    constexpr int UNR = 4;
     const int64_t rows_wg = (a.M + gridDim.x - 1) / gridDim.x;
     const int64_t mlo = (int64_t)blockIdx.x * rows_wg, mhi = min(a.M, mlo + rows_wg);
-    int64_t m = mlo + p;
-    int64_t grp = (a.row_scale || a.row_shift) ? m / a.rows_per_group : 0;
-    int64_t grp_end = (grp + 1) * a.rows_per_group;
-    int64_t dgrp = a.dy_rows_per_group > 0 ? m / a.dy_rows_per_group : 0;
-    int64_t dgrp_end = (dgrp + 1) * a.dy_rows_per_group;
-    for (; m < mhi; m += mp.P) {
-      if (a.row_scale || a.row_shift) {
-        while (m >= grp_end) { ++grp; grp_end += a.rows_per_group; }
-      }
-      if constexpr (MODE == 2) {
-        if (a.dy_rows_per_group > 0) {
-          while (m >= dgrp_end) { ++dgrp; dgrp_end += a.dy_rows_per_group; }
-        }
-      }
-      float va[CH], vb[CH], vo[CH], rsc[CH], rsh[CH];
-      const int64_t off = m * a.C + c0;
-      if constexpr (MODE == 2) {
-        if (a.dy_rows_per_group > 0) {
-          ld<T, CH>(A + dgrp * a.C + c0, va);
-        } else {
-          ld<T, CH>(A + off, va);
-        }
-      } else {
-        ld<T, CH>(A + off, va);
-      }
-      if constexpr (MODE == 2 || MODE == 3) {
-        if (B) ld<T, CH>(B + off, vb);
-        else {
+    const bool has_row = a.row_scale || a.row_shift;
+    for (int64_t mb = mlo + p; mb < mhi; mb += (int64_t)UNR * mp.P) {
+      float va[UNR][CH], vb[UNR][CH], rsc[UNR][CH], rsh[UNR][CH];
+      bool ok[UNR];
 #pragma unroll
-          for (int i = 0; i < CH; ++i) vb[i] = 0.f;
+      for (int u = 0; u < UNR; ++u) {
+        const int64_t m = mb + (int64_t)u * mp.P;
+        ok[u] = m < mhi;
+        const int64_t mc = ok[u] ? m : mlo + p;          // shadow a valid row, discard later
+        const int64_t off = mc * a.C + c0;
+        if constexpr (MODE == 2) {
+          if (a.dy_rows_per_group > 0) ld<T, CH>(A + (int64_t)((uint32_t)mc / (uint32_t)a.dy_rows_per_group) * a.C + c0, va[u]);
+          else ld<T, CH>(A + off, va[u]);
+        } else {
+          ld<T, CH>(A + off, va[u]);
+        }
+        if constexpr (MODE == 2 || MODE == 3) {
+          if (B) ld<T, CH>(B + off, vb[u]);
+          else {
+#pragma unroll
+            for (int i = 0; i < CH; ++i) vb[u][i] = 0.f;
+          }
+        }
+        if constexpr (MODE == 1 || MODE == 2) {
+#pragma unroll
+          for (int i = 0; i < CH; ++i) { rsc[u][i] = 1.f; rsh[u][i] = 0.f; }
+          if (has_row) {
+            const int64_t grp = (int64_t)((uint32_t)mc / (uint32_t)a.rows_per_group);
+            if (a.row_scale) {
+              const float* rp = a.row_scale + grp * a.C + c0;
+#pragma unroll
+              for (int i = 0; i < CH; ++i) rsc[u][i] = rp[i];
+            }
+            if (a.row_shift) {
+              const float* rq = a.row_shift + grp * a.C + c0;
+#pragma unroll
+              for (int i = 0; i < CH; ++i) rsh[u][i] = rq[i];
+            }
+          }
         }
       }
-      if constexpr (MODE == 1 || MODE == 2) {
-        const float* rp = a.row_scale ? a.row_scale + grp * a.C + c0 : nullptr;
-        const float* rq = a.row_shift ? a.row_shift + grp * a.C + c0 : nullptr;
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        if (!ok[u]) continue;
+        const int64_t off = (mb + (int64_t)u * mp.P) * a.C + c0;
+        float vo[CH];
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
-          rsc[i] = rp ? rp[i] : 1.f;
-          rsh[i] = rq ? rq[i] : 0.f;
+          if constexpr (MODE == 0) {
+            acc[0][i] += va[u][i];
+            acc[1][i] += va[u][i] * va[u][i];
+          } else if constexpr (MODE == 1) {
+            const float y = act_fwd(va[u][i] * sc[i] + sh[i], a.act, a.slope) * rsc[u][i] + rsh[u][i];
+            vo[i] = y;
+            const float yr = to_f32(from_f32<T>(y));
+            acc[0][i] += yr;
+            acc[1][i] += yr * yr;
+          } else if constexpr (MODE == 2) {
+            const float pre = vb[u][i] * sc[i] + sh[i];
+            const float g = va[u][i] * a.dy_mul * rsc[u][i] * act_bwd(pre, a.act, a.slope);
+            vo[i] = g;
+            const float gr = O ? to_f32(from_f32<T>(g)) : g;
+            acc[0][i] += gr;
+            acc[1][i] += gr * (vb[u][i] - mu[i]) * rs[i];
+          } else {
+            vo[i] = kA[i] * va[u][i] + kB[i] * vb[u][i] + kC[i];
+          }
         }
-      }
-#pragma unroll
-      for (int i = 0; i < CH; ++i) {
-        if constexpr (MODE == 0) {
-          acc[0][i] += va[i];
-          acc[1][i] += va[i] * va[i];
-        } else if constexpr (MODE == 1) {
-          const float y = act_fwd(va[i] * sc[i] + sh[i], a.act, a.slope) * rsc[i] + rsh[i];
-          vo[i] = y;
-          const float yr = to_f32(from_f32<T>(y));
-          acc[0][i] += yr;
-          acc[1][i] += yr * yr;
-        } else if constexpr (MODE == 2) {
-          const float pre = vb[i] * sc[i] + sh[i];
-          const float g = va[i] * a.dy_mul * rsc[i] * act_bwd(pre, a.act, a.slope);
-          vo[i] = g;
-          const float gr = O ? to_f32(from_f32<T>(g)) : g;
-          acc[0][i] += gr;
-          acc[1][i] += gr * (vb[i] - mu[i]) * rs[i];
-        } else {
-          vo[i] = kA[i] * va[i] + kB[i] * vb[i] + kC[i];
+        if constexpr (MODE != 0) {
+          if (O) stv<T, CH>(O + off, vo);
         }
-      }
-      if constexpr (MODE != 0) {
-        if (O) stv<T, CH>(O + off, vo);
       }
     }
   }
@@ -218,7 +225,8 @@ int launch_ew(EwArgs a, hipStream_t st) {
   a.map = vec ? make_map<VEC>(a.C) : make_map<1>(a.C);
   // >= 4 rows per thread; reducing launches stay <= ~512 workgroups per channel chunk so that, with the
   // 16 stats replicas, an address sees <= 32 same-address atomics
-  int64_t gx = pb_cdiv(a.M, (int64_t)a.map.P * 4);
+  PB_CHECK_ARG(a.M < 0x7fffffffLL, "elementwise kernels: M must fit 31 bits");
+  int64_t gx = pb_cdiv(a.M, (int64_t)a.map.P * 8);
   const int64_t cap = a.sums ? pb_cdiv(512, 1) : pb_cdiv(8192, a.map.chunks);
   if (gx > cap) gx = cap;
   if (gx < 1) gx = 1;

@@ -80,10 +80,15 @@ template <typename T>
 __device__ __forceinline__ Vec16<T> apply_prologue(Vec16<T> v, const RowScale<T>& rs, const PwArgs& a, int k) {
   constexpr int VEC = ElemTraits<T>::VEC;
   const bool affine = a.in_scale || a.in_shift || a.in_act != PB_ACT_NONE;
+  if (!affine) {            // squeeze-excite scale only (the training path): branch-free
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) v.set(i, v.get(i) * rs.v[i]);
+    return v;
+  }
 #pragma unroll
   for (int i = 0; i < VEC; ++i) {
     float x = v.get(i);
-    if (affine && k + i < a.K) {
+    if (k + i < a.K) {
       if (a.in_scale) x *= a.in_scale[k + i];
       if (a.in_shift) x += a.in_shift[k + i];
       x = act_fwd(x, a.in_act, a.in_slope);
@@ -132,10 +137,13 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
   constexpr int WCH = (BN * 8 + 255) / 256;            // weight chunks per thread (row-major W)
   constexpr int NQ = BN / 4;
   constexpr int WTQ = (KS * NQ + 255) / 256;           // float4 loads per thread (transposed W)
-  __shared__ __attribute__((aligned(16))) unsigned char smem[A_BYTES + W_BYTES + 4 * BN * 2 * 4];
+  constexpr int RS_MAXK = 1536;                          // squeeze-excite scale rows cached per tile: [2 clips][K]
+  constexpr int RS_BYTES = PRO ? 2 * RS_MAXK * 4 : 0;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[A_BYTES + W_BYTES + 4 * BN * 2 * 4 + RS_BYTES];
   unsigned char* As = smem;
   unsigned char* Ws = smem + A_BYTES;
   float* sred = (float*)(smem + A_BYTES + W_BYTES);   // [4 waves][BN][2]
+  float* rsS = (float*)(smem + A_BYTES + W_BYTES + 4 * BN * 2 * 4);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const T* X = (const T*)a.X;
@@ -160,6 +168,9 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
 
   Vec16<T> ra[ACH];
   RowScale<T> rsa[PRO ? ACH : 1];
+  // row scales come from an LDS cache of the tile's (at most two) clips when they fit
+  const bool rs_lds = PRO && a.row_scale && a.K <= RS_MAXK && (a.K & 3) == 0 && a.rows_per_group >= BM;
+  int64_t cur_g0_end = 0;
   Vec16<T> rw[TRANS ? 1 : WCH];
   f32x4 rt[TRANS ? WTQ : 1];
 
@@ -194,20 +205,38 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
         if (m < a.M && k < a.K) {
           if constexpr (ALIGNED) ra[i] = vec_load<T>(X + m * a.K + k);
           else ra[i] = load_row_chunk<T>(X, m, k, a.K, xvec);
-          if constexpr (PRO) rsa[i] = fetch_rowscale<T>(a, row_group(m, m0, g0, g0_end, a.rows_per_group), k);
+          if constexpr (PRO) {
+            if (!rs_lds) rsa[i] = fetch_rowscale<T>(a, row_group(m, m0, g0, g0_end, a.rows_per_group), k);
+          }
         }
       }
     }
   };
-  auto commit_a = [&](int ks) {
+  auto commit_a = [&](int t, int ks) {
     int kpad, csh;
     stage_dims(ks * KS, kpad, csh);
+    const int64_t m0 = (int64_t)tile_mt(t) * BM;
 #pragma unroll
     for (int i = 0; i < ACH; ++i) {
       const int f = tid + i * 256;
       if (f < (BM << csh)) {
         const int r = f >> csh, c = f & ((1 << csh) - 1);
-        if constexpr (PRO) ra[i] = apply_prologue<T>(ra[i], rsa[i], a, ks * KS + c * VEC);
+        if constexpr (PRO) {
+          const int k = ks * KS + c * VEC;
+          if (rs_lds) {
+            if (k < a.K) {
+              const float* src = rsS + ((m0 + r) >= cur_g0_end ? RS_MAXK : 0) + k;
+#pragma unroll
+              for (int q = 0; q < VEC / 4; ++q) {
+                const f32x4 tq = *reinterpret_cast<const f32x4*>(src + 4 * q);
+                rsa[i].v[4 * q] = tq[0]; rsa[i].v[4 * q + 1] = tq[1]; rsa[i].v[4 * q + 2] = tq[2]; rsa[i].v[4 * q + 3] = tq[3];
+              }
+            } else {
+              rsa[i].ones();
+            }
+          }
+          ra[i] = apply_prologue<T>(ra[i], rsa[i], a, k);
+        }
         vec_store<T>((T*)(As + r * LDB) + c * VEC, ra[i]);
       }
     }
@@ -344,7 +373,23 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
   fetch_a(t, 0);
   if (!w_cached) fetch_w(t, 0);
   while (t < total) {
-    commit_a(ks);
+    if constexpr (PRO) {
+      if (rs_lds && ks == 0) {
+        // this tile's clip rows of the scale matrix -> LDS (rows of a 128-row tile span <= 2 clips)
+        const int64_t m0 = (int64_t)tile_mt(t) * BM;
+        const int64_t g0 = m0 / a.rows_per_group;
+        const int64_t ng = (a.M + a.rows_per_group - 1) / a.rows_per_group;
+        cur_g0_end = (g0 + 1) * a.rows_per_group;
+        for (int i = tid; i < 2 * (a.K >> 2); i += 256) {
+          const int which = i >= (a.K >> 2), q = i - which * (a.K >> 2);
+          const int64_t g = min(g0 + which, ng - 1);
+          *reinterpret_cast<f32x4*>(rsS + which * RS_MAXK + 4 * q) =
+              *reinterpret_cast<const f32x4*>(a.row_scale + g * a.K + 4 * q);
+        }
+        lds_barrier();
+      }
+    }
+    commit_a(t, ks);
     if (!w_cached) commit_w(ks);
     lds_barrier();
     // issue the next stage's (or next tile's) global loads; they complete under the MFMAs below

@@ -109,16 +109,192 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemArgs a) {
   }
 }
 
+// Input window of SW_PIX consecutive output pixels of one output row, as [at][ah][wl][ci] in LDS
+// (zero outside the clip): row by row, lanes along the (pixel, channel) run - contiguous in memory for
+// the NDHWC clip, still correct for any strides.
+constexpr int FW_R = 9;      // max kt*kh window rows
+constexpr int FW_I = 4;      // max 64-lane sweeps per row (row length <= 256 elements)
+
+template <typename XT, typename T>
+__device__ __forceinline__ void fill_window(T* win, const XT* x, float x_scale, const pb_stem_shape& s, int n, int to,
+                                            int ho, int wo0, int WL, int lane) {
+  // two passes: every (clamped, unconditional) global load is issued first, only then converted and
+  // written to LDS - a load->use pair inside the sweep would cost one HBM round trip per iteration
+  const int ti0 = to * s.st - s.pt, hi0 = ho * s.sh - s.ph, wi0 = wo0 * s.sw - s.pw;
+  const int rowlen = WL * s.Cin, nrows = s.kt * s.kh;
+  const XT* xn = x + (int64_t)n * s.xs_n;
+  XT raw[FW_R][FW_I];
+  bool okm[FW_R][FW_I];
+#pragma unroll
+  for (int rr = 0; rr < FW_R; ++rr) {
+    const int rc = min(rr, nrows - 1);
+    const int at = rc / s.kh, ah = rc - at * s.kh;
+    const int ti = ti0 + at, hi = hi0 + ah;
+    const bool row_ok = rr < nrows && ti >= 0 && ti < s.Ti && hi >= 0 && hi < s.Hi;
+    const XT* base = xn + (int64_t)min(max(ti, 0), s.Ti - 1) * s.xs_t + (int64_t)min(max(hi, 0), s.Hi - 1) * s.xs_h;
+#pragma unroll
+    for (int it = 0; it < FW_I; ++it) {
+      const int e = min(lane + 64 * it, rowlen - 1);
+      const int wl = e / s.Cin, ci = e - wl * s.Cin;
+      const int wi = wi0 + wl;
+      okm[rr][it] = row_ok && wi >= 0 && wi < s.Wi;
+      raw[rr][it] = base[(int64_t)min(max(wi, 0), s.Wi - 1) * s.xs_w + (int64_t)ci * s.xs_c];
+    }
+  }
+#pragma unroll
+  for (int rr = 0; rr < FW_R; ++rr)
+#pragma unroll
+    for (int it = 0; it < FW_I; ++it) {
+      const int e = lane + 64 * it;
+      if (rr < nrows && e < rowlen) win[rr * rowlen + e] = from_f32<T>(okm[rr][it] ? (float)raw[rr][it] * x_scale : 0.f);
+    }
+}
+
+constexpr int SW_PIX = 32;          // pixels per wave step
+constexpr int SW_MAXWIN = 2048;     // LDS window elements per wave (kt*kh*(31*sw+kw)*Cin)
+constexpr int SW_NB = 8;            // column blocks of 16 (Cin*taps + 1 <= 128)
+constexpr int SW_KS = 4;            // 32-wide k steps of the forward GEMM (Cin*taps <= 128)
+
+// Forward as an MFMA GEMM over the same LDS window: out[pixel][oc] = sum_col patch[pixel][col] * W[oc][col].
+// A = im2col gathers from the window (16 pixels x 32 columns per MFMA), B = the filter (kept in
+// registers for the whole walk), 32 pixels per wave step.  The [32][16] result goes through a
+// wave-private LDS tile so that the store is one contiguous 16 B/lane run; BatchNorm statistics are
+// accumulated in registers over the walk.
+template <typename XT, typename T>
+__global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(StemArgs a) {
+  __shared__ __attribute__((aligned(16))) T win_s[4][SW_MAXWIN];
+  __shared__ __attribute__((aligned(16))) T out_s[4][SW_PIX * OCB];
+  __shared__ float red[2 * OCB];
+  const pb_stem_shape& s = a.s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int taps = s.kt * s.kh * s.kw, CT = s.Cin * taps;
+  const int nks = (CT + 31) / 32;
+  const int oc0 = blockIdx.y * OCB;
+  const int WL = (SW_PIX - 1) * s.sw + s.kw;
+  const int wblocks = (s.Wo + SW_PIX - 1) / SW_PIX;
+  const int64_t nitems = (int64_t)s.N * s.To * s.Ho * wblocks;
+  const XT* x = (const XT*)a.x;
+  T* y = (T*)a.y;
+  T* win = win_s[wave];
+  T* outt = out_s[wave];
+  if (tid < 2 * OCB) red[tid] = 0.f;
+  __syncthreads();
+  const int row = lane & 15, g = lane >> 4;          // A: pixel row / k group; B: oc / k group; D: oc column, row group
+  // filter fragments: lane (oc = row, g) holds W[oc][32*ks + 8g + j]; window offsets of this lane's 8 columns
+  float wf[SW_KS][8];
+  int coff[SW_KS][8];
+#pragma unroll
+  for (int ks = 0; ks < SW_KS; ++ks)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = ks * 32 + g * 8 + j;
+      const bool cv = c < CT && ks < nks;
+      wf[ks][j] = (cv && oc0 + row < s.Cout) ? a.w[(int64_t)(oc0 + row) * CT + c] : 0.f;
+      const int ci = cv ? c / taps : 0;
+      const int tp = cv ? c - ci * taps : 0;
+      const int aw = tp % s.kw, ah = (tp / s.kw) % s.kh, at = tp / (s.kw * s.kh);
+      coff[ks][j] = cv ? ((at * s.kh + ah) * WL + aw) * s.Cin + ci : -1;
+    }
+  const float bias = (a.bias && oc0 + row < s.Cout) ? a.bias[oc0 + row] : 0.f;
+  float ssum = 0.f, ssq = 0.f;
+
+  for (int64_t it = (int64_t)blockIdx.x * 4 + wave; it < nitems; it += (int64_t)gridDim.x * 4) {
+    int64_t r = it;
+    const int wb = (int)(r % wblocks); r /= wblocks;
+    const int ho = (int)(r % s.Ho); r /= s.Ho;
+    const int to = (int)(r % s.To);
+    const int n = (int)(r / s.To);
+    const int wo0 = wb * SW_PIX;
+    const int npx = min(SW_PIX, s.Wo - wo0);
+    fill_window<XT, T>(win, x, a.x_scale, s, n, to, ho, wo0, WL, lane);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    f32x4 acc[2];
+    acc[0] = acc[1] = f32x4{bias, bias, bias, bias};
+#pragma unroll
+    for (int ks = 0; ks < SW_KS; ++ks) {
+      if (ks < nks) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          const int pbase = (mt * 16 + row) * s.sw * s.Cin;
+          if constexpr (sizeof(T) == 2) {
+            bf16x8 fa, fb;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              fa[j] = coff[ks][j] >= 0 ? win[coff[ks][j] + pbase] : (bf16_t)0.f;
+              fb[j] = (bf16_t)wf[ks][j];
+            }
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc[mt], 0, 0, 0);
+          } else {
+            // exact-f32 16x16x4: lane (row, g) supplies k = 4g + s per step; 8 steps cover this lane group's
+            // 32 columns in the order (j = 2s' + ...): use columns 8g'+j with g' = k group of the step
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              // step j: lane group g contributes column 32*ks + 8g + j  (any consistent A/B pairing is valid)
+              const float fa = coff[ks][j] >= 0 ? win[coff[ks][j] + pbase] : 0.f;
+              acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa, wf[ks][j], acc[mt], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+    // D map: column = oc = lane & 15, rows = pixels (lane>>4)*4 + r
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int p = mt * 16 + g * 4 + rr;
+        const T tv = from_f32<T>(acc[mt][rr]);
+        outt[p * OCB + row] = tv;
+        if (a.stats && p < npx && oc0 + row < s.Cout) {
+          const float fv = to_f32(tv);
+          ssum += fv;
+          ssq += fv * fv;
+        }
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    {
+      const int64_t pix0 = (((int64_t)n * s.To + to) * s.Ho + ho) * s.Wo + wo0;
+      constexpr int VEC = ElemTraits<T>::VEC;
+      if (oc0 + OCB <= s.Cout && s.Cout == OCB) {
+        // the 32x16 tile is one contiguous run of the output
+        for (int e = lane; e < SW_PIX * OCB / VEC; e += 64) {
+          const int p = e * VEC / OCB;
+          if (p < npx) vec_store<T>(y + pix0 * OCB + (int64_t)e * VEC, vec_load<T>(outt + e * VEC));
+        }
+      } else {
+        for (int e = lane; e < SW_PIX * OCB; e += 64) {
+          const int p = e / OCB, oc = e - p * OCB;
+          if (p < npx && oc0 + oc < s.Cout) y[(pix0 + p) * s.Cout + oc0 + oc] = outt[e];
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (a.stats) {
+    ssum += __shfl_xor(ssum, 16, 64); ssum += __shfl_xor(ssum, 32, 64);
+    ssq += __shfl_xor(ssq, 16, 64); ssq += __shfl_xor(ssq, 32, 64);
+    if (lane < 16) {
+      atomicAdd(&red[lane], ssum);
+      atomicAdd(&red[OCB + lane], ssq);
+    }
+    __syncthreads();
+    if (tid < OCB && oc0 + tid < s.Cout) {
+      float* st = a.stats + (size_t)(blockIdx.x % PB_STAT_REPLICAS) * 2 * s.Cout;
+      atomicAdd(st + oc0 + tid, red[tid]);
+      atomicAdd(st + s.Cout + oc0 + tid, red[OCB + tid]);
+    }
+  }
+}
+
 // Weight gradient as a small MFMA GEMM: dW[oc][col] = sum_pix dy[pix][oc] * patch[pix][col],
 // col = (ci, tap) (+ one virtual column of ones for the bias).  Each wave walks blocks of 32
 // consecutive output pixels of one output row: dy's [32][16] tile is one contiguous 1 KB read,
 // the input window those pixels see (kt x kh rows of 31*sw+kw pixels) is staged once in LDS, and
 // the MFMA "k" index is the pixel: A = dy^T (transposing LDS read for bf16), B = im2col gathers
 // from the LDS window.  Accumulators persist over the wave's whole walk.
-constexpr int SW_PIX = 32;          // pixels per wave step
-constexpr int SW_MAXWIN = 2048;     // LDS window elements per wave (kt*kh*(31*sw+kw)*Cin)
-constexpr int SW_NB = 8;            // column blocks of 16 (Cin*taps + 1 <= 128)
-
 template <typename XT, typename T>
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemArgs a) {
   __shared__ __attribute__((aligned(16))) T win_s[4][SW_MAXWIN];
@@ -167,26 +343,21 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemArgs a) {
     // dy tile [32][16] (rows past the row end are zero: they then contribute nothing)
     {
       const int64_t pix0 = (((int64_t)n * s.To + to) * s.Ho + ho) * s.Wo + wo0;
-      for (int e = lane; e < SW_PIX * OCB; e += 64) {
-        const int p = e / OCB, oc = e - p * OCB;
-        dyt[e] = (p < npx && oc0 + oc < s.Cout) ? dy[(pix0 + p) * s.Cout + oc0 + oc] : from_f32<T>(0.f);
+      constexpr int VEC = ElemTraits<T>::VEC;
+      if (s.Cout == OCB) {
+        // the [32][16] tile is one contiguous run: 16 B per lane
+        for (int e = lane; e < SW_PIX * OCB / VEC; e += 64) {
+          const int p = e * VEC / OCB;
+          vec_store<T>(dyt + e * VEC, p < npx ? vec_load<T>(dy + pix0 * OCB + (int64_t)e * VEC) : vec_zero<T>());
+        }
+      } else {
+        for (int e = lane; e < SW_PIX * OCB; e += 64) {
+          const int p = e / OCB, oc = e - p * OCB;
+          dyt[e] = (p < npx && oc0 + oc < s.Cout) ? dy[(pix0 + p) * s.Cout + oc0 + oc] : from_f32<T>(0.f);
+        }
       }
     }
-    // input window: [at][ah][wl][ci], zero outside the clip
-    {
-      const int ti0 = to * s.st - s.pt, hi0 = ho * s.sh - s.ph, wi0 = wo0 * s.sw - s.pw;
-      const int rowlen = WL * s.Cin;
-      for (int e = lane; e < win_elems; e += 64) {
-        const int rr = e / rowlen, q = e - rr * rowlen;
-        const int at = rr / s.kh, ah = rr - at * s.kh;
-        const int wl = q / s.Cin, ci = q - wl * s.Cin;
-        const int ti = ti0 + at, hi = hi0 + ah, wi = wi0 + wl;
-        float v = 0.f;
-        if (ti >= 0 && ti < s.Ti && hi >= 0 && hi < s.Hi && wi >= 0 && wi < s.Wi)
-          v = ldx<XT>(x + (int64_t)n * s.xs_n + ci * s.xs_c + ti * s.xs_t + hi * s.xs_h + wi * s.xs_w) * a.x_scale;
-        win[e] = from_f32<T>(v);
-      }
-    }
+    fill_window<XT, T>(win, x, a.x_scale, s, n, to, ho, wo0, WL, lane);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
     if constexpr (sizeof(T) == 2) {
@@ -281,8 +452,18 @@ extern "C" int pb_stem_conv3d_fwd(const void* x, int x_dtype, float x_scale, con
   StemArgs a = {};
   a.x = x; a.x_scale = x_scale; a.w = w; a.bias = bias; a.y = y; a.stats = stats; a.s = *s;
   a.npix = (int64_t)s->N * s->To * s->Ho * s->Wo;
-  dim3 grid((unsigned)pb_cdiv(a.npix, 256), (unsigned)pb_cdiv(s->Cout, OCB));
-  PB_STEM_DISPATCH(stem_fwd_kernel, grid);
+  const int wl = 31 * s->sw + s->kw;
+  if (s->kt * s->kh * wl * s->Cin <= SW_MAXWIN && s->Cin * s->kt * s->kh * s->kw <= 32 * SW_KS &&
+      s->kt * s->kh <= FW_R && wl * s->Cin <= 64 * FW_I) {
+    const int64_t items = (int64_t)s->N * s->To * s->Ho * pb_cdiv(s->Wo, SW_PIX);
+    int64_t gx = pb_cdiv(items, 4);
+    if (gx > 2048) gx = 2048;
+    dim3 grid((unsigned)gx, (unsigned)pb_cdiv(s->Cout, OCB));
+    PB_STEM_DISPATCH(stem_fwd_mfma_kernel, grid);
+  } else {
+    dim3 grid((unsigned)pb_cdiv(a.npix, 256), (unsigned)pb_cdiv(s->Cout, OCB));
+    PB_STEM_DISPATCH(stem_fwd_kernel, grid);
+  }
   PB_LAUNCH_CHECK();
   return 0;
 }
@@ -298,8 +479,8 @@ extern "C" int pb_stem_conv3d_bwd_weight(const void* dy, const void* x, int x_dt
   a.x = x; a.x_scale = x_scale; a.y = const_cast<void*>(dy); a.dw = dw; a.dbias = dbias; a.s = *s;
   a.npix = (int64_t)s->N * s->To * s->Ho * s->Wo;
   const int wl = 31 * s->sw + s->kw;
-  PB_CHECK_ARG(s->kt * s->kh * wl * s->Cin <= SW_MAXWIN, "pb_stem_conv3d_bwd_weight: window %d exceeds %d elements",
-               s->kt * s->kh * wl * s->Cin, SW_MAXWIN);
+  PB_CHECK_ARG(s->kt * s->kh * wl * s->Cin <= SW_MAXWIN && s->kt * s->kh <= FW_R && wl * s->Cin <= 64 * FW_I,
+               "pb_stem_conv3d_bwd_weight: window (%d rows x %d) exceeds the staged maximum", s->kt * s->kh, wl * s->Cin);
   const int64_t items = (int64_t)s->N * s->To * s->Ho * pb_cdiv(s->Wo, SW_PIX);
   int64_t gx = pb_cdiv(items, 4);
   if (gx > 1024) gx = 1024;

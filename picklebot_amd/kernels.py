@@ -115,7 +115,14 @@ def pw_fwd(x, w, *, w_transposed=False, in_scale=None, in_shift=None, in_act="no
         _f32(row_scale, (M // rows_per_group, K), "row_scale")
     y = torch.empty((M, N), dtype=x.dtype, device=x.device)
     dev, st = _dev_stream(x)
-    _launch("pw_gemm_bwd_data" if w_transposed else "pw_gemm_fwd", _nb(x, y, w), "pb_pwconv_fwd", _p(x), _p(w), _p(y), M, K, N, w.shape[1], int(w_transposed), _dt(x), _p(in_scale),
+    family = "pw_gemm_bwd_data" if w_transposed else "pw_gemm_fwd"
+    if w_transposed and N * K >= 4096:
+        # backward-data reads W transposed; staging a transposed tile costs scattered 2-byte LDS writes in
+        # every workgroup and K stage (2x on the wide layers), transposing the (<= 0.6 MB) matrix once is ~free
+        wt = torch.empty((N, K), dtype=torch.float32, device=w.device)
+        _launch("transpose_w", _nb(w, wt), "pb_transpose_f32", _p(w), _p(wt), K, N, dev, st)
+        w, w_transposed = wt, False
+    _launch(family, _nb(x, y, w), "pb_pwconv_fwd", _p(x), _p(w), _p(y), M, K, N, w.shape[1], int(w_transposed), _dt(x), _p(in_scale),
             _p(in_shift), ACT[in_act], float(in_slope), _p(row_scale), int(rows_per_group), _p(out_scale),
             _p(out_shift), ACT[out_act], float(out_slope), _p(stats), dev, st, detail=f"M{M} K{K} N{N}")
     return y
