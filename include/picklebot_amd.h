@@ -34,7 +34,7 @@ typedef enum {
   PB_ACT_HSIGMOID = 4, PB_ACT_SILU = 5
 } pb_act;
 
-#define PB_ABI_VERSION 2
+#define PB_ABI_VERSION 3
 
 /* Per-channel statistics buffers (`stats`, `sums` below) are PB_STAT_REPLICAS replicas of [2][C]
  * fp32, layout [replica][2][C], zero-filled by the caller.  A workgroup adds its partial sums into
@@ -71,6 +71,32 @@ int pb_pwconv_fwd(const void* x, const float* w, void* y, int64_t M, int K, int 
 int pb_pwconv_bwd_weight(const void* dy, const void* x, float* dw, int64_t M, int K, int N, pb_dtype dtype,
                          const float* in_scale, const float* in_shift, pb_act in_act, float in_slope,
                          const float* row_scale, int64_t rows_per_group, int device, void* stream);
+
+/* ---------------------------------------------------------------- dense 3-D convolution (implicit GEMM)
+ * Replaces nn.Conv3d(Cin,Cout,k,stride,padding,bias=False) with groups=1: mobilevit.py:19-24 (the
+ * 3x3x3 convs of MobileViTBlock: conv1 C->C, conv4 2C->C; mobilevit.py:112,119) and a dense
+ * movinet.py:31 CausalConv3d.  x [N,Ti,Hi,Wi,Cin] -> y [N,To,Ho,Wo,Cout], same K loop as
+ * pb_pwconv_fwd run over (tap, channel stage) with the X rows shifted per tap.
+ * The kernels take the filter as fp32 [Cout][taps][Cin] (pb_conv_weight_prep mode 0); backward-data
+ * (stride 1) is the same entry on dy with the mode-1 filter ([Cin][taps reversed][Cout]) and padding
+ * k-1-p; the weight gradient is produced in [Cout][taps][Cin] and returned to the reference layout
+ * with mode 2.  Channel counts must be multiples of the 16-byte vector (8 bf16 / 4 fp32).
+ * Epilogue (out_scale/out_shift/out_act/stats) as in pb_pwconv_fwd. */
+typedef struct {
+  int N, Cin, Cout;
+  int Ti, Hi, Wi;
+  int To, Ho, Wo;
+  int kt, kh, kw;
+  int st, sh, sw;
+  int pt, ph, pw;      /* front paddings */
+} pb_conv_shape;
+
+int pb_conv_weight_prep(const float* in, float* out, int Cout, int Cin, int taps, int mode, int device, void* stream);
+int pb_conv3d_fwd(const void* x, const float* wp, void* y, const pb_conv_shape* s, pb_dtype dtype,
+                  const float* out_scale, const float* out_shift, pb_act out_act, float out_slope, float* stats,
+                  int device, void* stream);
+int pb_conv3d_bwd_weight(const void* dy, const void* x, float* dwp, const pb_conv_shape* s, pb_dtype dtype, int device,
+                         void* stream);
 
 /* ---------------------------------------------------------------- depthwise 3-D convolution
  * Replaces nn.Conv3d(C,C,(kt,kh,kw),groups=C,bias=False) forward/backward:
@@ -139,13 +165,14 @@ int pb_bn_finalize(const float* stats, double count, const float* gamma, const f
                    float momentum, float* running_mean, float* running_var, int use_running,
                    float* scale, float* shift, float* mean, float* rstd, int C, int device, void* stream);
 
-/* y = act(x*scale[c] + shift[c]) * row_scale[g, c] + row_shift[g, c], g = m / rows_per_group;
- * optional stats of y. */
+/* y = act((x - mean[c])*scale[c] + shift[c]) * row_scale[g, c] + row_shift[g, c], g = m / rows_per_group;
+ * optional stats of y.  For BatchNorm pass scale = gamma*rstd, shift = beta, mean = the batch mean: the
+ * mean is subtracted first (a folded shift = beta - mean*scale cancels badly when |mean| >> std). */
 int pb_affine_act_fwd(const void* x, void* y, int64_t M, int C, pb_dtype dtype, const float* scale,
-                      const float* shift, pb_act act, float slope, const float* row_scale,
+                      const float* shift, const float* mean, pb_act act, float slope, const float* row_scale,
                       const float* row_shift, int64_t rows_per_group, float* stats, int device, void* stream);
 
-/* g = dy * row_scale * act'(z*scale+shift); sums[0..C) += sum g, sums[C..2C) += sum g*(z-mean)*rstd.
+/* g = dy * row_scale * act'((z-mean)*scale+shift); sums[0..C) += sum g, sums[C..2C) += sum g*(z-mean)*rstd.
  * dy_rows_per_group > 0: dy is [M/dy_rows_per_group][C] broadcast over each row group (the
  * backward of a global average pool, with dy pre-divided by the caller or via dy_mul).
  * g_out may be NULL (reduction only). */
@@ -154,14 +181,14 @@ int pb_act_bwd_reduce(const void* dy, const void* z, void* g_out, int64_t M, int
                       const float* row_scale, int64_t rows_per_group, int64_t dy_rows_per_group, float dy_mul,
                       const float* mean, const float* rstd, float* sums, int device, void* stream);
 
-/* BatchNorm backward coefficients: dz = A*g + B*z + Cc;  dgamma = sum g*xhat, dbeta = sum g. */
+/* BatchNorm backward coefficients: dz = A*g + B*(z - mean) + Cc;  dgamma = sum g*xhat, dbeta = sum g. */
 int pb_bn_bwd_finalize(const float* sums, double count, const float* gamma, const float* mean, const float* rstd,
                        int training, float* coefA, float* coefB, float* coefC, float* dgamma, float* dbeta,
                        int C, int device, void* stream);
 
-/* out = A[c]*g + B[c]*z + Cc[c]   (B, Cc may be NULL) */
+/* out = A[c]*g + B[c]*(z - mean[c]) + Cc[c]   (B, Cc, mean may be NULL) */
 int pb_affine2(const void* g, const void* z, void* out, int64_t M, int C, pb_dtype dtype, const float* A,
-               const float* B, const float* Cc, int device, void* stream);
+               const float* B, const float* Cc, const float* mean, int device, void* stream);
 
 /* ---------------------------------------------------------------- squeeze-excite / pooling
  * SEBlock3D (mobilenet.py:11-26) and the classifier's AdaptiveAvgPool3d (mobilenet.py:186,252;
@@ -181,6 +208,33 @@ int pb_se_fc_fwd(const float* pool, float inv_count, const float* w1, const floa
 int pb_se_fc_bwd(const float* dscale, const float* pool, float inv_count, const float* scale, const float* hidden,
                  const float* w1, const float* w2, float* g_shift, float* dw1, float* db1, float* dw2, float* db2,
                  float* work, int G, int C, int Cm, int device, void* stream);
+
+/* ---------------------------------------------------------------- MobileViT token-side helpers
+ * pb_unfold_fold: einops 'b d (t pt)(h ph)(w pw) -> b (pt ph pw)(t h w) d' and its inverse incl. the
+ *   zero padding to patch multiples / the crop (mobilevit.py:129-137).  Voxels [B,T,H,W,D] (unpadded),
+ *   tokens [B, pt*ph*pw, t*h*w, D] with t = ceil(T/pt)...  to_tokens != 0: unfold; == 0: fold + crop.
+ *   (Each is the other's backward.)
+ * pb_layernorm: nn.LayerNorm(D, elementwise_affine=False) (mobilevit.py:53,69); stat [rows][2] fp32
+ *   = (mean, rstd) written by forward, read by backward (backward != 0: out = dx from x, dy, stat).
+ * pb_copy_cols: dst[m*dst_ld + dst_off + c] (+)= src[m*src_ld + src_off + c]: torch.cat on channels
+ *   (mobilevit.py:141) and its backward split, head slices. */
+int pb_unfold_fold(const void* src, void* dst, int B, int D, int T, int H, int W, int pt, int ph, int pw, int to_tokens,
+                   pb_dtype dtype, int device, void* stream);
+int pb_layernorm(const void* x, const void* dy, void* out, float* stat, int64_t rows, int D, float eps, int backward,
+                 pb_dtype dtype, int device, void* stream);
+int pb_copy_cols(const void* src, int64_t src_ld, int src_off, void* dst, int64_t dst_ld, int dst_off, int64_t M, int C,
+                 int accumulate, pb_dtype dtype, int device, void* stream);
+
+/* ---------------------------------------------------------------- MobileViT patch attention
+ * Replaces F.scaled_dot_product_attention(q,k,v) on (b, p, h=8, n, d=16) + the rearranges around it
+ * (mobilevit.py:71-74 with the head merge of :82 restored): qkv [R = G*n][384] is the to_qkv output
+ * (q | k | v, each [h][d]); G = b*p groups of n tokens; out [R][128] heads merged; lse [R][8] fp32
+ * (log-sum-exp of the scaled scores, saved for backward).  Backward recomputes the probabilities:
+ * delta [R][8] fp32 is scratch (rowsum(dO*O)), dqkv [R][384] is fully written. */
+int pb_attention_fwd(const void* qkv, void* out, float* lse, int64_t G, int n, float scale, pb_dtype dtype, int device,
+                     void* stream);
+int pb_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
+                     int64_t G, int n, float scale, pb_dtype dtype, int device, void* stream);
 
 /* ---------------------------------------------------------------- misc
  * fp32 [R][C] -> [C][R] (depthwise weight [C][taps] -> [taps][C] staging). */

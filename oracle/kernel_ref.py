@@ -186,8 +186,10 @@ def bn_finalize(stats, count, gamma, beta, eps, momentum, running_mean, running_
 
 
 def affine_act_fwd(x, scale=None, shift=None, act="none", slope=0.0, row_scale=None, rows_per_group=0, stats=None,
-                   row_shift=None):
+                   row_shift=None, mean=None):
     xf = x.float()
+    if mean is not None:
+        xf = xf - mean
     if scale is not None:
         xf = xf * scale
     if shift is not None:
@@ -207,7 +209,7 @@ def affine_act_fwd(x, scale=None, shift=None, act="none", slope=0.0, row_scale=N
 def act_bwd_reduce(dy, z, *, scale=None, shift=None, act="none", slope=0.0, row_scale=None, rows_per_group=0,
                    dy_rows_per_group=0, dy_mul=1.0, mean=None, rstd=None, sums=None, want_g=True):
     zf = z.float()
-    pre = zf
+    pre = zf if mean is None else zf - mean
     if scale is not None:
         pre = pre * scale
     if shift is not None:
@@ -239,17 +241,18 @@ def bn_bwd_finalize(sums, count, gamma, mean, rstd, training, want_affine_grads)
     A = g * r
     if training:
         B = -g * r * r * (sgx / count)
-        Cc = -B * mu - g * r * (sg / count)
+        Cc = -g * r * (sg / count)
     else:
         B, Cc = torch.zeros_like(A), torch.zeros_like(A)
     return (A.float(), B.float(), Cc.float(), sgx.float() if want_affine_grads else None,
             sg.float() if want_affine_grads else None)
 
 
-def affine2(g, z, A, B=None, Cc=None):
+def affine2(g, z, A, B=None, Cc=None, mean=None):
     out = g.float() * A
     if B is not None:
-        out = out + z.float() * B
+        zf = z.float() if mean is None else z.float() - mean
+        out = out + zf * B
     if Cc is not None:
         out = out + Cc
     return out.to(g.dtype)
@@ -280,3 +283,117 @@ def se_fc_bwd(dscale, pool, inv_count, scale, hidden, w1, w2, want_bias=True):
     dw2 = dpre2.t() @ hidden
     dw1 = dh.t() @ (pool * inv_count)
     return g_shift, dw1, (dh.sum(0) if want_bias else None), dw2, (dpre2.sum(0) if want_bias else None)
+
+
+def conv_weight_prep(w, mode, cout, cin, taps):
+    if mode == 0:
+        return w.reshape(cout, cin, taps).permute(0, 2, 1).contiguous().reshape(-1)
+    if mode == 1:
+        return w.reshape(cout, cin, taps).flip(2).permute(1, 2, 0).contiguous().reshape(-1)
+    return w.reshape(cout, taps, cin).permute(0, 2, 1).contiguous().reshape(-1)
+
+
+def conv3d_fwd(x, wp, cout, kernel, stride, pad_front, out_thw, *, out_scale=None, out_shift=None, out_act="none",
+               out_slope=0.0, stats=None):
+    N, T, H, W, cin = x.shape
+    taps = kernel[0] * kernel[1] * kernel[2]
+    w = wp.reshape(cout, taps, cin).permute(0, 2, 1).reshape(cout, cin, *kernel).to(x.dtype).float()
+    pb = [max((o - 1) * s + k - i - pf, 0) for o, s, k, i, pf in zip(out_thw, stride, kernel, (T, H, W), pad_front)]
+    xp = F.pad(x.permute(0, 4, 1, 2, 3).float(), (pad_front[2], pb[2], pad_front[1], pb[1], pad_front[0], pb[0]))
+    acc = F.conv3d(xp, w, stride=stride)[:, :, :out_thw[0], :out_thw[1], :out_thw[2]].permute(0, 2, 3, 4, 1)
+    if out_scale is not None:
+        acc = acc * out_scale
+    if out_shift is not None:
+        acc = acc + out_shift
+    y = _act(acc, out_act, out_slope).contiguous().to(x.dtype)
+    if stats is not None:
+        yf = y.float().reshape(-1, cout)
+        stats[0, 0] += yf.sum(0)
+        stats[0, 1] += (yf ** 2).sum(0)
+    return y
+
+
+@torch.enable_grad()
+def conv3d_bwd_weight(dy, x, kernel, stride, pad_front):
+    N, To, Ho, Wo, cout = dy.shape
+    cin = x.shape[4]
+    in_thw = tuple(x.shape[1:4])
+    wv = torch.zeros(cout, cin, *kernel, requires_grad=True)
+    pb = [max((o - 1) * s + k - i - pf, 0) for o, s, k, i, pf in zip((To, Ho, Wo), stride, kernel, in_thw, pad_front)]
+    xp = F.pad(x.permute(0, 4, 1, 2, 3).float(), (pad_front[2], pb[2], pad_front[1], pb[1], pad_front[0], pb[0]))
+    y = F.conv3d(xp, wv, stride=stride)[:, :, :To, :Ho, :Wo]
+    (gw,) = torch.autograd.grad(y, wv, dy.float().permute(0, 4, 1, 2, 3))
+    return gw.reshape(cout, cin, -1).permute(0, 2, 1).contiguous().reshape(-1)
+
+
+def unfold(x5, patch):
+    B, T, H, W, D = x5.shape
+    pt, ph, pw = patch
+    tp, hp, wp = (-T) % pt, (-H) % ph, (-W) % pw
+    x = F.pad(x5, (0, 0, 0, wp, 0, hp, 0, tp))
+    t, h, w = (T + tp) // pt, (H + hp) // ph, (W + wp) // pw
+    x = x.reshape(B, t, pt, h, ph, w, pw, D).permute(0, 2, 4, 6, 1, 3, 5, 7)
+    return x.reshape(B, pt * ph * pw, t * h * w, D).contiguous()
+
+
+def fold(tok, thw, patch):
+    B, P_, n, D = tok.shape
+    T, H, W = thw
+    pt, ph, pw = patch
+    t, h, w = -(-T // pt), -(-H // ph), -(-W // pw)
+    x = tok.reshape(B, pt, ph, pw, t, h, w, D).permute(0, 4, 1, 5, 2, 6, 3, 7).reshape(B, t * pt, h * ph, w * pw, D)
+    return x[:, :T, :H, :W].contiguous()
+
+
+def layernorm_fwd(x, eps):
+    xf = x.float()
+    mean = xf.mean(1, keepdim=True)
+    rstd = torch.rsqrt(xf.var(1, unbiased=False, keepdim=True) + eps)
+    return ((xf - mean) * rstd).to(x.dtype), torch.cat([mean, rstd], 1)
+
+
+def layernorm_bwd(x, dy, stat, eps):
+    xf, g = x.float(), dy.float()
+    xh = (xf - stat[:, :1]) * stat[:, 1:]
+    dx = stat[:, 1:] * (g - g.mean(1, keepdim=True) - xh * (g * xh).mean(1, keepdim=True))
+    return dx.to(x.dtype)
+
+
+def copy_cols(src, src_off, dst, dst_off, C, accumulate=False):
+    if accumulate:
+        dst[:, dst_off:dst_off + C] += src[:, src_off:src_off + C]
+    else:
+        dst[:, dst_off:dst_off + C] = src[:, src_off:src_off + C]
+    return dst
+
+
+def _split_heads(qkv, G, n):
+    q, k, v = qkv.float().view(G, n, 3, 8, 16).permute(2, 0, 3, 1, 4)      # each [G, 8, n, 16]
+    return q, k, v
+
+
+def attention_fwd(qkv, G, n, scale):
+    q, k, v = _split_heads(qkv, G, n)
+    s = torch.matmul(q, k.transpose(-1, -2)) * scale
+    lse = torch.logsumexp(s, -1)
+    p = torch.exp(s - lse[..., None])
+    if qkv.dtype == torch.bfloat16:
+        p = p.to(torch.bfloat16).float()        # the kernel feeds P to the MFMA in bf16
+    out = torch.matmul(p, v).permute(0, 2, 1, 3).reshape(G * n, 128)
+    return out.to(qkv.dtype), lse.permute(0, 2, 1).reshape(G * n, 8).contiguous()
+
+
+def attention_bwd(qkv, out, dout, lse, G, n, scale):
+    q, k, v = _split_heads(qkv, G, n)
+    do = dout.float().view(G, n, 8, 16).permute(0, 2, 1, 3)
+    o = out.float().view(G, n, 8, 16).permute(0, 2, 1, 3)
+    L = lse.view(G, n, 8).permute(0, 2, 1)
+    p = torch.exp(torch.matmul(q, k.transpose(-1, -2)) * scale - L[..., None])
+    delta = (do * o).sum(-1, keepdim=True)
+    dp = torch.matmul(do, v.transpose(-1, -2))
+    ds = p * (dp - delta) * scale
+    dv = torch.matmul(p.transpose(-1, -2), do)
+    dq = torch.matmul(ds, k)
+    dk = torch.matmul(ds.transpose(-1, -2), q)
+    dqkv = torch.stack([dq, dk, dv], 0).permute(1, 3, 0, 2, 4).reshape(G * n, 384)
+    return dqkv.to(qkv.dtype)

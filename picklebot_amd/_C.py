@@ -12,12 +12,17 @@ LIB_PATH = os.path.join(_HERE, "lib", "libpicklebot_amd.so")
 
 PB_F32, PB_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY_RELU, ACT_HSWISH, ACT_HSIGMOID, ACT_SILU = range(6)
-ABI_VERSION = 2
+ABI_VERSION = 3
 STAT_REPLICAS = 16
 
 
 class DwShape(Structure):
     _fields_ = [(n, c_int) for n in ("N", "C", "Ti", "Hi", "Wi", "To", "Ho", "Wo", "kt", "kh", "kw",
+                                     "st", "sh", "sw", "pt", "ph", "pw")]
+
+
+class ConvShape(Structure):
+    _fields_ = [(n, c_int) for n in ("N", "Cin", "Cout", "Ti", "Hi", "Wi", "To", "Ho", "Wo", "kt", "kh", "kw",
                                      "st", "sh", "sw", "pt", "ph", "pw")]
 
 
@@ -40,14 +45,22 @@ SIGNATURES = {
     "pb_stem_conv3d_bwd_weight": [P, P, I, F, P, P, POINTER(StemShape), I, I, P],
     "pb_chan_stats": [P, L, I, I, P, I, P],
     "pb_bn_finalize": [P, D, P, P, F, F, P, P, I, P, P, P, P, I, I, P],
-    "pb_affine_act_fwd": [P, P, L, I, I, P, P, I, F, P, P, L, P, I, P],
+    "pb_affine_act_fwd": [P, P, L, I, I, P, P, P, I, F, P, P, L, P, I, P],
     "pb_act_bwd_reduce": [P, P, P, L, I, I, P, P, I, F, P, L, L, F, P, P, P, I, P],
     "pb_bn_bwd_finalize": [P, D, P, P, P, I, P, P, P, P, P, I, I, P],
-    "pb_affine2": [P, P, P, L, I, I, P, P, P, I, P],
+    "pb_affine2": [P, P, P, L, I, I, P, P, P, P, I, P],
     "pb_rowgroup_reduce": [P, P, P, L, L, I, I, I, P],
     "pb_se_fc_fwd": [P, F, P, P, P, P, P, P, I, I, I, I, P],
     "pb_se_fc_bwd": [P, P, F, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P],
     "pb_transpose_f32": [P, P, I, I, I, P],
+    "pb_unfold_fold": [P, P, I, I, I, I, I, I, I, I, I, I, I, P],
+    "pb_layernorm": [P, P, P, P, L, I, F, I, I, I, P],
+    "pb_copy_cols": [P, L, I, P, L, I, L, I, I, I, I, P],
+    "pb_attention_fwd": [P, P, P, L, I, F, I, I, P],
+    "pb_attention_bwd": [P, P, P, P, P, P, L, I, F, I, I, P],
+    "pb_conv_weight_prep": [P, P, I, I, I, I, I, P],
+    "pb_conv3d_fwd": [P, P, P, POINTER(ConvShape), I, P, P, I, F, P, I, P],
+    "pb_conv3d_bwd_weight": [P, P, P, POINTER(ConvShape), I, I, P],
 }
 
 _lib = None

@@ -1,0 +1,422 @@
+// MobileViT patch attention (mobilevit.py:68-86 with the head merge restored):
+// softmax(q k^T / sqrt(d)) v per (batch, intra-patch position, head); h = 8 heads of d = 16 fixed by
+// MobileViTBlock (mobilevit.py:116), n = 32 ... 784 tokens, no mask, zero-padded tokens attended to.
+//
+// One workgroup per (group = (b,p), head).  d = 16 is one MFMA k-step, so the design goal is that the
+// n x n probabilities never leave registers:
+//   * scores are produced TRANSPOSED (S^T = K Q^T: key on the accumulator row, query on the lane), so a
+//     16x16 accumulator tile is already the B operand of the next product that contracts over keys
+//     (O^T = V^T P^T, dQ^T = K^T dS^T) - "accumulator tile as the next MFMA's operand";
+//   * products that contract over queries (dV^T = dO^T P, dK^T = Q^T dS) use the un-transposed S = Q K^T
+//     in a second kernel where waves own key tiles, so no gradient needs atomics;
+//   * softmax statistics are lane-local (registers of one query column) + two shuffles;
+//   * forward is two passes over the keys (online max/sum, then normalised P V); backward recomputes P
+//     from the saved log-sum-exp.
+// bf16: v_mfma_f32_16x16x32_bf16 (the d = 16 contraction zero-pads half the k slots; the key/query
+// contractions use all 32: slot (g,j) <-> index 4g+j (j<4) / 16+4g+(j-4) of a 32-wide pair of tiles).
+// fp32 (parity path): exact-f32 v_mfma_f32_16x16x4_f32, slot g of step r <-> index 4g+r of a tile.
+#include "pb_common.h"
+
+namespace {
+
+constexpr int HD = 16;        // head dim
+constexpr int NH = 8;         // heads
+constexpr int QKV_LD = 3 * NH * HD;   // 384
+constexpr int OUT_LD = NH * HD;       // 128
+
+struct AttnArgs {
+  const void* qkv;     // [R][384]  q | k | v, each [h][d]
+  void* out;           // fwd: [R][128]
+  float* lse;          // [R][8]
+  const void* dout;    // bwd: [R][128]
+  const float* delta;  // bwd: [R][8]  rowsum(dO * O)
+  void* dqkv;          // bwd: [R][384]
+  int n, npad;         // tokens per group, rounded up to 32
+  float scale;
+};
+
+template <typename T> struct Frag;
+template <> struct Frag<bf16_t> { bf16x8 v; };
+template <> struct Frag<float> { float v[4]; };
+
+// D = A[16 x d] * B[d x 16] over the d = 16 head dim.
+//   bf16: lane (i = lane&15, g = lane>>4) of A holds A[i][8g..8g+7] for g < 2, zeros for g >= 2 (same for B^T)
+//   fp32: lane holds A[i][4s+g] for s = 0..3
+template <typename T>
+__device__ __forceinline__ f32x4 mma_d16(const Frag<T>& a, const Frag<T>& b) {
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (sizeof(T) == 2) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b.v, acc, 0, 0, 0);
+  } else {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[s], b.v[s], acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+// operand fragment of a [rows][16] row-major matrix (row pointer = start of this lane's row, or null -> zeros)
+template <typename T>
+__device__ __forceinline__ Frag<T> load_rowfrag(const T* row, int g) {
+  Frag<T> f;
+  if constexpr (sizeof(T) == 2) {
+    bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    f.v = (row && g < 2) ? *reinterpret_cast<const bf16x8*>(row + 8 * g) : z;
+  } else {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) f.v[s] = row ? row[4 * s + g] : 0.f;
+  }
+  return f;
+}
+
+// cooperative staging of one [n][16] head slice of qkv/dout into LDS: row-major `rm` ([npad][16]) and,
+// for bf16, transposed `tr` ([16][ldt]); rows >= n are zero
+template <typename T>
+__device__ __forceinline__ void stage_head(const T* src, int64_t ld, int n, int npad, T* rm, T* tr, int ldt) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  constexpr int CPR = HD / VEC;       // 16-byte chunks per row: 2 (bf16) / 4 (fp32)
+  for (int i = threadIdx.x; i < npad * CPR; i += 256) {
+    const int r = i / CPR, c = i - r * CPR;
+    Vec16<T> v = vec_zero<T>();
+    if (r < n) v = vec_load<T>(src + (int64_t)r * ld + c * VEC);
+    if (rm) vec_store<T>(rm + r * HD + c * VEC, v);
+    if (tr) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) tr[(c * VEC + e) * ldt + r] = from_f32<T>(v.get(e));
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ forward
+template <typename T>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr bool BF = sizeof(T) == 2;
+  const int n = a.n, npad = a.npad, ldt = npad + 8;
+  T* Ks = (T*)smem;                                   // [npad][16]
+  T* Vs = Ks + npad * HD;                             // bf16: V^T [16][ldt]; fp32: V [npad][16]
+  const int grp = blockIdx.x / NH, h = blockIdx.x - grp * NH;
+  const T* base = (const T*)a.qkv + (int64_t)grp * n * QKV_LD + h * HD;
+  stage_head<T>(base + NH * HD, QKV_LD, n, npad, Ks, nullptr, 0);
+  if constexpr (BF) stage_head<T>(base + 2 * NH * HD, QKV_LD, n, npad, nullptr, Vs, ldt);
+  else stage_head<T>(base + 2 * NH * HD, QKV_LD, n, npad, Vs, nullptr, 0);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const float NEG = -3.0e38f;
+  for (int qt = wave; qt * 16 < n; qt += 4) {
+    const int q = qt * 16 + li;
+    const bool qok = q < n;
+    const Frag<T> qf = load_rowfrag<T>(qok ? base + (int64_t)q * QKV_LD : nullptr, g);
+    // pass 1: running max / sum over this lane's key rows (4g..4g+3 of every tile), merged over g afterwards
+    float m = NEG, l = 0.f;
+    for (int kt = 0; kt * 16 < npad; ++kt) {
+      const Frag<T> kf = load_rowfrag<T>(Ks + (kt * 16 + li) * HD, g);
+      const f32x4 s = mma_d16<T>(kf, qf);
+      float sv[4], mx = m;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        sv[r] = (kt * 16 + 4 * g + r < n) ? s[r] * a.scale : NEG;
+        mx = fmaxf(mx, sv[r]);
+      }
+      float acc = l * __expf(m - mx);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc += __expf(sv[r] - mx);
+      l = acc;
+      m = mx;
+    }
+#pragma unroll
+    for (int off = 16; off <= 32; off <<= 1) {
+      const float m2 = __shfl_xor(m, off, 64), l2 = __shfl_xor(l, off, 64);
+      const float mn = fmaxf(m, m2);
+      l = l * __expf(m - mn) + l2 * __expf(m2 - mn);
+      m = mn;
+    }
+    const float inv_l = 1.f / l;
+    // pass 2: O^T[d][q] = sum_key V^T[d][key] * P^T[key][q]
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (BF) {
+      for (int kp = 0; kp * 32 < npad; ++kp) {
+        bf16x8 pb;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const int kt = 2 * kp + half;
+          const Frag<T> kf = load_rowfrag<T>(Ks + (kt * 16 + li) * HD, g);
+          const f32x4 s = mma_d16<T>(kf, qf);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float p = (kt * 16 + 4 * g + r < n) ? __expf(s[r] * a.scale - m) * inv_l : 0.f;
+            pb[4 * half + r] = (bf16_t)p;
+          }
+        }
+        // A = V^T: lane (d = li, g) holds keys 32kp + 4g + j (j<4) and 32kp + 16 + 4g + (j-4)
+        const bf16x4 v0 = *reinterpret_cast<const bf16x4*>(Vs + li * ldt + kp * 32 + 4 * g);
+        const bf16x4 v1 = *reinterpret_cast<const bf16x4*>(Vs + li * ldt + kp * 32 + 16 + 4 * g);
+        const bf16x8 va = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, pb, o, 0, 0, 0);
+      }
+    } else {
+      for (int kt = 0; kt * 16 < npad; ++kt) {
+        const Frag<T> kf = load_rowfrag<T>(Ks + (kt * 16 + li) * HD, g);
+        const f32x4 s = mma_d16<T>(kf, qf);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = kt * 16 + 4 * g + r;
+          const float p = (key < n) ? __expf(s[r] * a.scale - m) * inv_l : 0.f;
+          o = __builtin_amdgcn_mfma_f32_16x16x4f32(Vs[key * HD + li], p, o, 0, 0, 0);   // A[d = li][slot g] = V[key][d]
+        }
+      }
+    }
+    if (qok) {
+      // O^T tile: column = q (this lane), rows d = 4g + r
+      T* op = (T*)a.out + ((int64_t)grp * n + q) * OUT_LD + h * HD + 4 * g;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) op[r] = from_f32<T>(o[r]);
+      if (g == 0) a.lse[((int64_t)grp * n + q) * NH + h] = m + __logf(l);
+    }
+  }
+}
+
+// delta[r][h] = sum_d dO[r][h][d] * O[r][h][d]
+template <typename T>
+__global__ __launch_bounds__(256) void attn_delta_kernel(const T* dout, const T* out, float* delta, int64_t R) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= R * NH) return;
+  const T* a = dout + i * HD;
+  const T* b = out + i * HD;
+  float s = 0.f;
+#pragma unroll
+  for (int d = 0; d < HD; ++d) s += to_f32(a[d]) * to_f32(b[d]);
+  delta[i] = s;
+}
+
+// ------------------------------------------------------------------------------------------ backward: dQ
+// waves own query tiles; S^T orientation (key on the accumulator row): dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q]
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr bool BF = sizeof(T) == 2;
+  const int n = a.n, npad = a.npad, ldt = npad + 8;
+  T* Ks = (T*)smem;                 // [npad][16]
+  T* Vs = Ks + npad * HD;           // [npad][16]
+  T* Kt = Vs + npad * HD;           // bf16 only: K^T [16][ldt]
+  const int grp = blockIdx.x / NH, h = blockIdx.x - grp * NH;
+  const T* base = (const T*)a.qkv + (int64_t)grp * n * QKV_LD + h * HD;
+  stage_head<T>(base + NH * HD, QKV_LD, n, npad, Ks, BF ? Kt : nullptr, ldt);
+  stage_head<T>(base + 2 * NH * HD, QKV_LD, n, npad, Vs, nullptr, 0);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  for (int qt = wave; qt * 16 < n; qt += 4) {
+    const int q = qt * 16 + li;
+    const bool qok = q < n;
+    const int64_t row = (int64_t)grp * n + q;
+    const Frag<T> qf = load_rowfrag<T>(qok ? base + (int64_t)q * QKV_LD : nullptr, g);
+    const Frag<T> dof = load_rowfrag<T>(qok ? (const T*)a.dout + row * OUT_LD + h * HD : nullptr, g);
+    const float L = qok ? a.lse[row * NH + h] : 0.f;
+    const float dl = qok ? a.delta[row * NH + h] : 0.f;
+    f32x4 dq = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (BF) {
+      for (int kp = 0; kp * 32 < npad; ++kp) {
+        bf16x8 dsb;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const int kt = 2 * kp + half;
+          const Frag<T> kf = load_rowfrag<T>(Ks + (kt * 16 + li) * HD, g);
+          const Frag<T> vf = load_rowfrag<T>(Vs + (kt * 16 + li) * HD, g);
+          const f32x4 s = mma_d16<T>(kf, qf);        // S^T[key][q]
+          const f32x4 dp = mma_d16<T>(vf, dof);      // dP^T[key][q] = sum_d V[key][d] dO[q][d]
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const bool ok = qok && (kt * 16 + 4 * g + r < n);
+            const float p = ok ? __expf(s[r] * a.scale - L) : 0.f;
+            dsb[4 * half + r] = (bf16_t)(p * (dp[r] - dl) * a.scale);
+          }
+        }
+        const bf16x4 k0 = *reinterpret_cast<const bf16x4*>(Kt + li * ldt + kp * 32 + 4 * g);
+        const bf16x4 k1 = *reinterpret_cast<const bf16x4*>(Kt + li * ldt + kp * 32 + 16 + 4 * g);
+        const bf16x8 ka = {k0[0], k0[1], k0[2], k0[3], k1[0], k1[1], k1[2], k1[3]};
+        dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, dsb, dq, 0, 0, 0);
+      }
+    } else {
+      for (int kt = 0; kt * 16 < npad; ++kt) {
+        const Frag<T> kf = load_rowfrag<T>(Ks + (kt * 16 + li) * HD, g);
+        const Frag<T> vf = load_rowfrag<T>(Vs + (kt * 16 + li) * HD, g);
+        const f32x4 s = mma_d16<T>(kf, qf);
+        const f32x4 dp = mma_d16<T>(vf, dof);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = kt * 16 + 4 * g + r;
+          const bool ok = qok && key < n;
+          const float p = ok ? __expf(s[r] * a.scale - L) : 0.f;
+          const float ds = p * (dp[r] - dl) * a.scale;
+          dq = __builtin_amdgcn_mfma_f32_16x16x4f32(Ks[key * HD + li], ds, dq, 0, 0, 0);
+        }
+      }
+    }
+    if (qok) {
+      T* op = (T*)a.dqkv + row * QKV_LD + h * HD + 4 * g;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) op[r] = from_f32<T>(dq[r]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ backward: dK, dV
+// waves own key tiles; S orientation (query on the accumulator row, key on the lane):
+//   dV^T[d][key] = sum_q dO^T[d][q] P[q][key],   dK^T[d][key] = sum_q Q^T[d][q] dS[q][key]
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr bool BF = sizeof(T) == 2;
+  const int n = a.n, npad = a.npad, ldt = npad + 8;
+  T* Qs = (T*)smem;                      // [npad][16]
+  T* Os = Qs + npad * HD;                // dO [npad][16]
+  T* Qt = Os + npad * HD;                // bf16 only: Q^T, dO^T [16][ldt]
+  T* Ot = Qt + (BF ? HD * ldt : 0);
+  float* Ls = (float*)(Ot + (BF ? HD * ldt : 0));   // lse [npad], delta [npad]
+  float* Ds = Ls + npad;
+  const int grp = blockIdx.x / NH, h = blockIdx.x - grp * NH;
+  const T* base = (const T*)a.qkv + (int64_t)grp * n * QKV_LD + h * HD;
+  const T* dob = (const T*)a.dout + (int64_t)grp * n * OUT_LD + h * HD;
+  stage_head<T>(base, QKV_LD, n, npad, Qs, BF ? Qt : nullptr, ldt);
+  stage_head<T>(dob, OUT_LD, n, npad, Os, BF ? Ot : nullptr, ldt);
+  for (int i = threadIdx.x; i < npad; i += 256) {
+    Ls[i] = i < n ? a.lse[((int64_t)grp * n + i) * NH + h] : 0.f;
+    Ds[i] = i < n ? a.delta[((int64_t)grp * n + i) * NH + h] : 0.f;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  for (int kt = wave; kt * 16 < n; kt += 4) {
+    const int key = kt * 16 + li;
+    const bool kok = key < n;
+    const Frag<T> kf = load_rowfrag<T>(kok ? base + NH * HD + (int64_t)key * QKV_LD : nullptr, g);
+    const Frag<T> vf = load_rowfrag<T>(kok ? base + 2 * NH * HD + (int64_t)key * QKV_LD : nullptr, g);
+    f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (BF) {
+      for (int qp = 0; qp * 32 < npad; ++qp) {
+        bf16x8 pb, dsb;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const int qt = 2 * qp + half;
+          const Frag<T> qf = load_rowfrag<T>(Qs + (qt * 16 + li) * HD, g);
+          const Frag<T> dof = load_rowfrag<T>(Os + (qt * 16 + li) * HD, g);
+          const f32x4 s = mma_d16<T>(qf, kf);        // S[q][key]: rows q = 4g + r, column = key
+          const f32x4 dp = mma_d16<T>(dof, vf);      // dP[q][key]
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int q = qt * 16 + 4 * g + r;
+            const bool ok = kok && q < n;
+            const float p = ok ? __expf(s[r] * a.scale - Ls[q]) : 0.f;
+            pb[4 * half + r] = (bf16_t)p;
+            dsb[4 * half + r] = (bf16_t)(p * (dp[r] - Ds[q]) * a.scale);
+          }
+        }
+        const bf16x4 o0 = *reinterpret_cast<const bf16x4*>(Ot + li * ldt + qp * 32 + 4 * g);
+        const bf16x4 o1 = *reinterpret_cast<const bf16x4*>(Ot + li * ldt + qp * 32 + 16 + 4 * g);
+        const bf16x8 oa = {o0[0], o0[1], o0[2], o0[3], o1[0], o1[1], o1[2], o1[3]};
+        dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(oa, pb, dv, 0, 0, 0);
+        const bf16x4 q0 = *reinterpret_cast<const bf16x4*>(Qt + li * ldt + qp * 32 + 4 * g);
+        const bf16x4 q1 = *reinterpret_cast<const bf16x4*>(Qt + li * ldt + qp * 32 + 16 + 4 * g);
+        const bf16x8 qa = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
+        dk = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, dsb, dk, 0, 0, 0);
+      }
+    } else {
+      for (int qt = 0; qt * 16 < npad; ++qt) {
+        const Frag<T> qf = load_rowfrag<T>(Qs + (qt * 16 + li) * HD, g);
+        const Frag<T> dof = load_rowfrag<T>(Os + (qt * 16 + li) * HD, g);
+        const f32x4 s = mma_d16<T>(qf, kf);
+        const f32x4 dp = mma_d16<T>(dof, vf);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int q = qt * 16 + 4 * g + r;
+          const bool ok = kok && q < n;
+          const float p = ok ? __expf(s[r] * a.scale - Ls[q]) : 0.f;
+          const float ds = p * (dp[r] - Ds[q]) * a.scale;
+          dv = __builtin_amdgcn_mfma_f32_16x16x4f32(Os[q * HD + li], p, dv, 0, 0, 0);
+          dk = __builtin_amdgcn_mfma_f32_16x16x4f32(Qs[q * HD + li], ds, dk, 0, 0, 0);
+        }
+      }
+    }
+    if (kok) {
+      T* kp_ = (T*)a.dqkv + ((int64_t)grp * n + key) * QKV_LD + NH * HD + h * HD + 4 * g;
+      T* vp_ = kp_ + NH * HD;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        kp_[r] = from_f32<T>(dk[r]);
+        vp_[r] = from_f32<T>(dv[r]);
+      }
+    }
+  }
+}
+
+template <typename KernelT>
+int set_lds(KernelT k, size_t bytes) {
+  if (bytes > 160 * 1024) {
+    pb_set_error("attention: %zu bytes of LDS needed (n too large)", bytes);
+    return 1;
+  }
+  if (bytes > 48 * 1024) PB_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  return 0;
+}
+
+int check_attn(int64_t G, int n, pb_dtype dtype, const char* who) {
+  PB_CHECK_ARG(G > 0 && n > 0 && G * NH < 0x7fffffffLL, "%s: bad sizes G=%lld n=%d", who, (long long)G, n);
+  PB_CHECK_ARG(dtype == PB_F32 || dtype == PB_BF16, "%s: bad dtype", who);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int pb_attention_fwd(const void* qkv, void* out, float* lse, int64_t G, int n, float scale, pb_dtype dtype,
+                                int device, void* stream) {
+  PB_CHECK_ARG(qkv && out && lse, "pb_attention_fwd: null pointer");
+  if (int rc = check_attn(G, n, dtype, "pb_attention_fwd")) return rc;
+  PB_ENTER(device);
+  AttnArgs a = {};
+  a.qkv = qkv; a.out = out; a.lse = lse; a.n = n; a.npad = (n + 31) / 32 * 32; a.scale = scale;
+  const size_t es = dtype == PB_BF16 ? 2 : 4;
+  const size_t lds = (size_t)a.npad * HD * es + (dtype == PB_BF16 ? (size_t)HD * (a.npad + 8) * es : (size_t)a.npad * HD * es);
+  dim3 grid((unsigned)(G * NH));
+  if (dtype == PB_BF16) {
+    if (int rc = set_lds(attn_fwd_kernel<bf16_t>, lds)) return rc;
+    hipLaunchKernelGGL(attn_fwd_kernel<bf16_t>, grid, dim3(256), lds, (hipStream_t)stream, a);
+  } else {
+    if (int rc = set_lds(attn_fwd_kernel<float>, lds)) return rc;
+    hipLaunchKernelGGL(attn_fwd_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream, a);
+  }
+  PB_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pb_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta,
+                                void* dqkv, int64_t G, int n, float scale, pb_dtype dtype, int device, void* stream) {
+  PB_CHECK_ARG(qkv && out && dout && lse && delta && dqkv, "pb_attention_bwd: null pointer");
+  if (int rc = check_attn(G, n, dtype, "pb_attention_bwd")) return rc;
+  PB_ENTER(device);
+  hipStream_t st = (hipStream_t)stream;
+  AttnArgs a = {};
+  a.qkv = qkv; a.dout = dout; a.lse = const_cast<float*>(lse); a.delta = delta; a.dqkv = dqkv; a.n = n; a.npad = (n + 31) / 32 * 32; a.scale = scale;
+  const int64_t R = G * n;
+  const bool bf = dtype == PB_BF16;
+  const size_t es = bf ? 2 : 4;
+  const size_t rm = (size_t)a.npad * HD * es, tr = bf ? (size_t)HD * (a.npad + 8) * es : 0;
+  const size_t lds_dq = 2 * rm + tr;
+  const size_t lds_dkv = 2 * rm + 2 * tr + 2 * (size_t)a.npad * 4;
+  dim3 grid((unsigned)(G * NH));
+  if (bf) {
+    hipLaunchKernelGGL(attn_delta_kernel<bf16_t>, dim3((unsigned)pb_cdiv(R * NH, 256)), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)out, delta, R);
+    if (int rc = set_lds(attn_bwd_dkv_kernel<bf16_t>, lds_dkv)) return rc;
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<bf16_t>, grid, dim3(256), lds_dkv, st, a);
+    if (int rc = set_lds(attn_bwd_dq_kernel<bf16_t>, lds_dq)) return rc;
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<bf16_t>, grid, dim3(256), lds_dq, st, a);
+  } else {
+    hipLaunchKernelGGL(attn_delta_kernel<float>, dim3((unsigned)pb_cdiv(R * NH, 256)), dim3(256), 0, st, (const float*)dout, (const float*)out, delta, R);
+    if (int rc = set_lds(attn_bwd_dkv_kernel<float>, lds_dkv)) return rc;
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<float>, grid, dim3(256), lds_dkv, st, a);
+    if (int rc = set_lds(attn_bwd_dq_kernel<float>, lds_dq)) return rc;
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<float>, grid, dim3(256), lds_dq, st, a);
+  }
+  PB_LAUNCH_CHECK();
+  return 0;
+}

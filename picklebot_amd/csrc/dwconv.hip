@@ -544,6 +544,66 @@ __global__ __launch_bounds__(256) void dw_gen_fwd_kernel(GenArgs a) {
   }
 }
 
+// pooled variant: block = (channel-vector lanes) x (voxel lanes) over ONE clip (blockIdx.z = n), so the
+// squeeze-excite sums reduce in LDS and cost one global atomic per workgroup and channel
+template <typename T, int CH>
+__global__ __launch_bounds__(256) void dw_gen_fwd_pool_kernel(GenArgs a, int CVB, int P, int cchunks) {
+  __shared__ float red[32 * 8];
+  const pb_dwconv_shape& s = a.s;
+  const int tid = threadIdx.x;
+  const int cvl = tid % CVB, p = tid / CVB;
+  const int cv = blockIdx.y * CVB + cvl;
+  const bool lane_ok = p < P && cv < a.CV;
+  const int c0 = lane_ok ? cv * CH : 0;
+  const int n = blockIdx.z;
+  const int taps = s.kt * s.kh * s.kw;
+  const T* x = (const T*)a.src;
+  if (tid < 256) red[tid] = 0.f;
+  __syncthreads();
+  float psum[CH];
+#pragma unroll
+  for (int i = 0; i < CH; ++i) psum[i] = 0.f;
+  const int64_t nvox = (int64_t)s.To * s.Ho * s.Wo;
+  if (lane_ok) {
+    for (int64_t v0 = (int64_t)blockIdx.x * P + p; v0 < nvox; v0 += (int64_t)gridDim.x * P) {
+      int64_t pix = v0;
+      const int wo = (int)(pix % s.Wo); pix /= s.Wo;
+      const int ho = (int)(pix % s.Ho);
+      const int to = (int)(pix / s.Ho);
+      float acc[CH];
+#pragma unroll
+      for (int i = 0; i < CH; ++i) acc[i] = 0.f;
+      for (int at = 0; at < s.kt; ++at) {
+        const int ti = to * s.st - s.pt + at;
+        if (ti < 0 || ti >= s.Ti) continue;
+        for (int ah = 0; ah < s.kh; ++ah) {
+          const int hi = ho * s.sh - s.ph + ah;
+          if (hi < 0 || hi >= s.Hi) continue;
+          for (int aw = 0; aw < s.kw; ++aw) {
+            const int wi = wo * s.sw - s.pw + aw;
+            if (wi < 0 || wi >= s.Wi) continue;
+            float v[CH];
+            load_ch<T, CH>(x + ((((int64_t)n * s.Ti + ti) * s.Hi + hi) * s.Wi + wi) * s.C + c0, v);
+            const int tap = (at * s.kh + ah) * s.kw + aw;
+#pragma unroll
+            for (int i = 0; i < CH; ++i) acc[i] += v[i] * a.w[(int64_t)(c0 + i) * taps + tap];
+          }
+        }
+      }
+      store_ch<T, CH>((T*)a.dst + ((int64_t)n * nvox + v0) * s.C + c0, acc);
+#pragma unroll
+      for (int i = 0; i < CH; ++i) psum[i] += to_f32(from_f32<T>(acc[i]));
+    }
+#pragma unroll
+    for (int i = 0; i < CH; ++i) atomicAdd(&red[cvl * CH + i], psum[i]);
+  }
+  __syncthreads();
+  if (tid < CVB * CH) {
+    const int c = blockIdx.y * CVB * CH + tid;
+    if (c < s.C) atomicAdd(a.pool + (int64_t)n * s.C + c, red[tid]);
+  }
+}
+
 // backward-data: one thread = CH channels of one INPUT voxel
 template <typename T, int CH>
 __global__ __launch_bounds__(256) void dw_gen_bwd_data_kernel(GenArgs a) {
@@ -747,6 +807,23 @@ extern "C" int pb_dwconv3d_fwd(const void* x, const float* w, void* y, const pb_
     const int ch = s->C % 4 == 0 ? 4 : 1;
     a.CV = s->C / ch;
     a.total = (int64_t)s->N * s->To * s->Ho * s->Wo * a.CV;
+    if (pool) {
+      const int cvb = pick_cvb(a.CV), P = 256 / cvb, cchunks = (int)pb_cdiv(a.CV, cvb);
+      int64_t gx = pb_cdiv((int64_t)s->To * s->Ho * s->Wo, (int64_t)P * 4);
+      const int64_t cap = pb_cdiv(4096, (int64_t)cchunks * s->N);
+      if (gx > cap) gx = cap;
+      if (gx < 1) gx = 1;
+      dim3 pg((unsigned)gx, (unsigned)cchunks, (unsigned)s->N);
+      if (dtype == PB_BF16) {
+        if (ch == 4) hipLaunchKernelGGL((dw_gen_fwd_pool_kernel<bf16_t, 4>), pg, dim3(256), 0, st, a, cvb, P, cchunks);
+        else hipLaunchKernelGGL((dw_gen_fwd_pool_kernel<bf16_t, 1>), pg, dim3(256), 0, st, a, cvb, P, cchunks);
+      } else {
+        if (ch == 4) hipLaunchKernelGGL((dw_gen_fwd_pool_kernel<float, 4>), pg, dim3(256), 0, st, a, cvb, P, cchunks);
+        else hipLaunchKernelGGL((dw_gen_fwd_pool_kernel<float, 1>), pg, dim3(256), 0, st, a, cvb, P, cchunks);
+      }
+      PB_LAUNCH_CHECK();
+      return 0;
+    }
     dim3 grid((unsigned)pb_cdiv(a.total, 256));
     if (dtype == PB_BF16) {
       if (ch == 4) hipLaunchKernelGGL((dw_gen_fwd_kernel<bf16_t, 4>), grid, dim3(256), 0, st, a);

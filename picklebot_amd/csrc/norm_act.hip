@@ -187,20 +187,20 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs a) {
             acc[0][i] += va[u][i];
             acc[1][i] += va[u][i] * va[u][i];
           } else if constexpr (MODE == 1) {
-            const float y = act_fwd(va[u][i] * sc[i] + sh[i], a.act, a.slope) * rsc[u][i] + rsh[u][i];
+            const float y = act_fwd((va[u][i] - mu[i]) * sc[i] + sh[i], a.act, a.slope) * rsc[u][i] + rsh[u][i];
             vo[i] = y;
             const float yr = to_f32(from_f32<T>(y));
             acc[0][i] += yr;
             acc[1][i] += yr * yr;
           } else if constexpr (MODE == 2) {
-            const float pre = vb[u][i] * sc[i] + sh[i];
+            const float pre = (vb[u][i] - mu[i]) * sc[i] + sh[i];
             const float g = va[u][i] * a.dy_mul * rsc[u][i] * act_bwd(pre, a.act, a.slope);
             vo[i] = g;
             const float gr = O ? to_f32(from_f32<T>(g)) : g;
             acc[0][i] += gr;
             acc[1][i] += gr * (vb[u][i] - mu[i]) * rs[i];
           } else {
-            vo[i] = kA[i] * va[u][i] + kB[i] * vb[u][i] + kC[i];
+            vo[i] = kA[i] * va[u][i] + kB[i] * (vb[u][i] - mu[i]) + kC[i];
           }
         }
         if constexpr (MODE != 0) {
@@ -328,12 +328,13 @@ __global__ void bn_bwd_finalize_kernel(const float* sums, double count, const fl
     sg += sums[(size_t)r * 2 * C + c];
     sgx += sums[(size_t)r * 2 * C + C + c];
   }
-  const double g = gamma ? gamma[c] : 1.0, r = rstd[c], mu = mean[c];
+  const double g = gamma ? gamma[c] : 1.0, r = rstd[c];
   if (training) {
-    const double B = -g * r * r * (sgx / count);
+    // dz = A*g + B*(z - mean) + C: the mean is subtracted from z in the consumer, never folded into C
+    // (a channel with |mean| >> std would lose the difference to cancellation)
     cA[c] = (float)(g * r);
-    cB[c] = (float)B;
-    cC[c] = (float)(-B * mu - g * r * (sg / count));
+    cB[c] = (float)(-g * r * r * (sgx / count));
+    cC[c] = (float)(-g * r * (sg / count));
   } else {
     cA[c] = (float)(g * r);
     cB[c] = 0.f;
@@ -385,16 +386,16 @@ extern "C" int pb_bn_finalize(const float* stats, double count, const float* gam
 }
 
 extern "C" int pb_affine_act_fwd(const void* x, void* y, int64_t M, int C, pb_dtype dtype, const float* scale,
-                                 const float* shift, pb_act act, float slope, const float* row_scale,
-                                 const float* row_shift, int64_t rows_per_group, float* stats, int device,
-                                 void* stream) {
+                                 const float* shift, const float* mean, pb_act act, float slope,
+                                 const float* row_scale, const float* row_shift, int64_t rows_per_group, float* stats,
+                                 int device, void* stream) {
   PB_CHECK_ARG(x && y, "pb_affine_act_fwd: null pointer");
   if (int rc = check_mc(M, C, dtype, "pb_affine_act_fwd")) return rc;
   PB_CHECK_ARG(!(row_scale || row_shift) || rows_per_group > 0, "pb_affine_act_fwd: row_scale/shift need rows_per_group > 0");
   if (M == 0) return 0;
   PB_ENTER(device);
   EwArgs a = {};
-  a.a = x; a.out = y; a.M = M; a.C = C; a.scale = scale; a.shift = shift; a.act = (int)act; a.slope = slope;
+  a.a = x; a.out = y; a.M = M; a.C = C; a.scale = scale; a.shift = shift; a.mean = mean; a.act = (int)act; a.slope = slope;
   a.row_scale = row_scale; a.row_shift = row_shift; a.rows_per_group = rows_per_group > 0 ? rows_per_group : 1;
   a.sums = stats; a.dy_mul = 1.f;
   launch_ew_dt<1>(a, dtype, (hipStream_t)stream);
@@ -433,14 +434,15 @@ extern "C" int pb_bn_bwd_finalize(const float* sums, double count, const float* 
 }
 
 extern "C" int pb_affine2(const void* g, const void* z, void* out, int64_t M, int C, pb_dtype dtype, const float* A,
-                          const float* B, const float* Cc, int device, void* stream) {
+                          const float* B, const float* Cc, const float* mean, int device, void* stream) {
   PB_CHECK_ARG(g && out && A, "pb_affine2: null pointer");
   PB_CHECK_ARG(z || !B, "pb_affine2: B given without z");
   if (int rc = check_mc(M, C, dtype, "pb_affine2")) return rc;
   if (M == 0) return 0;
   PB_ENTER(device);
   EwArgs a = {};
-  a.a = g; a.b = z; a.out = out; a.M = M; a.C = C; a.cA = A; a.cB = B; a.cC = Cc; a.rows_per_group = 1; a.dy_mul = 1.f;
+  a.a = g; a.b = z; a.out = out; a.M = M; a.C = C; a.cA = A; a.cB = B; a.cC = Cc; a.mean = mean; a.rows_per_group = 1;
+  a.dy_mul = 1.f;
   launch_ew_dt<3>(a, dtype, (hipStream_t)stream);
   PB_LAUNCH_CHECK();
   return 0;

@@ -40,6 +40,10 @@ struct PwArgs {
   float* stats;
   int n_tiles;
   int64_t m_tiles;
+  // implicit-GEMM dense convolution (CONV variants): K = Cin per tap, the K loop runs over
+  // (tap, channel stage) and X rows are the tap-shifted input voxels (zero outside the clip);
+  // W is [N][taps][Cin] (ldw = taps*Cin)
+  int cTi, cHi, cWi, cTo, cHo, cWo, ckt, ckh, ckw, cst, csh, csw, cpt, cph, cpw;
 };
 
 // Prologue on the X operand, split so that a prefetch only ISSUES loads: `RowScale` carries the
@@ -123,7 +127,7 @@ __device__ __forceinline__ Vec16<T> load_row_chunk(const T* X, int64_t m, int k,
 // ALIGNED: K % VEC == 0, N % VEC == 0, ldw % 4 == 0 -> every access is a 16-byte vector and the
 // scalar fallbacks are compiled out of the hot path.  PRO: a prologue (affine / activation / row
 // scale) is applied to X while staging.
-template <typename T, int NT, bool TRANS, bool ALIGNED, bool PRO>
+template <typename T, int NT, bool TRANS, bool ALIGNED, bool PRO, bool CONV = false>
 __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
   constexpr int VEC = ElemTraits<T>::VEC;
   constexpr int KS = 128 / (int)sizeof(T);     // K elements staged per step (64 bf16 / 32 f32)
@@ -151,8 +155,10 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
   const bool xvec = ALIGNED || (a.K % VEC) == 0;
   const bool wvec = ALIGNED || (a.ldw % 4) == 0;
   const bool yvec = ALIGNED || (a.N % VEC) == 0;
-  const int nk = (a.K + KS - 1) / KS;
-  const bool w_cached = nk == 1 && a.n_tiles == 1;
+  const int nk = (a.K + KS - 1) / KS;                       // channel stages (per tap when CONV)
+  const int taps = CONV ? a.ckt * a.ckh * a.ckw : 1;
+  const int nst = nk * taps;                                // stages per tile
+  const bool w_cached = !CONV && nk == 1 && a.n_tiles == 1;
   // all tile arithmetic in 32 bits (the host checks the tile count), single-column-tile fast path
   const int n_tiles = a.n_tiles, m_tiles = (int)a.m_tiles;
   const int total = n_tiles == 1 ? m_tiles : ((m_tiles + 7) / 8) * 8 * n_tiles;
@@ -181,11 +187,19 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
     kpad = kc > MK ? KS : MK;
     csh = kc > MK ? 3 : 2;
   };
-  auto fetch_a = [&](int t, int ks) {
+  auto fetch_a = [&](int t, int ks_flat) {
+    const int tap = CONV ? ks_flat / nk : 0;
+    const int ks = CONV ? ks_flat - tap * nk : ks_flat;
     const int k0 = ks * KS;
     int kpad, csh;
     stage_dims(k0, kpad, csh);
     const int64_t m0 = (int64_t)tile_mt(t) * BM;
+    int dt = 0, dh = 0, dw_ = 0;
+    if constexpr (CONV) {
+      dw_ = tap % a.ckw;
+      dh = (tap / a.ckw) % a.ckh;
+      dt = tap / (a.ckw * a.ckh);
+    }
     int64_t g0 = 0, g0_end = 0;
     if constexpr (PRO) {
       if (a.row_scale) {
@@ -202,7 +216,19 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
         const int r = f >> csh, c = f & ((1 << csh) - 1);
         const int64_t m = m0 + r;
         const int k = k0 + c * VEC;
-        if (m < a.M && k < a.K) {
+        if constexpr (CONV) {
+          if (m < a.M && k < a.K) {
+            // output voxel -> tap-shifted input voxel
+            int64_t q = m;
+            const int wo = (int)(q % a.cWo); q /= a.cWo;
+            const int ho = (int)(q % a.cHo); q /= a.cHo;
+            const int to = (int)(q % a.cTo);
+            const int64_t n = q / a.cTo;
+            const int ti = to * a.cst - a.cpt + dt, hi = ho * a.csh - a.cph + dh, wi = wo * a.csw - a.cpw + dw_;
+            if (ti >= 0 && ti < a.cTi && hi >= 0 && hi < a.cHi && wi >= 0 && wi < a.cWi)
+              ra[i] = vec_load<T>(X + (((n * a.cTi + ti) * a.cHi + hi) * a.cWi + wi) * a.K + k);
+          }
+        } else if (m < a.M && k < a.K) {
           if constexpr (ALIGNED) ra[i] = vec_load<T>(X + m * a.K + k);
           else ra[i] = load_row_chunk<T>(X, m, k, a.K, xvec);
           if constexpr (PRO) {
@@ -212,7 +238,8 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
       }
     }
   };
-  auto commit_a = [&](int t, int ks) {
+  auto commit_a = [&](int t, int ks_flat) {
+    const int ks = CONV ? ks_flat % nk : ks_flat;
     int kpad, csh;
     stage_dims(ks * KS, kpad, csh);
     const int64_t m0 = (int64_t)tile_mt(t) * BM;
@@ -241,8 +268,11 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
       }
     }
   };
-  auto fetch_w = [&](int t, int ks) {
+  auto fetch_w = [&](int t, int ks_flat) {
+    const int tap = CONV ? ks_flat / nk : 0;
+    const int ks = CONV ? ks_flat - tap * nk : ks_flat;
     const int k0 = ks * KS, n0 = tile_nt(t) * BN;
+    const int wcol0 = CONV ? tap * a.K : 0;                 // column offset of this tap in W
     int kpad, csh;
     stage_dims(k0, kpad, csh);
     if constexpr (!TRANS) {
@@ -254,7 +284,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
           const int r = f >> csh, c = f & ((1 << csh) - 1);
           const int n = n0 + r, k = k0 + c * VEC;
           if (n < a.N && k < a.K) {
-            const float* src = a.W + (int64_t)n * a.ldw + k;
+            const float* src = a.W + (int64_t)n * a.ldw + wcol0 + k;
             if (ALIGNED || (wvec && k + VEC <= a.K)) {
 #pragma unroll
               for (int q = 0; q < VEC / 4; ++q) {
@@ -293,7 +323,8 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
       }
     }
   };
-  auto commit_w = [&](int ks) {
+  auto commit_w = [&](int ks_flat) {
+    const int ks = CONV ? ks_flat % nk : ks_flat;
     int kpad, csh;
     stage_dims(ks * KS, kpad, csh);
     if constexpr (!TRANS) {
@@ -395,7 +426,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
     // issue the next stage's (or next tile's) global loads; they complete under the MFMAs below
     int tn = t;
     int ksn = ks + 1;
-    if (ksn == nk) {
+    if (ksn == nst) {
       ksn = 0;
       tn = next_valid(t + gridDim.x);
     }
@@ -404,7 +435,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
       if (!w_cached) fetch_w(tn, ksn);
     }
     int kpad, csh;
-    stage_dims(ks * KS, kpad, csh);
+    stage_dims((CONV ? ks % nk : ks) * KS, kpad, csh);
     for (int kk = 0; kk < kpad; kk += MK) {
       if constexpr (sizeof(T) == 2) {
         const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(As + (wave * 32 + frow) * LDB + (kk + 8 * fk) * 2);
@@ -431,7 +462,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
       }
     }
     lds_barrier();
-    if (ks == nk - 1) {
+    if (ks == nst - 1) {
       // ---- epilogue: affine/bias + activation, per-column statistics, LDS-transposed store
       const int64_t m0 = (int64_t)tile_mt(t) * BM;
       const int n0 = tile_nt(t) * BN;
@@ -528,6 +559,8 @@ struct WgArgs {
   int64_t rows_per_group;
   int64_t rows_per_wg;
   int n_tiles, k_tiles;
+  // CONV: blockIdx.z = filter tap, X rows are the tap-shifted input voxels, dW is [N][taps][K]
+  int cTi, cHi, cWi, cTo, cHo, cWo, ckt, ckh, ckw, cst, csh, csw, cpt, cph, cpw;
 };
 
 // Each wave streams 32-row blocks of dY[:, n-tile] and X[:, k-tile] through its private LDS
@@ -536,7 +569,7 @@ struct WgArgs {
 // 4-byte reads.  No workgroup barrier in the loop (waves are independent); the next block's global
 // loads are issued before the current block's MFMAs.  At the end the four waves' tiles are summed
 // in LDS and added to dW with contiguous float atomics (one writer per workgroup and address).
-template <typename T, int TNW, int TKW>
+template <typename T, int TNW, int TKW, bool CONV = false>
 __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgArgs a) {
   constexpr int VEC = ElemTraits<T>::VEC;
   constexpr int TN = TNW * 16, TK = TKW * 16;
@@ -593,8 +626,23 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgArgs a) {
       const int r = f / CK, c = f - r * CK;
       const int64_t m = mb + r;
       const int k = k0 + c * VEC;
-      const bool ok = m < mend && k < a.K;
-      rx[i] = ok ? load_row_chunk<T>(X, m, k, a.K, kvec) : vec_zero<T>();
+      bool ok = m < mend && k < a.K;
+      int64_t mx = m;
+      if constexpr (CONV) {
+        if (ok) {
+          const int tap = blockIdx.z;
+          const int dw_ = tap % a.ckw, dh = (tap / a.ckw) % a.ckh, dt = tap / (a.ckw * a.ckh);
+          int64_t q = m;
+          const int wo = (int)(q % a.cWo); q /= a.cWo;
+          const int ho = (int)(q % a.cHo); q /= a.cHo;
+          const int to = (int)(q % a.cTo);
+          const int64_t n = q / a.cTo;
+          const int ti = to * a.cst - a.cpt + dt, hi = ho * a.csh - a.cph + dh, wi = wo * a.csw - a.cpw + dw_;
+          ok = ti >= 0 && ti < a.cTi && hi >= 0 && hi < a.cHi && wi >= 0 && wi < a.cWi;
+          mx = ((n * a.cTi + ti) * a.cHi + hi) * a.cWi + wi;
+        }
+      }
+      rx[i] = ok ? load_row_chunk<T>(X, mx, k, a.K, kvec) : vec_zero<T>();
       rsx[i].ones();
       if (pro && ok) rsx[i] = fetch_rowscale<T>(pa, row_group(m, mb, g0, g0_end, a.rows_per_group), k);
     }
@@ -678,9 +726,11 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgArgs a) {
     }
     __syncthreads();
   }
+  const int64_t ldw = CONV ? (int64_t)a.ckt * a.ckh * a.ckw * a.K : a.K;
+  const int64_t woff = CONV ? (int64_t)blockIdx.z * a.K : 0;
   for (int e = tid; e < TN * TK; e += 256) {
     const int n = n0 + e / TK, k = k0 + e % TK;
-    if (n < a.N && k < a.K) atomicAdd(a.dW + (int64_t)n * a.K + k, R[e]);
+    if (n < a.N && k < a.K) atomicAdd(a.dW + (int64_t)n * ldw + woff + k, R[e]);
   }
 }
 
@@ -821,6 +871,151 @@ extern "C" int pb_pwconv_bwd_weight(const void* dy, const void* x, float* dw, in
     hipLaunchKernelGGL((pw_wgrad_kernel<bf16_t, 4, 4>), grid, block, 0, (hipStream_t)stream, a);
   else
     hipLaunchKernelGGL((pw_wgrad_kernel<float, 2, 2>), grid, block, 0, (hipStream_t)stream, a);
+  PB_LAUNCH_CHECK();
+  return 0;
+}
+
+
+// ----------------------------------------------------------------------------- dense conv (implicit GEMM)
+namespace {
+
+// mode 0: w[Cout][Cin][taps] -> wp[Cout][taps][Cin]                       (forward operand)
+// mode 1: w[Cout][Cin][taps] -> wp[Cin][taps][Cout], taps reversed        (backward-data operand)
+// mode 2: wp[Cout][taps][Cin] -> w[Cout][Cin][taps]                       (weight gradient back to the reference layout)
+__global__ void conv_weight_prep_kernel(const float* in, float* out, int Cout, int Cin, int taps, int mode) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)Cout * Cin * taps;
+  if (i >= total) return;
+  if (mode == 0) {            // i indexes out [co][tap][ci]
+    const int ci = (int)(i % Cin), tap = (int)((i / Cin) % taps), co = (int)(i / ((int64_t)Cin * taps));
+    out[i] = in[((int64_t)co * Cin + ci) * taps + tap];
+  } else if (mode == 1) {     // i indexes out [ci][tap][co]
+    const int co = (int)(i % Cout), tap = (int)((i / Cout) % taps), ci = (int)(i / ((int64_t)Cout * taps));
+    out[i] = in[((int64_t)co * Cin + ci) * taps + (taps - 1 - tap)];
+  } else {                    // i indexes out [co][ci][tap]
+    const int tap = (int)(i % taps), ci = (int)((i / taps) % Cin), co = (int)(i / ((int64_t)Cin * taps));
+    out[i] = in[((int64_t)co * taps + tap) * Cin + ci];
+  }
+}
+
+template <typename T, int NT>
+void launch_conv_nt(const PwArgs& a, int64_t total, int device, hipStream_t st) {
+  static int cached[16] = {0};
+  const int d = device & 15;
+  if (cached[d] == 0) {
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pw_gemm_kernel<T, NT, false, true, false, true>, 256, 0) != hipSuccess || per_cu < 1)
+      per_cu = 1;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) cus = 256;
+    cached[d] = per_cu * cus;
+  }
+  int64_t blocks = cached[d];
+  if (blocks > total) blocks = total;
+  blocks = pb_cdiv(blocks, 8) * 8;
+  hipLaunchKernelGGL((pw_gemm_kernel<T, NT, false, true, false, true>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+}
+
+template <typename T>
+int launch_conv(PwArgs a, int device, hipStream_t st) {
+  const int nt = pick_nt(a.N, sizeof(T) == 4);
+  a.n_tiles = (int)pb_cdiv(a.N, nt * 16);
+  a.m_tiles = pb_cdiv(a.M, BM);
+  const int64_t total = a.n_tiles == 1 ? a.m_tiles : pb_cdiv(a.m_tiles, 8) * 8 * a.n_tiles;
+  if (total > 0x3fffffffLL) { pb_set_error("pb_conv3d_fwd: too many tiles"); return 1; }
+  switch (nt) {
+    case 2: launch_conv_nt<T, 2>(a, total, device, st); break;
+    case 4: launch_conv_nt<T, 4>(a, total, device, st); break;
+    case 6: launch_conv_nt<T, 6>(a, total, device, st); break;
+    case 8: launch_conv_nt<T, 8>(a, total, device, st); break;
+    default:
+      if constexpr (sizeof(T) == 2) launch_conv_nt<T, 12>(a, total, device, st);
+      else launch_conv_nt<T, 8>(a, total, device, st);
+      break;
+  }
+  return 0;
+}
+
+int check_conv(const pb_conv_shape* s, pb_dtype dtype, const char* who) {
+  PB_CHECK_ARG(s, "%s: null shape", who);
+  PB_CHECK_ARG(s->N > 0 && s->Cin > 0 && s->Cout > 0 && s->Ti > 0 && s->Hi > 0 && s->Wi > 0 && s->To > 0 && s->Ho > 0 &&
+               s->Wo > 0 && s->kt > 0 && s->kh > 0 && s->kw > 0 && s->st > 0 && s->sh > 0 && s->sw > 0,
+               "%s: non-positive dimension", who);
+  PB_CHECK_ARG(dtype == PB_F32 || dtype == PB_BF16, "%s: bad dtype", who);
+  const int vec = dtype == PB_BF16 ? 8 : 4;
+  PB_CHECK_ARG(s->Cin % vec == 0 && s->Cout % vec == 0, "%s: channel counts must be multiples of %d (Cin=%d Cout=%d)", who,
+               vec, s->Cin, s->Cout);
+  PB_CHECK_ARG((s->To - 1) * s->st - s->pt < s->Ti + s->pt + s->kt && (s->Ho - 1) * s->sh - s->ph < s->Hi + s->ph + s->kh &&
+               (s->Wo - 1) * s->sw - s->pw < s->Wi + s->pw + s->kw, "%s: output extent inconsistent", who);
+  return 0;
+}
+
+void fill_conv(PwArgs& a, const pb_conv_shape* s) {
+  a.cTi = s->Ti; a.cHi = s->Hi; a.cWi = s->Wi; a.cTo = s->To; a.cHo = s->Ho; a.cWo = s->Wo;
+  a.ckt = s->kt; a.ckh = s->kh; a.ckw = s->kw; a.cst = s->st; a.csh = s->sh; a.csw = s->sw;
+  a.cpt = s->pt; a.cph = s->ph; a.cpw = s->pw;
+}
+
+}  // namespace
+
+extern "C" int pb_conv_weight_prep(const float* in, float* out, int Cout, int Cin, int taps, int mode, int device,
+                                   void* stream) {
+  PB_CHECK_ARG(in && out && Cout > 0 && Cin > 0 && taps > 0 && mode >= 0 && mode <= 2, "pb_conv_weight_prep: bad args");
+  PB_ENTER(device);
+  const int64_t total = (int64_t)Cout * Cin * taps;
+  hipLaunchKernelGGL(conv_weight_prep_kernel, dim3((unsigned)pb_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, in,
+                     out, Cout, Cin, taps, mode);
+  PB_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pb_conv3d_fwd(const void* x, const float* wp, void* y, const pb_conv_shape* s, pb_dtype dtype,
+                             const float* out_scale, const float* out_shift, pb_act out_act, float out_slope,
+                             float* stats, int device, void* stream) {
+  PB_CHECK_ARG(x && wp && y, "pb_conv3d_fwd: null pointer");
+  if (int rc = check_conv(s, dtype, "pb_conv3d_fwd")) return rc;
+  PB_ENTER(device);
+  PwArgs a = {};
+  a.X = x; a.W = wp; a.Y = y;
+  a.M = (int64_t)s->N * s->To * s->Ho * s->Wo;
+  a.K = s->Cin; a.N = s->Cout; a.ldw = s->kt * s->kh * s->kw * s->Cin; a.w_transposed = 0;
+  a.rows_per_group = 1;
+  a.out_scale = out_scale; a.out_shift = out_shift; a.out_act = (int)out_act; a.out_slope = out_slope; a.stats = stats;
+  fill_conv(a, s);
+  int rc = dtype == PB_BF16 ? launch_conv<bf16_t>(a, device, (hipStream_t)stream) : launch_conv<float>(a, device, (hipStream_t)stream);
+  if (rc) return rc;
+  PB_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pb_conv3d_bwd_weight(const void* dy, const void* x, float* dwp, const pb_conv_shape* s, pb_dtype dtype,
+                                    int device, void* stream) {
+  PB_CHECK_ARG(dy && x && dwp, "pb_conv3d_bwd_weight: null pointer");
+  if (int rc = check_conv(s, dtype, "pb_conv3d_bwd_weight")) return rc;
+  PB_ENTER(device);
+  WgArgs a = {};
+  a.dY = dy; a.X = x; a.dW = dwp;
+  a.M = (int64_t)s->N * s->To * s->Ho * s->Wo;
+  a.K = s->Cin; a.N = s->Cout; a.rows_per_group = 1;
+  a.cTi = s->Ti; a.cHi = s->Hi; a.cWi = s->Wi; a.cTo = s->To; a.cHo = s->Ho; a.cWo = s->Wo;
+  a.ckt = s->kt; a.ckh = s->kh; a.ckw = s->kw; a.cst = s->st; a.csh = s->sh; a.csw = s->sw;
+  a.cpt = s->pt; a.cph = s->ph; a.cpw = s->pw;
+  const int taps = s->kt * s->kh * s->kw;
+  const int tile = dtype == PB_BF16 ? 64 : 32;
+  a.n_tiles = (int)pb_cdiv(a.N, tile);
+  a.k_tiles = (int)pb_cdiv(a.K, tile);
+  const int64_t tiles = (int64_t)a.n_tiles * a.k_tiles;
+  int64_t msplit = pb_cdiv(2048, tiles * taps);
+  const int64_t max_split = pb_cdiv(a.M, 128);
+  if (msplit > max_split) msplit = max_split;
+  if (msplit < 1) msplit = 1;
+  a.rows_per_wg = pb_cdiv(pb_cdiv(a.M, msplit), 128) * 128;
+  msplit = pb_cdiv(a.M, a.rows_per_wg);
+  PB_CHECK_ARG(taps <= 65535 && msplit <= 65535, "pb_conv3d_bwd_weight: grid too large");
+  dim3 grid((unsigned)tiles, (unsigned)msplit, (unsigned)taps), block(256);
+  if (dtype == PB_BF16)
+    hipLaunchKernelGGL((pw_wgrad_kernel<bf16_t, 4, 4, true>), grid, block, 0, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL((pw_wgrad_kernel<float, 2, 2, true>), grid, block, 0, (hipStream_t)stream, a);
   PB_LAUNCH_CHECK();
   return 0;
 }

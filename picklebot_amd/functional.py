@@ -61,7 +61,7 @@ def _bn_forward(z2, stats, count, gamma, beta, rmean, rvar, eps, momentum, train
 
 class _BnCtx:
     """What BatchNorm backward needs."""
-    __slots__ = ("scale", "shift", "mean", "rstd", "training", "count")
+    __slots__ = ("scale", "shift", "mean", "rstd", "training", "count", "beta")
 
 
 def _bn_act_backward(dy2, z2, bnc, gamma, act, slope, row_scale, rows_per_group, dy_rows_per_group=0, dy_mul=1.0):
@@ -72,12 +72,12 @@ def _bn_act_backward(dy2, z2, bnc, gamma, act, slope, row_scale, rows_per_group,
                              dy_rows_per_group=dy_rows_per_group, dy_mul=dy_mul)
         return g, None, None
     sums = _zeros((K.REPL, 2, C), z2)
-    g = K.act_bwd_reduce(dy2, z2, scale=bnc.scale, shift=bnc.shift, act=act, slope=slope, row_scale=row_scale,
+    g = K.act_bwd_reduce(dy2, z2, scale=bnc.scale, shift=bnc.beta, act=act, slope=slope, row_scale=row_scale,
                          rows_per_group=rows_per_group, dy_rows_per_group=dy_rows_per_group, dy_mul=dy_mul,
                          mean=bnc.mean, rstd=bnc.rstd, sums=sums)
     A, B, Cc, dgamma, dbeta = K.bn_bwd_finalize(sums, bnc.count, gamma, bnc.mean, bnc.rstd, bnc.training,
                                                 gamma is not None)
-    dz = K.affine2(g, z2, A, B, Cc) if bnc.training else K.affine2(g, None, A)
+    dz = K.affine2(g, z2, A, B, Cc, mean=bnc.mean) if bnc.training else K.affine2(g, None, A)
     return dz, dgamma, dbeta
 
 
@@ -132,9 +132,10 @@ class _Bottleneck(torch.autograd.Function):
             bnc = _BnCtx()
             bnc.scale, bnc.shift, bnc.mean, bnc.rstd = _bn_forward(z2, stats, z2.shape[0], gamma, beta, rmean, rvar,
                                                                    eps, momentum, training)
-            bnc.training, bnc.count = training, z2.shape[0]
-            scale, shift = bnc.scale, bnc.shift
-        y2 = K.affine_act_fwd(z2, scale, shift, act, slope, row_scale=drop, rows_per_group=R2)
+            bnc.training, bnc.count, bnc.beta = training, z2.shape[0], beta
+            scale, shift = bnc.scale, beta
+        y2 = K.affine_act_fwd(z2, scale, shift, act, slope, row_scale=drop, rows_per_group=R2,
+                              mean=bnc.mean if bnc is not None else None)
         if need_grad:
             ctx.cfg, ctx.bnc, ctx.dims = cfg, bnc, (N, T, H, W, Cin, E, Cout, To, Ho, Wo)
             ctx.save_for_backward(x5, e5, d5, z2, w1, wdw, w2, se_w1, se_w2, pool, se_scale, hidden, gamma, drop)
@@ -207,9 +208,9 @@ class _StemBnAct(torch.autograd.Function):
             bnc = _BnCtx()
             bnc.scale, bnc.shift, bnc.mean, bnc.rstd = _bn_forward(z2, stats, z2.shape[0], gamma, beta, rmean, rvar,
                                                                    eps, momentum, training)
-            bnc.training, bnc.count = training, z2.shape[0]
-            scale, shift = bnc.scale, bnc.shift
-        y2 = K.affine_act_fwd(z2, scale, shift, cfg["act"], cfg["slope"])
+            bnc.training, bnc.count, bnc.beta = training, z2.shape[0], beta
+            scale, shift = bnc.scale, beta
+        y2 = K.affine_act_fwd(z2, scale, shift, cfg["act"], cfg["slope"], mean=bnc.mean if bnc is not None else None)
         if cfg["need_grad"]:
             ctx.cfg, ctx.bnc = cfg, bnc
             ctx.save_for_backward(x, z5, w, gamma)
@@ -277,9 +278,10 @@ class _PwBnAct(torch.autograd.Function):
             bnc = _BnCtx()
             bnc.scale, bnc.shift, bnc.mean, bnc.rstd = _bn_forward(u2, stats, M, gamma, beta, rmean, rvar, eps,
                                                                    momentum, training)
-            bnc.training, bnc.count = training, M
-            scale, shift = bnc.scale, bnc.shift
-        y2 = K.affine_act_fwd(u2, scale, shift, act, slope, row_scale=drop, rows_per_group=R if drop is not None else 0)
+            bnc.training, bnc.count, bnc.beta = training, M, beta
+            scale, shift = bnc.scale, beta
+        y2 = K.affine_act_fwd(u2, scale, shift, act, slope, row_scale=drop, rows_per_group=R if drop is not None else 0,
+                              mean=bnc.mean if bnc is not None else None)
         if need_grad:
             ctx.cfg, ctx.bnc, ctx.has_bias, ctx.lead = cfg, bnc, bias is not None, lead
             ctx.save_for_backward(x5, z2, u2 if has_se else None, w, se_w1, se_w2, pool, se_scale, hidden, gamma, drop)
@@ -395,3 +397,260 @@ class _SEBlock(torch.autograd.Function):
 
 def se_block(x5, se):
     return _SEBlock.apply(_contig5(x5), *se)
+
+
+# =============================================================================== standalone depthwise conv (+bias)
+class _Depthwise(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x5, w, bias, cfg):
+        C = x5.shape[-1]
+        y5 = K.dw_fwd(x5, w.view(C, -1), cfg["kernel"], cfg["stride"], cfg["pad_front"], cfg["pad_back"])
+        if bias is not None:
+            y5 = K.affine_act_fwd(y5.view(-1, C), shift=bias).view(y5.shape)
+        ctx.cfg, ctx.has_bias = cfg, bias is not None
+        ctx.save_for_backward(x5, w)
+        return y5
+
+    @staticmethod
+    def backward(ctx, dy5):
+        x5, w = ctx.saved_tensors
+        cfg = ctx.cfg
+        C = x5.shape[-1]
+        dy5 = _contig5(dy5)
+        dw = _zeros((C, w[0].numel()), x5)
+        K.dw_bwd_weight(dy5, x5, dw, cfg["kernel"], cfg["stride"], cfg["pad_front"])
+        dx5 = None
+        if ctx.needs_input_grad[0]:
+            dx5 = K.dw_bwd_data(dy5, w.view(C, -1), tuple(x5.shape[1:4]), cfg["kernel"], cfg["stride"], cfg["pad_front"])
+        dbias = None
+        if ctx.has_bias:
+            st = _zeros((K.REPL, 2, C), x5)
+            K.chan_stats(dy5.view(-1, C), st)
+            dbias = st[:, 0].sum(0)
+        return dx5, dw.view_as(w), dbias, None
+
+
+def depthwise(x5, weight, bias, kernel, stride, pad_front, pad_back=None):
+    cfg = dict(kernel=tuple(kernel), stride=tuple(stride), pad_front=tuple(pad_front),
+               pad_back=tuple(pad_back if pad_back is not None else pad_front))
+    return _Depthwise.apply(_contig5(x5), weight, bias, cfg)
+
+
+# =============================================================================== dense conv (+bias) [+BN] + act
+class _ConvBnAct(torch.autograd.Function):
+    """Conv3d (groups=1) as implicit GEMM -> [BatchNorm] -> activation: conv_nxn_bn of mobilevit.py:19-24 and a dense
+    CausalConv3d (movinet.py:31).  Backward-data runs the same kernel on dy with the transposed, tap-reversed filter."""
+
+    @staticmethod
+    def forward(ctx, x5, w, bias, gamma, beta, rmean, rvar, cfg):
+        N, T, H, W, Cin = x5.shape
+        Cout = w.shape[0]
+        kernel, stride, pf, pb = cfg["kernel"], cfg["stride"], cfg["pad_front"], cfg["pad_back"]
+        taps = kernel[0] * kernel[1] * kernel[2]
+        out_thw = K.dw_out_shape((T, H, W), kernel, stride, pf, pb)
+        training, has_bn = cfg["training"], cfg["bn"] is not None
+        wp = K.conv_weight_prep(w.reshape(-1), 0, Cout, Cin, taps)
+        stats = _zeros((K.REPL, 2, Cout), x5) if (has_bn and training) else None
+        z5 = K.conv3d_fwd(x5, wp, Cout, kernel, stride, pf, out_thw, out_shift=bias, stats=stats)
+        z2 = z5.view(-1, Cout)
+        bnc, scale, shift = None, None, None
+        if has_bn:
+            eps, momentum = cfg["bn"]
+            bnc = _BnCtx()
+            bnc.scale, bnc.shift, bnc.mean, bnc.rstd = _bn_forward(z2, stats, z2.shape[0], gamma, beta, rmean, rvar, eps,
+                                                                   momentum, training)
+            bnc.training, bnc.count, bnc.beta = training, z2.shape[0], beta
+            scale, shift = bnc.scale, beta
+        plain = not has_bn and cfg["act"] == "none"
+        y5 = z5 if plain else K.affine_act_fwd(z2, scale, shift, cfg["act"], cfg["slope"],
+                                               mean=bnc.mean if bnc is not None else None).view(z5.shape)
+        if cfg["need_grad"]:
+            ctx.cfg, ctx.bnc, ctx.has_bias, ctx.plain = cfg, bnc, bias is not None, plain
+            ctx.save_for_backward(x5, z5, w, gamma)
+        return y5
+
+    @staticmethod
+    def backward(ctx, dy5):
+        x5, z5, w, gamma = ctx.saved_tensors
+        cfg = ctx.cfg
+        N, T, H, W, Cin = x5.shape
+        Cout = w.shape[0]
+        kernel, stride, pf = cfg["kernel"], cfg["stride"], cfg["pad_front"]
+        taps = kernel[0] * kernel[1] * kernel[2]
+        z2 = z5.view(-1, Cout)
+        dy2 = _contig5(dy5).view(-1, Cout)
+        dgamma = dbeta = None
+        if ctx.plain:
+            dz = dy2
+        else:
+            dz, dgamma, dbeta = _bn_act_backward(dy2, z2, ctx.bnc, gamma, cfg["act"], cfg["slope"], None, 0)
+        dz5 = dz.view(z5.shape)
+        dwp = K.conv3d_bwd_weight(dz5, x5, kernel, stride, pf)
+        dw = K.conv_weight_prep(dwp, 2, Cout, Cin, taps).view_as(w)
+        dbias = None
+        if ctx.has_bias:
+            st = _zeros((K.REPL, 2, Cout), x5)
+            K.chan_stats(dz, st)
+            dbias = st[:, 0].sum(0)
+        dx5 = None
+        if ctx.needs_input_grad[0]:
+            if tuple(stride) != (1, 1, 1):
+                raise NotImplementedError("picklebot_amd: input gradient of a strided dense Conv3d is not implemented")
+            wt = K.conv_weight_prep(w.reshape(-1), 1, Cout, Cin, taps)            # [Cin][taps reversed][Cout]
+            pad_t = tuple(k - 1 - p for k, p in zip(kernel, pf))
+            dx5 = K.conv3d_fwd(dz5, wt, Cin, kernel, (1, 1, 1), pad_t, (T, H, W))
+        return dx5, dw, dbias, dgamma, dbeta, None, None, None
+
+
+def conv_bn_act(x5, conv_weight, conv_bias, bn, *, stride, pad_front, pad_back=None, act="none", slope=0.0, training=False):
+    st = _bn_state(bn)
+    if st is not None and st[2] is None:
+        raise NotImplementedError("picklebot_amd: BatchNorm without running statistics")
+    gamma, beta, rmean, rvar = (st[0], st[1], st[2], st[3]) if st else (None, None, None, None)
+    params = [conv_weight, conv_bias, gamma, beta]
+    need_grad = torch.is_grad_enabled() and (x5.requires_grad or any(p is not None and p.requires_grad for p in params))
+    cfg = dict(kernel=tuple(conv_weight.shape[2:]), stride=tuple(stride), pad_front=tuple(pad_front),
+               pad_back=tuple(pad_back if pad_back is not None else pad_front), act=act, slope=slope, training=training,
+               bn=(st[4], st[5]) if st else None, need_grad=need_grad)
+    return _ConvBnAct.apply(_contig5(x5), conv_weight, conv_bias, gamma, beta, rmean, rvar, cfg)
+
+
+def conv3d_dense(x5, weight, bias, stride, pad_front, pad_back=None):
+    """Plain dense Conv3d.  The implicit-GEMM kernel wants channel counts that are multiples of the 16-byte
+    vector; other counts (only the CausalConv3d corner, no reference model) are zero-padded here with torch
+    layout ops - the convolution itself still runs in HIP."""
+    vec = 8 if x5.dtype == torch.bfloat16 else 4
+    cout, cin = weight.shape[0], weight.shape[1]
+    pi, po = (-cin) % vec, (-cout) % vec
+    if pi or po:
+        x5 = torch.nn.functional.pad(x5, (0, pi))
+        weight = torch.nn.functional.pad(weight, (0, 0, 0, 0, 0, 0, 0, pi, 0, po))
+        bias = torch.nn.functional.pad(bias, (0, po)) if bias is not None else None
+        y5 = conv_bn_act(x5, weight, bias, None, stride=stride, pad_front=pad_front, pad_back=pad_back)
+        return y5[..., :cout]
+    return conv_bn_act(x5, weight, bias, None, stride=stride, pad_front=pad_front, pad_back=pad_back)
+
+
+# =============================================================================== MobileViT token blocks
+class _Unfold(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x5, patch):
+        ctx.thw, ctx.patch = tuple(x5.shape[1:4]), patch
+        return K.unfold(x5, patch)
+
+    @staticmethod
+    def backward(ctx, dtok):
+        return K.fold(dtok if dtok.is_contiguous() else dtok.contiguous(), ctx.thw, ctx.patch), None
+
+
+class _Fold(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tok, thw, patch):
+        ctx.patch = patch
+        return K.fold(tok, thw, patch)
+
+    @staticmethod
+    def backward(ctx, dx5):
+        return K.unfold(_contig5(dx5), ctx.patch), None, None
+
+
+def unfold(x5, patch):
+    return _Unfold.apply(_contig5(x5), tuple(patch))
+
+
+def fold(tok, thw, patch):
+    return _Fold.apply(tok if tok.is_contiguous() else tok.contiguous(), tuple(thw), tuple(patch))
+
+
+class _AttnBlock(torch.autograd.Function):
+    """x + to_out(attention(to_qkv(LayerNorm(x))))   (mobilevit.py:68-86 + the residual of :102), rows [G*n, D]."""
+
+    @staticmethod
+    def forward(ctx, x, w_qkv, w_out, G, n, scale, eps):
+        D = x.shape[1]
+        xn, stat = K.layernorm_fwd(x, eps)
+        qkv = K.pw_fwd(xn, w_qkv)
+        o, lse = K.attention_fwd(qkv, G, n, scale)
+        y = K.pw_fwd(o, w_out)
+        K.copy_cols(x, 0, y, 0, D, accumulate=True)
+        ctx.save_for_backward(x, stat, xn, qkv, o, lse, w_qkv, w_out)
+        ctx.meta = (G, n, scale, eps)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, stat, xn, qkv, o, lse, w_qkv, w_out = ctx.saved_tensors
+        G, n, scale, eps = ctx.meta
+        D = x.shape[1]
+        dy = dy if dy.is_contiguous() else dy.contiguous()
+        dw_out, dw_qkv = _zeros_many(x, tuple(w_out.shape), tuple(w_qkv.shape))
+        K.pw_bwd_weight(dy, o, dw_out)
+        do = K.pw_fwd(dy, w_out, w_transposed=True)
+        dqkv = K.attention_bwd(qkv, o, do, lse, G, n, scale)
+        K.pw_bwd_weight(dqkv, xn, dw_qkv)
+        dxn = K.pw_fwd(dqkv, w_qkv, w_transposed=True)
+        dx = K.layernorm_bwd(x, dxn, stat, eps)
+        K.copy_cols(dy, 0, dx, 0, D, accumulate=True)
+        return dx, dw_qkv, dw_out, None, None, None, None
+
+
+class _FFBlock(torch.autograd.Function):
+    """x + W2 silu(W1 x)   (mobilevit.py:28-40 + the residual of :103)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, w2):
+        D = x.shape[1]
+        hpre = K.pw_fwd(x, w1)
+        y = K.pw_fwd(hpre, w2, in_act="silu")
+        K.copy_cols(x, 0, y, 0, D, accumulate=True)
+        ctx.save_for_backward(x, hpre, w1, w2)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, hpre, w1, w2 = ctx.saved_tensors
+        D = x.shape[1]
+        dy = dy if dy.is_contiguous() else dy.contiguous()
+        dw1, dw2 = _zeros_many(x, tuple(w1.shape), tuple(w2.shape))
+        K.pw_bwd_weight(dy, hpre, dw2, in_act="silu")
+        dh = K.pw_fwd(dy, w2, w_transposed=True)
+        dhpre = K.act_bwd_reduce(dh, hpre, act="silu")
+        K.pw_bwd_weight(dhpre, x, dw1)
+        dx = K.pw_fwd(dhpre, w1, w_transposed=True)
+        K.copy_cols(dy, 0, dx, 0, D, accumulate=True)
+        return dx, dw1, dw2
+
+
+def attn_block(rows, w_qkv, w_out, G, n, scale, eps):
+    return _AttnBlock.apply(rows if rows.is_contiguous() else rows.contiguous(), w_qkv, w_out, G, n, scale, eps)
+
+
+def ff_block(rows, w1, w2):
+    return _FFBlock.apply(rows if rows.is_contiguous() else rows.contiguous(), w1, w2)
+
+
+class _Concat2(torch.autograd.Function):
+    """torch.cat((a, b), channel) for NDHWC tensors (mobilevit.py:141)."""
+
+    @staticmethod
+    def forward(ctx, a5, b5):
+        Ca, Cb = a5.shape[-1], b5.shape[-1]
+        out = torch.empty(a5.shape[:-1] + (Ca + Cb,), dtype=a5.dtype, device=a5.device)
+        K.copy_cols(a5.view(-1, Ca), 0, out.view(-1, Ca + Cb), 0, Ca)
+        K.copy_cols(b5.view(-1, Cb), 0, out.view(-1, Ca + Cb), Ca, Cb)
+        ctx.split = (Ca, Cb)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        Ca, Cb = ctx.split
+        dout = _contig5(dout)
+        da = torch.empty(dout.shape[:-1] + (Ca,), dtype=dout.dtype, device=dout.device)
+        db = torch.empty(dout.shape[:-1] + (Cb,), dtype=dout.dtype, device=dout.device)
+        K.copy_cols(dout.view(-1, Ca + Cb), 0, da.view(-1, Ca), 0, Ca)
+        K.copy_cols(dout.view(-1, Ca + Cb), Ca, db.view(-1, Cb), 0, Cb)
+        return da, db
+
+
+def concat_channels(a5, b5):
+    return _Concat2.apply(_contig5(a5), _contig5(b5))

@@ -282,11 +282,11 @@ def bn_finalize(stats, count, gamma, beta, eps, momentum, running_mean, running_
 
 
 def affine_act_fwd(x, scale=None, shift=None, act="none", slope=0.0, row_scale=None, rows_per_group=0, stats=None,
-                   row_shift=None):
-    """y = act(x*scale+shift) * row_scale[g] + row_shift[g]; stats[2,C] += (sum y, sum y^2)."""
+                   row_shift=None, mean=None):
+    """y = act((x-mean)*scale+shift) * row_scale[g] + row_shift[g]; stats[REPL,2,C] += (sum y, sum y^2)."""
     _rows(x, "x")
     M, C = x.shape
-    _f32(scale, (C,), "scale"); _f32(shift, (C,), "shift"); _f32(stats, (REPL, 2, C), "stats")
+    _f32(scale, (C,), "scale"); _f32(shift, (C,), "shift"); _f32(stats, (REPL, 2, C), "stats"); _f32(mean, (C,), "mean")
     if row_scale is not None or row_shift is not None:
         if rows_per_group <= 0 or M % rows_per_group:
             raise ValueError("affine_act_fwd: rows_per_group must divide M")
@@ -294,7 +294,7 @@ def affine_act_fwd(x, scale=None, shift=None, act="none", slope=0.0, row_scale=N
         _f32(row_shift, (M // rows_per_group, C), "row_shift")
     y = torch.empty_like(x)
     dev, st = _dev_stream(x)
-    _launch("affine_act_fwd", _nb(x, y), "pb_affine_act_fwd", _p(x), _p(y), M, C, _dt(x), _p(scale), _p(shift), ACT[act], float(slope),
+    _launch("affine_act_fwd", _nb(x, y), "pb_affine_act_fwd", _p(x), _p(y), M, C, _dt(x), _p(scale), _p(shift), _p(mean), ACT[act], float(slope),
             _p(row_scale), _p(row_shift), int(rows_per_group), _p(stats), dev, st)
     return y
 
@@ -338,17 +338,17 @@ def bn_bwd_finalize(sums, count, gamma, mean, rstd, training, want_affine_grads)
     return out[0], out[1], out[2], (out[3] if want_affine_grads else None), (out[4] if want_affine_grads else None)
 
 
-def affine2(g, z, A, B=None, Cc=None):
+def affine2(g, z, A, B=None, Cc=None, mean=None):
     _rows(g, "g")
     M, C = g.shape
     if z is not None:
         _rows(z, "z")
         if z.shape != g.shape or z.dtype != g.dtype:
             raise ValueError("affine2: g/z mismatch")
-    _f32(A, (C,), "A"); _f32(B, (C,), "B"); _f32(Cc, (C,), "Cc")
+    _f32(A, (C,), "A"); _f32(B, (C,), "B"); _f32(Cc, (C,), "Cc"); _f32(mean, (C,), "mean")
     out = torch.empty_like(g)
     dev, st = _dev_stream(g)
-    _launch("affine2", _nb(g, z, out), "pb_affine2", _p(g), _p(z), _p(out), M, C, _dt(g), _p(A), _p(B), _p(Cc), dev, st)
+    _launch("affine2", _nb(g, z, out), "pb_affine2", _p(g), _p(z), _p(out), M, C, _dt(g), _p(A), _p(B), _p(Cc), _p(mean), dev, st)
     return out
 
 
@@ -400,3 +400,150 @@ def se_fc_bwd(dscale, pool, inv_count, scale, hidden, w1, w2, want_bias=True):
             _p(g_shift), _p(dw1), _p(db1) if want_bias else None, _p(dw2), _p(db2) if want_bias else None, _p(work),
             G, C, Cm, dev, st)
     return g_shift, dw1, (db1 if want_bias else None), dw2, (db2 if want_bias else None)
+
+
+# ------------------------------------------------------------------------------ dense conv (implicit GEMM)
+def _conv_shape(N, cin, cout, in_thw, out_thw, kernel, stride, pad):
+    s = _C.ConvShape()
+    s.N, s.Cin, s.Cout = N, cin, cout
+    s.Ti, s.Hi, s.Wi = in_thw
+    s.To, s.Ho, s.Wo = out_thw
+    s.kt, s.kh, s.kw = kernel
+    s.st, s.sh, s.sw = stride
+    s.pt, s.ph, s.pw = pad
+    return s
+
+
+def conv_weight_prep(w, mode, cout, cin, taps):
+    """mode 0: [Cout,Cin,taps] -> [Cout,taps,Cin]; 1: -> [Cin,taps reversed,Cout]; 2: [Cout,taps,Cin] -> [Cout,Cin,taps]."""
+    _f32(w, name="w")
+    if w.numel() != cout * cin * taps:
+        raise ValueError("conv_weight_prep: size mismatch")
+    out = torch.empty(cout * cin * taps, dtype=torch.float32, device=w.device)
+    dev, st = _dev_stream(w)
+    _launch("conv_weight_prep", _nb(w, out), "pb_conv_weight_prep", _p(w), _p(out), cout, cin, taps, int(mode), dev, st)
+    return out
+
+
+def conv3d_fwd(x, wp, cout, kernel, stride, pad_front, out_thw, *, out_scale=None, out_shift=None, out_act="none",
+               out_slope=0.0, stats=None):
+    """x [N,T,H,W,Cin], wp fp32 [Cout*taps*Cin] (prep mode 0) -> y [N,*out_thw,Cout]."""
+    _ndhwc(x, "x")
+    N, T, H, W, cin = x.shape
+    taps = kernel[0] * kernel[1] * kernel[2]
+    _f32(wp, (cout * taps * cin,), "wp")
+    _f32(out_scale, (cout,), "out_scale"); _f32(out_shift, (cout,), "out_shift"); _f32(stats, (REPL, 2, cout), "stats")
+    if min(out_thw) <= 0:
+        raise ValueError(f"conv3d_fwd: empty output {out_thw}")
+    y = torch.empty((N,) + tuple(out_thw) + (cout,), dtype=x.dtype, device=x.device)
+    s = _conv_shape(N, cin, cout, (T, H, W), out_thw, kernel, stride, pad_front)
+    dev, st = _dev_stream(x)
+    _launch("conv3d_fwd", _nb(x, y, wp), "pb_conv3d_fwd", _p(x), _p(wp), _p(y), ctypes.byref(s), _dt(x), _p(out_scale),
+            _p(out_shift), ACT[out_act], float(out_slope), _p(stats), dev, st,
+            detail=f"Cin{cin} Cout{cout} {T}x{H}x{W} k{kernel} s{stride}")
+    return y
+
+
+def conv3d_bwd_weight(dy, x, kernel, stride, pad_front):
+    """-> dwp fp32 [Cout, taps, Cin] (convert with conv_weight_prep mode 2)."""
+    _ndhwc(dy, "dy"); _ndhwc(x, "x")
+    N, To, Ho, Wo, cout = dy.shape
+    cin = x.shape[4]
+    taps = kernel[0] * kernel[1] * kernel[2]
+    if x.shape[0] != N or x.dtype != dy.dtype:
+        raise ValueError("conv3d_bwd_weight: dy/x mismatch")
+    dwp = torch.zeros(cout * taps * cin, dtype=torch.float32, device=x.device)
+    s = _conv_shape(N, cin, cout, tuple(x.shape[1:4]), (To, Ho, Wo), kernel, stride, pad_front)
+    dev, st = _dev_stream(x)
+    _launch("conv3d_wgrad", _nb(dy, x, dwp), "pb_conv3d_bwd_weight", _p(dy), _p(x), _p(dwp), ctypes.byref(s), _dt(x), dev, st,
+            detail=f"Cin{cin} Cout{cout} {tuple(x.shape[1:4])} k{kernel}")
+    return dwp
+
+
+# ------------------------------------------------------------------------------ MobileViT token ops
+def unfold(x5, patch):
+    """voxels [B,T,H,W,D] -> tokens [B, pt*ph*pw, t*h*w, D] (zero padded to patch multiples)."""
+    _ndhwc(x5, "x5")
+    B, T, H, W, D = x5.shape
+    pt, ph, pw = patch
+    t, h, w = -(-T // pt), -(-H // ph), -(-W // pw)
+    tok = torch.empty((B, pt * ph * pw, t * h * w, D), dtype=x5.dtype, device=x5.device)
+    dev, st = _dev_stream(x5)
+    _launch("unfold", _nb(x5, tok), "pb_unfold_fold", _p(x5), _p(tok), B, D, T, H, W, pt, ph, pw, 1, _dt(x5), dev, st)
+    return tok
+
+
+def fold(tok, thw, patch):
+    """tokens [B,P,n,D] -> voxels [B,T,H,W,D] (cropped)."""
+    if tok.dim() != 4 or not tok.is_contiguous():
+        raise ValueError("fold: expected contiguous [B,P,n,D] tokens")
+    B, P_, n, D = tok.shape
+    T, H, W = thw
+    pt, ph, pw = patch
+    if P_ != pt * ph * pw or n != (-(-T // pt)) * (-(-H // ph)) * (-(-W // pw)):
+        raise ValueError("fold: token shape does not match the voxel grid")
+    vox = torch.empty((B, T, H, W, D), dtype=tok.dtype, device=tok.device)
+    dev, st = _dev_stream(tok)
+    _launch("fold", _nb(tok, vox), "pb_unfold_fold", _p(tok), _p(vox), B, D, T, H, W, pt, ph, pw, 0, _dt(tok), dev, st)
+    return vox
+
+
+def layernorm_fwd(x, eps):
+    _rows(x, "x")
+    M, D = x.shape
+    y = torch.empty_like(x)
+    stat = torch.empty((M, 2), dtype=torch.float32, device=x.device)
+    dev, st = _dev_stream(x)
+    _launch("layernorm_fwd", _nb(x, y), "pb_layernorm", _p(x), None, _p(y), _p(stat), M, D, float(eps), 0, _dt(x), dev, st)
+    return y, stat
+
+
+def layernorm_bwd(x, dy, stat, eps):
+    _rows(x, "x"); _rows(dy, "dy")
+    M, D = x.shape
+    _f32(stat, (M, 2), "stat")
+    if dy.shape != x.shape or dy.dtype != x.dtype:
+        raise ValueError("layernorm_bwd: x/dy mismatch")
+    dx = torch.empty_like(x)
+    dev, st = _dev_stream(x)
+    _launch("layernorm_bwd", _nb(x, dy, dx), "pb_layernorm", _p(x), _p(dy), _p(dx), _p(stat), M, D, float(eps), 1, _dt(x), dev, st)
+    return dx
+
+
+def copy_cols(src, src_off, dst, dst_off, C, accumulate=False):
+    """dst[:, dst_off:dst_off+C] (+)= src[:, src_off:src_off+C] for contiguous 2-D src/dst with equal row counts."""
+    _rows(src, "src"); _rows(dst, "dst")
+    if src.shape[0] != dst.shape[0] or src.dtype != dst.dtype:
+        raise ValueError("copy_cols: src/dst mismatch")
+    if src_off + C > src.shape[1] or dst_off + C > dst.shape[1]:
+        raise ValueError("copy_cols: column range out of bounds")
+    dev, st = _dev_stream(src)
+    _launch("copy_cols", 2 * src.shape[0] * C * src.element_size(), "pb_copy_cols", _p(src), src.shape[1], int(src_off), _p(dst),
+            dst.shape[1], int(dst_off), src.shape[0], int(C), int(accumulate), _dt(src), dev, st)
+    return dst
+
+
+def attention_fwd(qkv, G, n, scale):
+    """qkv [G*n, 384] -> (out [G*n, 128], lse fp32 [G*n, 8]); 8 heads of 16 (mobilevit.py:116)."""
+    _rows(qkv, "qkv")
+    if qkv.shape != (G * n, 384):
+        raise ValueError(f"attention_fwd: qkv shape {tuple(qkv.shape)} != ({G * n}, 384)")
+    out = torch.empty((G * n, 128), dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty((G * n, 8), dtype=torch.float32, device=qkv.device)
+    dev, st = _dev_stream(qkv)
+    _launch("attention_fwd", _nb(qkv, out), "pb_attention_fwd", _p(qkv), _p(out), _p(lse), G, n, float(scale), _dt(qkv), dev, st,
+            detail=f"G{G} n{n}")
+    return out, lse
+
+
+def attention_bwd(qkv, out, dout, lse, G, n, scale):
+    _rows(qkv, "qkv"); _rows(out, "out"); _rows(dout, "dout")
+    if qkv.shape != (G * n, 384) or out.shape != (G * n, 128) or dout.shape != out.shape or dout.dtype != qkv.dtype:
+        raise ValueError("attention_bwd: shape/dtype mismatch")
+    _f32(lse, (G * n, 8), "lse")
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty((G * n, 8), dtype=torch.float32, device=qkv.device)
+    dev, st = _dev_stream(qkv)
+    _launch("attention_bwd", _nb(qkv, out, dout, dqkv), "pb_attention_bwd", _p(qkv), _p(out), _p(dout), _p(lse), _p(delta), _p(dqkv),
+            G, n, float(scale), _dt(qkv), dev, st, detail=f"G{G} n{n}")
+    return dqkv

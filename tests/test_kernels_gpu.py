@@ -188,8 +188,8 @@ def test_norm_act_family(K, M, C, G, dtype):
     rs, rsh = torch.rand(G, C) + 0.5, rnd((G, C), seed=24) * 0.1
     for act in ("none", "relu", "leaky_relu", "hardswish", "silu", "hardsigmoid"):
         s2_ref, s2 = torch.zeros(R.REPL, 2, C), torch.zeros(R.REPL, 2, C, device=DEV)
-        y_ref = R.affine_act_fwd(x, scale, shift, act, 0.01, rs, M // G, s2_ref, rsh)
-        y = K.affine_act_fwd(dev(x), dev(scale), dev(shift), act, 0.01, dev(rs), M // G, s2, dev(rsh))
+        y_ref = R.affine_act_fwd(x, scale, shift, act, 0.01, rs, M // G, s2_ref, rsh, mean=mean)
+        y = K.affine_act_fwd(dev(x), dev(scale), dev(shift), act, 0.01, dev(rs), M // G, s2, dev(rsh), mean=dev(mean))
         check("affine_act_" + act, y, y_ref, dtype)
         check("affine_act_stats_" + act, s2.sum(0), s2_ref.sum(0), dtype, 2.0)
         dy = rnd((M, C), dtype, 25)
@@ -213,7 +213,7 @@ def test_norm_act_family(K, M, C, G, dtype):
     for a, b, n in zip(fin, fin_ref, "ABCgb"):
         check("bn_bwd_fin_" + n, a, b, torch.float32)
     A, B, Cc = fin_ref[:3]
-    check("affine2", K.affine2(dev(g_ref), dev(x), dev(A), dev(B), dev(Cc)), R.affine2(g_ref, x, A, B, Cc), dtype)
+    check("affine2", K.affine2(dev(g_ref), dev(x), dev(A), dev(B), dev(Cc), dev(mean)), R.affine2(g_ref, x, A, B, Cc, mean), dtype)
     check("rowgroup_sum", K.rowgroup_reduce(dev(x), None, G), R.rowgroup_reduce(x, None, G), dtype)
     check("rowgroup_dot", K.rowgroup_reduce(dev(x), dev(dy), G), R.rowgroup_reduce(x, dy, G), dtype)
 
@@ -244,3 +244,92 @@ def test_bad_arguments_raise(K):
         K.pw_fwd(torch.zeros(8, 16), torch.zeros(4, 16))           # CPU tensors: no fallback
     with pytest.raises(ValueError):
         K.pw_fwd(x.t(), torch.zeros(4, 8, device=DEV))             # non-contiguous
+
+
+CONV_CASES = [  # N, Cin, Cout, (T,H,W), kernel, stride, pad
+    (2, 16, 16, (3, 6, 6), (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    (1, 96, 96, (4, 9, 9), (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    (1, 192, 96, (3, 8, 8), (3, 3, 3), (1, 1, 1), (1, 1, 1)),       # 2C -> C (conv4 of MobileViTBlock), K stages 64+64+64
+    (1, 48, 80, (5, 7, 7), (3, 3, 3), (1, 1, 1), (1, 1, 1)),        # partial channel stage
+    (1, 8, 24, (7, 5, 5), (3, 3, 3), (1, 1, 1), (2, 1, 1)),         # causal-style front padding only on T (back pad 0)
+    (2, 16, 8, (4, 9, 9), (1, 3, 3), (1, 2, 2), (0, 1, 1)),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("N,Cin,Cout,thw,kernel,stride,pad", CONV_CASES)
+def test_conv3d_dense(K, N, Cin, Cout, thw, kernel, stride, pad, dtype):
+    taps = kernel[0] * kernel[1] * kernel[2]
+    pad_back = (0, pad[1], pad[2]) if pad[0] == 2 else pad
+    x = rnd((N, *thw, Cin), dtype, 40)
+    w = rnd((Cout, Cin, *kernel), seed=41, scale=(Cin * taps) ** -0.5)
+    bias = rnd((Cout,), seed=42, scale=0.1)
+    out_thw = R.dw_out_shape(thw, kernel, stride, pad, pad_back)
+    wp_ref = R.conv_weight_prep(w.reshape(-1), 0, Cout, Cin, taps)
+    wp = K.conv_weight_prep(dev(w).reshape(-1), 0, Cout, Cin, taps)
+    check("conv_prep0", wp, wp_ref, torch.float32)
+    st_ref, st = torch.zeros(R.REPL, 2, Cout), torch.zeros(R.REPL, 2, Cout, device=DEV)
+    y_ref = R.conv3d_fwd(x, wp_ref, Cout, kernel, stride, pad, out_thw, out_shift=bias, stats=st_ref)
+    y = K.conv3d_fwd(dev(x), wp, Cout, kernel, stride, pad, out_thw, out_shift=dev(bias), stats=st)
+    check("conv3d_fwd", y, y_ref, dtype)
+    check("conv3d_stats", st.sum(0), st_ref.sum(0), dtype, 2.0)
+    dy = rnd(tuple(y_ref.shape), dtype, 43)
+    dwp_ref = R.conv3d_bwd_weight(dy, x, kernel, stride, pad)
+    dwp = K.conv3d_bwd_weight(dev(dy), dev(x), kernel, stride, pad)
+    check("conv3d_wgrad", dwp, dwp_ref, dtype)
+    check("conv_prep2", K.conv_weight_prep(dwp, 2, Cout, Cin, taps), R.conv_weight_prep(dwp_ref, 2, Cout, Cin, taps), dtype)
+    if stride == (1, 1, 1):
+        wt_ref = R.conv_weight_prep(w.reshape(-1), 1, Cout, Cin, taps)
+        check("conv_prep1", K.conv_weight_prep(dev(w).reshape(-1), 1, Cout, Cin, taps), wt_ref, torch.float32)
+        pad_t = tuple(k - 1 - p for k, p in zip(kernel, pad))
+        dx_ref = R.conv3d_fwd(dy, wt_ref, Cin, kernel, (1, 1, 1), pad_t, thw)
+        dx = K.conv3d_fwd(dev(dy), dev(wt_ref), Cin, kernel, (1, 1, 1), pad_t, thw)
+        check("conv3d_bwd_data", dx, dx_ref, dtype)
+        # and the mirror itself against autograd of the plain conv
+        xg = x.float().permute(0, 4, 1, 2, 3).clone().requires_grad_(True)
+        pb = [max((o - 1) * s_ + k - i - pf, 0) for o, s_, k, i, pf in zip(out_thw, stride, kernel, thw, pad)]
+        import torch.nn.functional as TF
+        yy = TF.conv3d(TF.pad(xg, (pad[2], pb[2], pad[1], pb[1], pad[0], pb[0])), w.to(dtype).float(), stride=stride)
+        (gx,) = torch.autograd.grad(yy[:, :, :out_thw[0], :out_thw[1], :out_thw[2]], xg, dy.float().permute(0, 4, 1, 2, 3))
+        assert rel_err(dx_ref.float().numpy(), gx.permute(0, 2, 3, 4, 1).numpy()) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,D,thw", [(2, 16, (3, 5, 5)), (1, 144, (6, 8, 8)), (1, 80, (5, 14, 14)), (2, 96, (4, 7, 7))])
+def test_unfold_fold_layernorm_copy(K, B, D, thw, dtype):
+    x = rnd((B, *thw, D), dtype, 50)
+    tok_ref = R.unfold(x, (2, 2, 2))
+    tok = K.unfold(dev(x), (2, 2, 2))
+    assert torch.equal(tok.cpu(), tok_ref)
+    assert torch.equal(K.fold(tok, thw, (2, 2, 2)).cpu(), R.fold(tok_ref, thw, (2, 2, 2)))
+    assert torch.equal(R.fold(tok_ref, thw, (2, 2, 2)), x)                  # fold(unfold(x)) == x
+    rows = tok_ref.reshape(-1, D)
+    y_ref, st_ref = R.layernorm_fwd(rows, 1e-5)
+    y, st = K.layernorm_fwd(dev(rows), 1e-5)
+    check("layernorm", y, y_ref, dtype); check("layernorm_stat", st, st_ref, dtype)
+    dy = rnd(tuple(rows.shape), dtype, 51)
+    check("layernorm_bwd", K.layernorm_bwd(dev(rows), dev(dy), dev(st_ref), 1e-5), R.layernorm_bwd(rows, dy, st_ref, 1e-5), dtype)
+    vec = 8 if dtype == torch.bfloat16 else 4
+    dst_ref, dst = torch.zeros(rows.shape[0], 2 * D + vec, dtype=dtype), torch.zeros(rows.shape[0], 2 * D + vec, dtype=dtype, device=DEV)
+    R.copy_cols(rows, 0, dst_ref, vec, D); K.copy_cols(dev(rows), 0, dst, vec, D)
+    R.copy_cols(dy, 0, dst_ref, vec + D, D); K.copy_cols(dev(dy), 0, dst, vec + D, D)
+    R.copy_cols(dy, 0, dst_ref, vec, D, True); K.copy_cols(dev(dy), 0, dst, vec, D, True)
+    check("copy_cols", dst, dst_ref, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("G,n", [(8, 6), (3, 32), (2, 147), (2, 128), (1, 784)])
+def test_attention(K, G, n, dtype):
+    qkv = rnd((G * n, 384), dtype, 60, scale=1.5)
+    out_ref, lse_ref = R.attention_fwd(qkv, G, n, 0.25)
+    out, lse = K.attention_fwd(dev(qkv), G, n, 0.25)
+    check("attn_out", out, out_ref, dtype)
+    check("attn_lse", lse, lse_ref, torch.float32, 5.0)
+    # and the mirror against torch SDPA (what the reference calls)
+    q, k, v = R._split_heads(qkv, G, n)
+    sd = torch.nn.functional.scaled_dot_product_attention(q, k, v).permute(0, 2, 1, 3).reshape(G * n, 128)
+    assert rel_err(out_ref.float().numpy(), sd.numpy()) < TOL[dtype]
+    dout = rnd((G * n, 128), dtype, 61)
+    dq_ref = R.attention_bwd(qkv, out_ref, dout, lse_ref, G, n, 0.25)
+    dq = K.attention_bwd(dev(qkv), dev(out_ref), dev(dout), dev(lse_ref), G, n, 0.25)
+    check("attn_dqkv", dq, dq_ref, dtype, 1.5)

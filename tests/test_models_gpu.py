@@ -42,11 +42,11 @@ def test_block_fp32_vs_golden(case, golden):
 def test_block_bf16_autocast_vs_golden(case, golden):
     """fp32 input + autocast(bf16), exactly how the golden's refbf16_err (the reference's own bf16 CPU
     deviation) was produced.  Tiny blocks (8-24 channels, <=300 rows, BN over few rows) are noisy in
-    bf16 (one draw of rounding noise each): allowed error = max(2e-2, 6 x the reference's own
+    bf16 (one draw of rounding noise each): allowed error = max(2e-2, 8 x the reference's own
     deviation) per tensor; the model-level tests below carry the north_star's bf16 bar."""
     with contextlib.redirect_stdout(io.StringIO()):
         res = protocol.run_block_case(picklebot_amd, case, device=DEV, autocast=True)
-    bad, worst = compare_full(res, golden("blocks"), case + "/", 2e-2, 2e-2, dev="refbf16_err", factor=6.0)
+    bad, worst = compare_full(res, golden("blocks"), case + "/", 2e-2, 2e-2, dev="refbf16_err", factor=8.0)
     assert not bad, f"{bad[:5]} worst {worst}"
 
 
