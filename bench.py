@@ -114,6 +114,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+    host_enqueue_ms = (time.perf_counter() - t0) / args.steps * 1e3     # host time to submit a step (GPU runs behind)
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -146,8 +147,18 @@ def main():
         dom = next(iter(families))
         d = prof[dom]
         ach = d["bytes"] / 1e9 / (d["ms"] / 1e3)
+        # HBM bytes per launch from the committed PMC summary (rocprofv3 FETCH_SIZE/WRITE_SIZE passes of this
+        # same command, corrected as MI355X_MICROARCH.md prescribes; tools/pmc_summary.py) - null if absent
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
+            key = dom.split("<")[0]
+            if key in pmc:
+                traffic = pmc[key]["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
         roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "bytes_per_launch": int(d["bytes"] / d["launches"]), "avg_launch_us": round(d["ms"] / d["launches"] * 1e3, 2),
                     "launches": d["launches"], "measured_over": f"{args.steps} steps re-run with HIP events around every launch"}
     if world > 1:
@@ -164,6 +175,7 @@ def main():
                        "step": "fwd + CE loss + bwd + RCCL grad all-reduce (n>1) + fused AdamW",
                        "weights": "random init (seed 1234)", "loss": round(float(loss.item()), 4)},
             "roofline": roofline,
+            "host_enqueue_ms_per_step": round(host_enqueue_ms, 3),
             "kernel_families": families,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -34,7 +34,7 @@ typedef enum {
   PB_ACT_HSIGMOID = 4, PB_ACT_SILU = 5
 } pb_act;
 
-#define PB_ABI_VERSION 3
+#define PB_ABI_VERSION 4
 
 /* Per-channel statistics buffers (`stats`, `sums` below) are PB_STAT_REPLICAS replicas of [2][C]
  * fp32, layout [replica][2][C], zero-filled by the caller.  A workgroup adds its partial sums into
@@ -126,6 +126,10 @@ int pb_dwconv3d_bwd_data(const void* dy, const float* w, void* dx, const pb_dwco
                          const float* g_scale, const float* g_shift, int device, void* stream);
 int pb_dwconv3d_bwd_weight(const void* dy, const void* x, float* dw, const pb_dwconv_shape* s, pb_dtype dtype,
                            const float* g_scale, const float* g_shift, int device, void* stream);
+
+/* Name of the HIP kernel the dispatcher picks for this shape (profiling labels: rocprofv3 kernel names
+ * <-> bench.py families).  which: 0 = forward, 1 = backward-data, 2 = backward-weight.  Static string. */
+const char* pb_dwconv3d_kernel_name(const pb_dwconv_shape* s, pb_dtype dtype, int which);
 
 /* ---------------------------------------------------------------- dense conv with tiny Cin (stems)
  * Replaces nn.Conv3d(3,Cout,k,stride,pad) on the raw clip: mobilenet.py:141,221 (3x3x3 s2 p1 +bias),

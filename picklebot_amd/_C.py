@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libpicklebot_amd.so")
 
 PB_F32, PB_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY_RELU, ACT_HSWISH, ACT_HSIGMOID, ACT_SILU = range(6)
-ABI_VERSION = 3
+ABI_VERSION = 4
 STAT_REPLICAS = 16
 
 
@@ -66,6 +66,12 @@ SIGNATURES = {
 _lib = None
 
 
+# entry points returning a static C string instead of a status
+STRING_SIGNATURES = {
+    "pb_dwconv3d_kernel_name": [POINTER(DwShape), I, I],
+}
+
+
 def load():
     """Load (once) and type the library.  Raises RuntimeError when it is not built."""
     global _lib
@@ -83,6 +89,10 @@ def load():
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = c_int
+        fn.argtypes = args
+    for name, args in STRING_SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = c_char_p
         fn.argtypes = args
     if lib.pb_abi_version() != ABI_VERSION:
         raise RuntimeError(f"picklebot_amd: ABI version mismatch ({lib.pb_abi_version()} != {ABI_VERSION}); rebuild")

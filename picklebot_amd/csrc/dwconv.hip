@@ -13,7 +13,7 @@
 //   backward-data, s=1 : the same kernel on dy with the filter flipped
 //   backward-weight    : same walk, taps accumulated in registers across a persistent loop
 // Generic path: any (kt,kh,kw)/stride/padding (MoViNet blocks, CausalConv3d, s=2 backward-data).
-#include "pb_common.h"
+#include "dw_internal.h"
 
 namespace {
 
@@ -784,7 +784,38 @@ int check_shape(const pb_dwconv_shape* s, const char* who) {
   return 0;
 }
 
+// stride-1 backward-data as a forward-type correlation of dy with the flipped filter (padding k-1-p)
+bool bwd_is_s1_corr(const pb_dwconv_shape& s) {
+  return strip_ok(s) && s.sh == 1 && s.st == 1 && s.Ho == s.Hi + 2 * s.ph - s.kh + 1 && s.Wo == s.Wi + 2 * s.pw - s.kw + 1;
+}
+pb_dwconv_shape bwd_corr_shape(const pb_dwconv_shape& s) {
+  pb_dwconv_shape c = s;
+  c.Ti = s.To; c.Hi = s.Ho; c.Wi = s.Wo;
+  c.To = s.Ti; c.Ho = s.Hi; c.Wo = s.Wi;
+  c.ph = c.pw = s.kh - 1 - s.ph;
+  c.st = 1; c.pt = -s.pt;            // ts = td + pt
+  return c;
+}
+
 }  // namespace
+
+extern "C" const char* pb_dwconv3d_kernel_name(const pb_dwconv_shape* s, pb_dtype dtype, int which) {
+  if (!s) return "";
+  if (which == 0) {
+    if (pb_dw_tile_eligible(s, dtype, false)) return "dw_tile_fwd_kernel";
+    return strip_ok(*s) ? "dw_strip_fwd_kernel" : "dw_gen_fwd_kernel";
+  }
+  if (which == 1) {
+    if (bwd_is_s1_corr(*s)) {
+      const pb_dwconv_shape c = bwd_corr_shape(*s);
+      return pb_dw_tile_eligible(&c, dtype, false) ? "dw_tile_fwd_kernel" : "dw_strip_fwd_kernel";
+    }
+    if (strip_ok(*s) && s->sh == 2 && s->ph == s->kh / 2) return "dw_strip_bwd_s2_kernel";
+    return "dw_gen_bwd_data_kernel";
+  }
+  if (pb_dw_tile_eligible(s, dtype, true)) return "dw_tile_wgrad_kernel";
+  return strip_ok(*s) ? "dw_strip_wgrad_kernel" : "dw_gen_wgrad_kernel";
+}
 
 extern "C" int pb_dwconv3d_fwd(const void* x, const float* w, void* y, const pb_dwconv_shape* s, pb_dtype dtype,
                                float* pool, int device, void* stream) {
@@ -793,6 +824,10 @@ extern "C" int pb_dwconv3d_fwd(const void* x, const float* w, void* y, const pb_
   PB_CHECK_ARG(dtype == PB_F32 || dtype == PB_BF16, "pb_dwconv3d_fwd: bad dtype");
   PB_ENTER(device);
   hipStream_t st = (hipStream_t)stream;
+  {
+    const int rc = pb_dw_tile_fwd(x, w, y, s, dtype, 0, nullptr, nullptr, pool, st);
+    if (rc >= 0) return rc;
+  }
   if (strip_ok(*s)) {
     StripArgs a = {};
     a.src = x; a.w = w; a.dst = y; a.N = s->N; a.C = s->C;
@@ -846,8 +881,12 @@ extern "C" int pb_dwconv3d_bwd_data(const void* dy, const float* w, void* dx, co
   PB_ENTER(device);
   hipStream_t st = (hipStream_t)stream;
   // stride-1 spatial + temporal: correlation of dy with the flipped filter, padding k-1-p
-  if (strip_ok(*s) && s->sh == 1 && s->st == 1 && s->Ho == s->Hi + 2 * s->ph - s->kh + 1 &&
-      s->Wo == s->Wi + 2 * s->pw - s->kw + 1) {
+  if (bwd_is_s1_corr(*s)) {
+    const pb_dwconv_shape c = bwd_corr_shape(*s);
+    const int rc = pb_dw_tile_fwd(dy, w, dx, &c, dtype, 1, g_scale, g_shift, nullptr, st);
+    if (rc >= 0) return rc;
+  }
+  if (bwd_is_s1_corr(*s)) {
     StripArgs a = {};
     a.src = dy; a.w = w; a.dst = dx; a.N = s->N; a.C = s->C;
     a.Tsrc = s->To; a.Hs = s->Ho; a.Ws = s->Wo; a.Tdst = s->Ti; a.Hd = s->Hi; a.Wd = s->Wi;
@@ -907,6 +946,10 @@ extern "C" int pb_dwconv3d_bwd_weight(const void* dy, const void* x, float* dw, 
   PB_CHECK_ARG(dtype == PB_F32 || dtype == PB_BF16, "pb_dwconv3d_bwd_weight: bad dtype");
   PB_ENTER(device);
   hipStream_t st = (hipStream_t)stream;
+  {
+    const int rc = pb_dw_tile_wgrad(dy, x, dw, s, dtype, g_scale, g_shift, st);
+    if (rc >= 0) return rc;
+  }
   if (strip_ok(*s)) {
     StripArgs a = {};
     a.dst = const_cast<void*>(dy); a.x = x; a.dw = dw; a.N = s->N; a.C = s->C;

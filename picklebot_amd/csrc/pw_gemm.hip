@@ -15,6 +15,7 @@
 //     masters, L2 resident) are converted while staging;
 //   * the accumulators go back through LDS so that Y is written as whole 16 B/lane row segments.
 #include "pb_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -559,6 +560,8 @@ struct WgArgs {
   int64_t rows_per_group;
   int64_t rows_per_wg;
   int n_tiles, k_tiles;
+  int ranges_per_group;   // > 0: row ranges are clip-aligned and the squeeze-excite scale is applied to the accumulators
+  int split;           // pw_wgrad128: number of row ranges (grid.x is padded to 8 * tiles * ceil(split/8))
   // CONV: blockIdx.z = filter tap, X rows are the tap-shifted input voxels, dW is [N][taps][K]
   int cTi, cHi, cWi, cTo, cHo, cWo, ckt, ckh, ckw, cst, csh, csw, cpt, cph, cpw;
 };
@@ -734,6 +737,308 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgArgs a) {
   }
 }
 
+// 128 x 128 output tile per workgroup (bf16): the four waves own the four 64 x 64 quadrants and share
+// every staged 32-row block of dY[:, 128] and X[:, 128] (double-buffered LDS, one barrier per block), so
+// each operand is re-read N/128 resp. K/128 times instead of N/64, K/64 - the 64 x 64 wave-private
+// version measured 2.3x its algorithmic bytes in HBM traffic (profiles/r01_pmc_traffic.json).
+template <bool CONV>
+__global__ __launch_bounds__(256) void pw_wgrad128_kernel(WgArgs a) {
+  typedef bf16_t T;
+  constexpr int VEC = 8, TT = 128;
+  constexpr int LD = (TT + VEC) * 2;                 // bytes per LDS row (272)
+  constexpr int SLAB = 32 * LD;                      // one operand, one buffer
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * SLAB];    // [buf][dY | X]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave & 1, wk = wave >> 1;
+  // XCD-aware order: workgroup ids are dealt round-robin to the 8 XCDs, so the tiles that re-read the
+  // same row range get ids 8 apart - same XCD (same L2), dispatched back to back.
+  const int tiles = a.n_tiles * a.k_tiles;
+  const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+  const int tile = jj % tiles, srange = (jj / tiles) * 8 + xcd;
+  if (srange >= a.split) return;
+  const int nt = tile % a.n_tiles, kt = tile / a.n_tiles;
+  const int n0 = nt * TT, k0 = kt * TT;
+  // Squeeze-excite input scale (X[m][k] * s[clip(m)][k]): when every row range lies inside one clip the
+  // factor leaves the reduction - dW[n][k] += s[clip][k] * sum_m dY[m][n] X[m][k] - and is applied once
+  // to the accumulators; nothing rides on the streaming loop.
+  int64_t mbeg, mend;
+  int clip = 0;
+  if (a.ranges_per_group > 0) {
+    clip = srange / a.ranges_per_group;
+    const int sub = srange - clip * a.ranges_per_group;
+    mbeg = (int64_t)clip * a.rows_per_group + (int64_t)sub * a.rows_per_wg;
+    mend = min((int64_t)(clip + 1) * a.rows_per_group, mbeg + a.rows_per_wg);
+  } else {
+    mbeg = (int64_t)srange * a.rows_per_wg;
+    mend = min(a.M, mbeg + a.rows_per_wg);
+  }
+  const T* dY = (const T*)a.dY;
+  const T* X = (const T*)a.X;
+  PwArgs pa;
+  pa.K = a.K; pa.in_scale = a.in_scale; pa.in_shift = a.in_shift; pa.in_act = a.in_act;
+  pa.in_slope = a.in_slope; pa.row_scale = a.row_scale; pa.rows_per_group = a.rows_per_group; pa.M = a.M;
+  const bool pro = a.ranges_per_group == 0 && (a.in_scale || a.in_shift || a.in_act != PB_ACT_NONE || a.row_scale);
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // 32 rows x 16 chunks per operand = 512 chunks: 2 per thread
+  Vec16<T> rd[2], rx[2];
+  RowScale<T> rsx[2];
+  auto fetch = [&](int64_t mb) {
+    int64_t g0 = 0, g0_end = 0;
+    if (a.row_scale) {
+      g0 = mb / a.rows_per_group;
+      g0_end = (g0 + 1) * a.rows_per_group;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int f = tid + i * 256;
+      const int r = f >> 4, c = f & 15;
+      const int64_t m = mb + r;
+      const int n = n0 + c * VEC, k = k0 + c * VEC;
+      rd[i] = (m < mend && n < a.N) ? vec_load<T>(dY + m * a.N + n) : vec_zero<T>();
+      bool ok = m < mend && k < a.K;
+      int64_t mx = m;
+      if constexpr (CONV) {
+        if (ok) {
+          const int tap = blockIdx.z;
+          const int dw_ = tap % a.ckw, dh = (tap / a.ckw) % a.ckh, dt = tap / (a.ckw * a.ckh);
+          int64_t q = m;
+          const int wo = (int)(q % a.cWo); q /= a.cWo;
+          const int ho = (int)(q % a.cHo); q /= a.cHo;
+          const int to = (int)(q % a.cTo);
+          const int64_t nn = q / a.cTo;
+          const int ti = to * a.cst - a.cpt + dt, hi = ho * a.csh - a.cph + dh, wi = wo * a.csw - a.cpw + dw_;
+          ok = ti >= 0 && ti < a.cTi && hi >= 0 && hi < a.cHi && wi >= 0 && wi < a.cWi;
+          mx = ((nn * a.cTi + ti) * a.cHi + hi) * a.cWi + wi;
+        }
+      }
+      rx[i] = ok ? vec_load<T>(X + mx * a.K + k) : vec_zero<T>();
+      rsx[i].ones();
+      if (pro && ok) rsx[i] = fetch_rowscale<T>(pa, row_group(m, mb, g0, g0_end, a.rows_per_group), k);
+    }
+  };
+  int buf = 0;
+  if (mbeg < mend) fetch(mbeg);
+  for (int64_t mb = mbeg; mb < mend; mb += 32) {
+    unsigned char* Ds = smem + buf * 2 * SLAB;
+    unsigned char* Xs = Ds + SLAB;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int f = tid + i * 256;
+      const int r = f >> 4, c = f & 15;
+      vec_store<T>((T*)(Ds + r * LD) + c * VEC, rd[i]);
+      if (pro) rx[i] = apply_prologue<T>(rx[i], rsx[i], pa, k0 + c * VEC);
+      vec_store<T>((T*)(Xs + r * LD) + c * VEC, rx[i]);
+    }
+    lds_barrier();
+    if (mb + 32 < mend) fetch(mb + 32);              // in flight during the MFMAs
+    {
+      const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+      typedef __attribute__((address_space(3))) bf16x4* lds_p;
+      bf16x8 fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(Ds + (8 * g + q) * LD + (wn * 64 + i * 16 + 4 * p) * 2));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(Ds + (8 * g + 4 + q) * LD + (wn * 64 + i * 16 + 4 * p) * 2));
+        fa[i] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(Xs + (8 * g + q) * LD + (wk * 64 + j * 16 + 4 * p) * 2));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(Xs + (8 * g + 4 + q) * LD + (wk * 64 + j * 16 + 4 * p) * 2));
+        fb[j] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    buf ^= 1;
+  }
+  // quadrants are disjoint: each wave adds its own 64 x 64 block (row = n = (lane>>4)*4 + r, col = k = lane & 15)
+  const int64_t ldw = CONV ? (int64_t)a.ckt * a.ckh * a.ckw * a.K : a.K;
+  const int64_t woff = CONV ? (int64_t)blockIdx.z * a.K : 0;
+  float sk[4] = {1.f, 1.f, 1.f, 1.f};
+  if (a.ranges_per_group > 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = k0 + wk * 64 + j * 16 + (lane & 15);
+      if (k < a.K) sk[j] = a.row_scale[(int64_t)clip * a.K + k];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + wn * 64 + i * 16 + (lane >> 4) * 4 + r;
+        const int k = k0 + wk * 64 + j * 16 + (lane & 15);
+        if (n < a.N && k < a.K) atomicAdd(a.dW + (int64_t)n * ldw + woff + k, acc[i][j][r] * sk[j]);
+      }
+}
+
+// LDS-DMA variant of the 128 x 128 weight-gradient tile (plain streams: no affine prologue, no conv):
+// the 32-row blocks of dY[:, 128] and X[:, 128] go HBM -> LDS by global_load_lds_dwordx4 into a ring of
+// NS stage buffers, NS-1 blocks ahead of the MFMAs, with no registers and no commit pass in between.
+// The register-staged kernel above keeps at most one block in flight per workgroup and only while its
+// MFMAs run - measured 1.4 TB/s on cold operands; the ring keeps (NS-1) x 16 KB in flight per workgroup
+// all the time.  LDS rows are 256 B, unpadded (a DMA instruction writes 1 KiB = 4 rows linearly); bank
+// conflicts of the transposing reads are avoided by an XOR swizzle of the 16-byte chunk index applied to
+// the *source* address: LDS chunk c of row r holds global chunk c ^ (swz(r) << 1).
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ int wg_swz(int r) { return ((r & 3) | (((r >> 3) & 1) << 2)) << 1; }
+
+template <int NS>
+__global__ __launch_bounds__(256) void pw_wgrad128_dma_kernel(WgArgs a) {
+  typedef bf16_t T;
+  constexpr int TT = 128;
+  constexpr int SLAB = 32 * TT * 2;                  // 8 KB: one operand, one stage
+  extern __shared__ __attribute__((aligned(1024))) unsigned char dsmem[];     // [NS][dY | X]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave & 1, wk = wave >> 1;
+  const int tiles = a.n_tiles * a.k_tiles;
+  const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+  const int tile = jj % tiles, srange = (jj / tiles) * 8 + xcd;
+  if (srange >= a.split) return;
+  const int nt = tile % a.n_tiles, kt = tile / a.n_tiles;
+  const int n0 = nt * TT, k0 = kt * TT;
+  int64_t mbeg, mend;
+  int clip = 0;
+  if (a.ranges_per_group > 0) {
+    clip = srange / a.ranges_per_group;
+    const int sub = srange - clip * a.ranges_per_group;
+    mbeg = (int64_t)clip * a.rows_per_group + (int64_t)sub * a.rows_per_wg;
+    mend = min((int64_t)(clip + 1) * a.rows_per_group, mbeg + a.rows_per_wg);
+  } else {
+    mbeg = (int64_t)srange * a.rows_per_wg;
+    mend = min(a.M, mbeg + a.rows_per_wg);
+  }
+  if (mbeg >= mend) return;                          // uniform
+  const T* dY = (const T*)a.dY;
+  const T* X = (const T*)a.X;
+  typedef __attribute__((address_space(3))) unsigned char* lds_b;
+  const unsigned lds0 = (unsigned)(uintptr_t)(lds_b)dsmem;
+
+  // this thread's two chunks per operand and stage: f = i*256 + tid -> row f>>4, LDS chunk f&15
+  int rr[2], ncol[2], kcol[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int f = i * 256 + tid;
+    rr[i] = f >> 4;
+    const int cs = (f & 15) ^ wg_swz(rr[i]);
+    ncol[i] = n0 + cs * 8 < a.N ? n0 + cs * 8 : n0;          // columns past the edge: any valid address,
+    kcol[i] = k0 + cs * 8 < a.K ? k0 + cs * 8 : k0;          // they only feed outputs that are never stored
+  }
+  const unsigned wave_off = (unsigned)__builtin_amdgcn_readfirstlane(wave * 1024);
+  auto issue = [&](int64_t mb, int buf) {
+    const unsigned base = lds0 + (unsigned)buf * (2 * SLAB) + wave_off;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int64_t m = min(mb + rr[i], mend - 1);           // rows past the range re-read the last row; zeroed below
+      glds16(dY + m * a.N + ncol[i], base + i * 4096);
+      glds16(X + m * a.K + kcol[i], base + SLAB + i * 4096);
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nsteps = (int)((mend - mbeg + 31) >> 5);
+#pragma unroll
+  for (int s0 = 0; s0 < NS - 1; ++s0)
+    if (s0 < nsteps) issue(mbeg + 32 * s0, s0);
+
+  // transposing-read lane constants (see pw_wgrad128_kernel for the fragment layout)
+  const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+  const int sw = (q | (g << 2)) << 1;
+  const int row_off = (8 * g + q) * 256 + (pp & 1) * 8;
+  int a_off[4], b_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    a_off[i] = row_off + (((wn * 8 + i * 2 + (pp >> 1)) ^ sw) << 4);
+    b_off[i] = row_off + (((wk * 8 + i * 2 + (pp >> 1)) ^ sw) << 4) + SLAB;
+  }
+
+  int buf = 0;
+  for (int s = 0; s < nsteps; ++s) {
+    // retire this wave's DMAs of stage s; later stages stay in flight
+    const int later = min(nsteps - 1 - s, NS - 2);
+    if (later >= 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (later == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (later == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int64_t mb = mbeg + 32 * (int64_t)s;
+    unsigned char* Ds = dsmem + buf * (2 * SLAB);
+    if (mb + 32 > mend) {                            // ragged last block: rows past the range contribute zero
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        if (mb + rr[i] >= mend) {
+          *reinterpret_cast<u32x4*>(Ds + (i * 256 + tid) * 16) = u32x4{0u, 0u, 0u, 0u};
+          *reinterpret_cast<u32x4*>(Ds + SLAB + (i * 256 + tid) * 16) = u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+    lds_barrier();       // all waves' stage-s data has landed; all waves are done reading stage s-1
+    if (s + NS - 1 < nsteps) {
+      int nb = buf + NS - 1;
+      if (nb >= NS) nb -= NS;
+      issue(mb + 32 * (NS - 1), nb);
+    }
+    {
+      typedef __attribute__((address_space(3))) bf16x4* lds_p;
+      bf16x8 fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(Ds + a_off[i]));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(Ds + a_off[i] + 4 * 256));
+        fa[i] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(Ds + b_off[j]));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(Ds + b_off[j] + 4 * 256));
+        fb[j] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    if (++buf == NS) buf = 0;
+  }
+  float sk[4] = {1.f, 1.f, 1.f, 1.f};
+  if (a.ranges_per_group > 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = k0 + wk * 64 + j * 16 + (lane & 15);
+      if (k < a.K) sk[j] = a.row_scale[(int64_t)clip * a.K + k];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + wn * 64 + i * 16 + (lane >> 4) * 4 + r;
+        const int k = k0 + wk * 64 + j * 16 + (lane & 15);
+        if (n < a.N && k < a.K) atomicAdd(a.dW + (int64_t)n * a.K + k, acc[i][j][r] * sk[j]);
+      }
+}
+
 int pick_nt(int N, bool f32) {
   // cost = padded MFMA width + 16 per column tile (each extra tile re-reads the X panel through L2)
   const int cand[5] = {2, 4, 6, 8, 12};
@@ -854,6 +1159,61 @@ extern "C" int pb_pwconv_bwd_weight(const void* dy, const void* x, float* dw, in
   a.dY = dy; a.X = x; a.dW = dw; a.M = M; a.K = K; a.N = N;
   a.in_scale = in_scale; a.in_shift = in_shift; a.in_act = (int)in_act; a.in_slope = in_slope;
   a.row_scale = row_scale; a.rows_per_group = rows_per_group > 0 ? rows_per_group : 1;
+  const bool big = dtype == PB_BF16 && (N > 64 || K > 64) && (N % 8) == 0 && (K % 8) == 0;
+  if (big) {
+    a.n_tiles = (int)pb_cdiv(N, 128);
+    a.k_tiles = (int)pb_cdiv(K, 128);
+    const int64_t tiles128 = (int64_t)a.n_tiles * a.k_tiles;
+    // One round of co-resident workgroups (a second, nearly empty round would double the time).  Every
+    // workgroup is also one atomic writer per element of its dW tile and same-address float atomics
+    // serialise (~25 ns each), so layers with few tiles get fewer, deeper workgroups: 1 per CU with a
+    // 6-stage ring (80 KB in flight) instead of 3 per CU with 3 stages.
+    static int cus = 0;
+    if (cus == 0 && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) cus = 256;
+    static const int force_ns = getenv("PB_WGRAD_NS") ? atoi(getenv("PB_WGRAD_NS")) : 0;
+    static const int small_tiles = getenv("PB_WGRAD_SMALL_TILES") ? atoi(getenv("PB_WGRAD_SMALL_TILES")) : 4;
+    static const int small_ns = getenv("PB_WGRAD_SMALL_NS") ? atoi(getenv("PB_WGRAD_SMALL_NS")) : 6;
+    int ns = force_ns ? force_ns : (tiles128 <= small_tiles ? small_ns : 3);
+    if (ns != 3 && ns != 4 && ns != 6) ns = 3;
+    const int per_cu = ns == 3 ? 3 : (ns == 4 ? 2 : 1);        // 48 / 64 / 96 KB of LDS per workgroup
+    const int64_t target_wgs = (int64_t)per_cu * cus;
+    int64_t split = target_wgs / tiles128;
+    const int64_t max_split128 = pb_cdiv(M, 256);
+    if (split > max_split128) split = max_split128;
+    if (split < 1) split = 1;
+    a.rows_per_wg = pb_cdiv(pb_cdiv(M, split), 32) * 32;
+    split = pb_cdiv(M, a.rows_per_wg);
+    a.ranges_per_group = 0;
+    const bool se_only = row_scale && !in_scale && !in_shift && in_act == PB_ACT_NONE;
+    if (se_only && rows_per_group >= 64 && M % rows_per_group == 0) {
+      // clip-aligned ranges (the squeeze-excite scale then applies to the accumulators): at most the
+      // same number of workgroups, none straddling two clips
+      const int64_t clips = M / rows_per_group;
+      int64_t rpc = split / clips;
+      if (rpc < 1) rpc = 1;
+      a.rows_per_wg = pb_cdiv(pb_cdiv(rows_per_group, rpc), 32) * 32;
+      rpc = pb_cdiv(rows_per_group, a.rows_per_wg);
+      a.ranges_per_group = (int)rpc;
+      split = clips * rpc;
+    }
+    a.split = (int)split;
+    const bool in_loop_prologue = a.ranges_per_group == 0 && (row_scale || in_scale || in_shift || in_act != PB_ACT_NONE);
+    const dim3 grid((unsigned)(tiles128 * 8 * pb_cdiv(split, 8)));
+    if (!in_loop_prologue) {
+      static bool attr_done = false;
+      if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)pw_wgrad128_dma_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 16384);
+        attr_done = true;
+      }
+      if (ns == 6) hipLaunchKernelGGL((pw_wgrad128_dma_kernel<6>), grid, dim3(256), 6 * 16384, (hipStream_t)stream, a);
+      else if (ns == 4) hipLaunchKernelGGL((pw_wgrad128_dma_kernel<4>), grid, dim3(256), 4 * 16384, (hipStream_t)stream, a);
+      else hipLaunchKernelGGL((pw_wgrad128_dma_kernel<3>), grid, dim3(256), 3 * 16384, (hipStream_t)stream, a);
+    } else {
+      hipLaunchKernelGGL((pw_wgrad128_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    }
+    PB_LAUNCH_CHECK();
+    return 0;
+  }
   const int tile = dtype == PB_BF16 ? 64 : 32;
   a.n_tiles = (int)pb_cdiv(N, tile);
   a.k_tiles = (int)pb_cdiv(K, tile);
@@ -1012,10 +1372,21 @@ extern "C" int pb_conv3d_bwd_weight(const void* dy, const void* x, float* dwp, c
   msplit = pb_cdiv(a.M, a.rows_per_wg);
   PB_CHECK_ARG(taps <= 65535 && msplit <= 65535, "pb_conv3d_bwd_weight: grid too large");
   dim3 grid((unsigned)tiles, (unsigned)msplit, (unsigned)taps), block(256);
-  if (dtype == PB_BF16)
-    hipLaunchKernelGGL((pw_wgrad_kernel<bf16_t, 4, 4, true>), grid, block, 0, (hipStream_t)stream, a);
-  else
+  if (dtype == PB_BF16) {
+    a.n_tiles = (int)pb_cdiv(a.N, 128);
+    a.k_tiles = (int)pb_cdiv(a.K, 128);
+    const int64_t t128 = (int64_t)a.n_tiles * a.k_tiles;
+    int64_t split = pb_cdiv(2048, t128 * taps);
+    if (split > pb_cdiv(a.M, 256)) split = pb_cdiv(a.M, 256);
+    if (split < 1) split = 1;
+    a.rows_per_wg = pb_cdiv(pb_cdiv(a.M, split), 32) * 32;
+    split = pb_cdiv(a.M, a.rows_per_wg);
+    a.split = (int)split;
+    hipLaunchKernelGGL((pw_wgrad128_kernel<true>), dim3((unsigned)(t128 * 8 * pb_cdiv(split, 8)), 1, (unsigned)taps),
+                       block, 0, (hipStream_t)stream, a);
+  } else {
     hipLaunchKernelGGL((pw_wgrad_kernel<float, 2, 2, true>), grid, block, 0, (hipStream_t)stream, a);
+  }
   PB_LAUNCH_CHECK();
   return 0;
 }

@@ -115,7 +115,7 @@ def pw_fwd(x, w, *, w_transposed=False, in_scale=None, in_shift=None, in_act="no
         _f32(row_scale, (M // rows_per_group, K), "row_scale")
     y = torch.empty((M, N), dtype=x.dtype, device=x.device)
     dev, st = _dev_stream(x)
-    family = "pw_gemm_bwd_data" if w_transposed else "pw_gemm_fwd"
+    family = "pw_gemm_kernel"
     if w_transposed and N * K >= 4096:
         # backward-data reads W transposed; staging a transposed tile costs scattered 2-byte LDS writes in
         # every workgroup and K stage (2x on the wide layers), transposing the (<= 0.6 MB) matrix once is ~free
@@ -143,12 +143,19 @@ def pw_bwd_weight(dy, x, dw, *, in_scale=None, in_shift=None, in_act="none", in_
             raise ValueError("pw_bwd_weight: rows_per_group must divide M")
         _f32(row_scale, (M // rows_per_group, K), "row_scale")
     dev, st = _dev_stream(x)
-    _launch("pw_wgrad", _nb(dy, x, dw), "pb_pwconv_bwd_weight", _p(dy), _p(x), _p(dw), M, K, N, _dt(x), _p(in_scale), _p(in_shift),
+    _launch("pw_wgrad_kernel", _nb(dy, x, dw), "pb_pwconv_bwd_weight", _p(dy), _p(x), _p(dw), M, K, N, _dt(x), _p(in_scale), _p(in_shift),
             ACT[in_act], float(in_slope), _p(row_scale), int(rows_per_group), dev, st, detail=f"M{M} K{K} N{N}")
     return dw
 
 
 # ------------------------------------------------------------------------------ depthwise conv
+def _dw_kernel_name(which, s, dt):
+    """HIP kernel pb_dwconv3d_* will dispatch to (profiling labels only); which: 0 fwd, 1 bwd-data, 2 bwd-weight."""
+    if _spans is None:
+        return "dw"
+    return _C.load().pb_dwconv3d_kernel_name(ctypes.byref(s), dt, which).decode()
+
+
 def dw_out_shape(in_thw, kernel, stride, pad_front, pad_back=None):
     pad_back = pad_front if pad_back is None else pad_back
     return tuple((i + pf + pb - k) // s + 1 for i, k, s, pf, pb in zip(in_thw, kernel, stride, pad_front, pad_back))
@@ -184,7 +191,7 @@ def dw_fwd(x, w, kernel, stride, pad_front, pad_back=None, pool=None):
     y = torch.empty((N,) + out + (C,), dtype=x.dtype, device=x.device)
     s = _dw_shape(N, C, (T, H, W), out, kernel, stride, pad_front)
     dev, st = _dev_stream(x)
-    _launch("dw_fwd", _nb(x, y, w), "pb_dwconv3d_fwd", _p(x), _p(w), _p(y), ctypes.byref(s), _dt(x), _p(pool), dev, st,
+    _launch(_dw_kernel_name(0, s, _dt(x)), _nb(x, y, w), "pb_dwconv3d_fwd", _p(x), _p(w), _p(y), ctypes.byref(s), _dt(x), _p(pool), dev, st,
             detail=f"C{C} {T}x{H}x{W}->{out[0]}x{out[1]}x{out[2]} k{kernel} s{stride}")
     return y
 
@@ -197,7 +204,7 @@ def dw_bwd_data(dy, w, in_thw, kernel, stride, pad_front, g_scale=None, g_shift=
     dx = torch.empty((N,) + tuple(in_thw) + (C,), dtype=dy.dtype, device=dy.device)
     s = _dw_shape(N, C, in_thw, (To, Ho, Wo), kernel, stride, pad_front)
     dev, st = _dev_stream(dy)
-    _launch("dw_bwd_data", _nb(dy, dx, w), "pb_dwconv3d_bwd_data", _p(dy), _p(w), _p(dx), ctypes.byref(s), _dt(dy), _p(g_scale), _p(g_shift), dev, st,
+    _launch(_dw_kernel_name(1, s, _dt(dy)), _nb(dy, dx, w), "pb_dwconv3d_bwd_data", _p(dy), _p(w), _p(dx), ctypes.byref(s), _dt(dy), _p(g_scale), _p(g_shift), dev, st,
             detail=f"C{C} {To}x{Ho}x{Wo}->{tuple(in_thw)} k{kernel} s{stride}")
     return dx
 
@@ -211,7 +218,7 @@ def dw_bwd_weight(dy, x, dw, kernel, stride, pad_front, g_scale=None, g_shift=No
     _f32(g_scale, (N, C), "g_scale"); _f32(g_shift, (N, C), "g_shift")
     s = _dw_shape(N, C, tuple(x.shape[1:4]), (To, Ho, Wo), kernel, stride, pad_front)
     dev, st = _dev_stream(dy)
-    _launch("dw_bwd_weight", _nb(dy, x, dw), "pb_dwconv3d_bwd_weight", _p(dy), _p(x), _p(dw), ctypes.byref(s), _dt(dy), _p(g_scale), _p(g_shift), dev, st,
+    _launch(_dw_kernel_name(2, s, _dt(dy)), _nb(dy, x, dw), "pb_dwconv3d_bwd_weight", _p(dy), _p(x), _p(dw), ctypes.byref(s), _dt(dy), _p(g_scale), _p(g_shift), dev, st,
             detail=f"C{C} {tuple(x.shape[1:4])}->{To}x{Ho}x{Wo} k{kernel} s{stride}")
     return dw
 
@@ -243,7 +250,7 @@ def stem_fwd(x, w, bias, kernel, stride, pad, out_dtype, x_scale=1.0, stats=None
     y = torch.empty((x.shape[0],) + out + (cout,), dtype=out_dtype, device=x.device)
     s = _stem_shape(x, cout, out, kernel, stride, pad)
     dev, st = _dev_stream(x)
-    _launch("stem_fwd", _nb(x, y, w), "pb_stem_conv3d_fwd", _p(x), _XDT[x.dtype], float(x_scale), _p(w), _p(bias), _p(y), ctypes.byref(s),
+    _launch("stem_fwd_mfma_kernel", _nb(x, y, w), "pb_stem_conv3d_fwd", _p(x), _XDT[x.dtype], float(x_scale), _p(w), _p(bias), _p(y), ctypes.byref(s),
             _dt(y), _p(stats), dev, st)
     return y
 
@@ -254,7 +261,7 @@ def stem_bwd_weight(dy, x, dw, dbias, kernel, stride, pad, x_scale=1.0):
     _f32(dw, (cout, x.shape[1], *kernel), "dw"); _f32(dbias, (cout,), "dbias")
     s = _stem_shape(x, cout, tuple(dy.shape[1:4]), kernel, stride, pad)
     dev, st = _dev_stream(dy)
-    _launch("stem_wgrad", _nb(dy, x, dw), "pb_stem_conv3d_bwd_weight", _p(dy), _p(x), _XDT[x.dtype], float(x_scale), _p(dw), _p(dbias),
+    _launch("stem_wgrad_kernel", _nb(dy, x, dw), "pb_stem_conv3d_bwd_weight", _p(dy), _p(x), _XDT[x.dtype], float(x_scale), _p(dw), _p(dbias),
             ctypes.byref(s), _dt(dy), dev, st)
     return dw
 
@@ -264,7 +271,7 @@ def chan_stats(x, stats):
     _rows(x, "x")
     _f32(stats, (REPL, 2, x.shape[1]), "stats")
     dev, st = _dev_stream(x)
-    _launch("chan_stats", _nb(x), "pb_chan_stats", _p(x), x.shape[0], x.shape[1], _dt(x), _p(stats), dev, st)
+    _launch("ew_kernel<stats>", _nb(x), "pb_chan_stats", _p(x), x.shape[0], x.shape[1], _dt(x), _p(stats), dev, st)
     return stats
 
 
@@ -294,7 +301,7 @@ def affine_act_fwd(x, scale=None, shift=None, act="none", slope=0.0, row_scale=N
         _f32(row_shift, (M // rows_per_group, C), "row_shift")
     y = torch.empty_like(x)
     dev, st = _dev_stream(x)
-    _launch("affine_act_fwd", _nb(x, y), "pb_affine_act_fwd", _p(x), _p(y), M, C, _dt(x), _p(scale), _p(shift), _p(mean), ACT[act], float(slope),
+    _launch("ew_kernel<affine_act>", _nb(x, y), "pb_affine_act_fwd", _p(x), _p(y), M, C, _dt(x), _p(scale), _p(shift), _p(mean), ACT[act], float(slope),
             _p(row_scale), _p(row_shift), int(rows_per_group), _p(stats), dev, st)
     return y
 
@@ -320,7 +327,7 @@ def act_bwd_reduce(dy, z, *, scale=None, shift=None, act="none", slope=0.0, row_
         _f32(row_scale, (M // rows_per_group, C), "row_scale")
     g = torch.empty_like(z) if want_g else None
     dev, st = _dev_stream(z)
-    _launch("act_bwd_reduce", _nb(dy, z, g), "pb_act_bwd_reduce", _p(dy), _p(z), _p(g), M, C, _dt(z), _p(scale), _p(shift), ACT[act], float(slope),
+    _launch("ew_kernel<act_bwd>", _nb(dy, z, g), "pb_act_bwd_reduce", _p(dy), _p(z), _p(g), M, C, _dt(z), _p(scale), _p(shift), ACT[act], float(slope),
             _p(row_scale), int(rows_per_group), int(dy_rows_per_group), float(dy_mul), _p(mean), _p(rstd), _p(sums),
             dev, st)
     return g
@@ -348,7 +355,7 @@ def affine2(g, z, A, B=None, Cc=None, mean=None):
     _f32(A, (C,), "A"); _f32(B, (C,), "B"); _f32(Cc, (C,), "Cc"); _f32(mean, (C,), "mean")
     out = torch.empty_like(g)
     dev, st = _dev_stream(g)
-    _launch("affine2", _nb(g, z, out), "pb_affine2", _p(g), _p(z), _p(out), M, C, _dt(g), _p(A), _p(B), _p(Cc), _p(mean), dev, st)
+    _launch("ew_kernel<affine2>", _nb(g, z, out), "pb_affine2", _p(g), _p(z), _p(out), M, C, _dt(g), _p(A), _p(B), _p(Cc), _p(mean), dev, st)
     return out
 
 
@@ -364,7 +371,7 @@ def rowgroup_reduce(a, b, G):
             raise ValueError("rowgroup_reduce: a/b mismatch")
     out = torch.zeros((G, C), dtype=torch.float32, device=a.device)
     dev, st = _dev_stream(a)
-    _launch("rowgroup_reduce", _nb(a, b, out), "pb_rowgroup_reduce", _p(a), _p(b), _p(out), G, M // G, C, _dt(a), dev, st)
+    _launch("rowgroup_kernel", _nb(a, b, out), "pb_rowgroup_reduce", _p(a), _p(b), _p(out), G, M // G, C, _dt(a), dev, st)
     return out
 
 
@@ -438,7 +445,7 @@ def conv3d_fwd(x, wp, cout, kernel, stride, pad_front, out_thw, *, out_scale=Non
     y = torch.empty((N,) + tuple(out_thw) + (cout,), dtype=x.dtype, device=x.device)
     s = _conv_shape(N, cin, cout, (T, H, W), out_thw, kernel, stride, pad_front)
     dev, st = _dev_stream(x)
-    _launch("conv3d_fwd", _nb(x, y, wp), "pb_conv3d_fwd", _p(x), _p(wp), _p(y), ctypes.byref(s), _dt(x), _p(out_scale),
+    _launch("pw_gemm_kernel<conv>", _nb(x, y, wp), "pb_conv3d_fwd", _p(x), _p(wp), _p(y), ctypes.byref(s), _dt(x), _p(out_scale),
             _p(out_shift), ACT[out_act], float(out_slope), _p(stats), dev, st,
             detail=f"Cin{cin} Cout{cout} {T}x{H}x{W} k{kernel} s{stride}")
     return y
@@ -455,7 +462,7 @@ def conv3d_bwd_weight(dy, x, kernel, stride, pad_front):
     dwp = torch.zeros(cout * taps * cin, dtype=torch.float32, device=x.device)
     s = _conv_shape(N, cin, cout, tuple(x.shape[1:4]), (To, Ho, Wo), kernel, stride, pad_front)
     dev, st = _dev_stream(x)
-    _launch("conv3d_wgrad", _nb(dy, x, dwp), "pb_conv3d_bwd_weight", _p(dy), _p(x), _p(dwp), ctypes.byref(s), _dt(x), dev, st,
+    _launch("pw_wgrad_kernel<conv>", _nb(dy, x, dwp), "pb_conv3d_bwd_weight", _p(dy), _p(x), _p(dwp), ctypes.byref(s), _dt(x), dev, st,
             detail=f"Cin{cin} Cout{cout} {tuple(x.shape[1:4])} k{kernel}")
     return dwp
 

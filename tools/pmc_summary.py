@@ -1,0 +1,55 @@
+"""Summarise rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE, separate runs of the same bench command)
+into per-kernel HBM traffic per launch:
+
+    python tools/pmc_summary.py gpurun_out/pmc/fetch_counter_collection.csv gpurun_out/pmc/write_counter_collection.csv \
+        profiles/r01_pmc_traffic.json
+
+Units/corrections exactly as MI355X_MICROARCH.md "HBM" prescribes: FETCH_SIZE and WRITE_SIZE are in KB;
+on gfx950 FETCH_SIZE reports half of the bytes of wide (16 B/lane) streaming reads, so reads = 2 x FETCH_SIZE;
+WRITE_SIZE is exact for 16 B/lane stores and float atomics.  Kernel template instantiations are merged by
+base name (the launch mix of the bench is fixed, so per-launch averages are comparable run to run)."""
+import collections
+import csv
+import json
+import re
+import sys
+
+
+def base_name(n):
+    n = re.sub(r"\(anonymous namespace\)::", "", n)
+    m = re.match(r"_ZN12_GLOBAL__N_1\d+([a-z0-9_]+?_kernel)I", n)
+    if m:
+        return m.group(1)
+    m = re.match(r"(?:void )?([A-Za-z0-9_:]+)", n)
+    return m.group(1) if m else n
+
+
+def agg(path):
+    d = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(path)):
+        k = base_name(r["Kernel_Name"])
+        d[k][0] += 1
+        d[k][1] += float(r["Counter_Value"])
+    return d
+
+
+def main():
+    fetch, write, out = sys.argv[1:4]
+    fa, wa = agg(fetch), agg(write)
+    res = {}
+    for k in fa:
+        n = fa[k][0]
+        rd = 2.0 * fa[k][1] / n * 1024.0
+        wr = (wa[k][1] / wa[k][0] * 1024.0) if k in wa and wa[k][0] else 0.0
+        res[k] = {"launches": n, "read_bytes_per_launch": round(rd), "write_bytes_per_launch": round(wr),
+                  "hbm_bytes_per_launch": round(rd + wr)}
+    meta = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of bench.py --steps 3 --warmup 1",
+            "correction": "reads = 2 x FETCH_SIZE (gfx950 wide-read undercount), KB -> bytes"}
+    json.dump({"meta": meta, "kernels": dict(sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"]))},
+              open(out, "w"), indent=1)
+    for k, v in list(json.load(open(out))["kernels"].items())[:14]:
+        print("%-28s n=%4d  read %8.1f MB  write %8.1f MB per launch" % (k, v["launches"], v["read_bytes_per_launch"] / 1e6, v["write_bytes_per_launch"] / 1e6))
+
+
+if __name__ == "__main__":
+    main()
