@@ -14,6 +14,11 @@ import torch.nn.functional as F
 REPL = 16   # PB_STAT_REPLICAS: stats buffers are [REPL, 2, C]; the mirror adds into replica 0
 
 
+def zeros(shape, device):
+    """Mirror of kernels.zeros (the product carves these from a pre-zeroed arena)."""
+    return torch.zeros(shape, dtype=torch.float32, device=device)
+
+
 def _act(x, act, slope=0.0):
     if act == "none":
         return x

@@ -883,6 +883,75 @@ __global__ __launch_bounds__(256) void pw_wgrad128_kernel(WgArgs a) {
       }
 }
 
+// Skinny GEMM for M <= 64 rows (the classifier head on pooled features: 32 x 960 x 1280, 32 x 1280 x 13 and
+// their backward-data): the tiled kernel would run it on 1-10 workgroups.  A workgroup owns 4 output
+// columns and a block of 32 rows; its 4 waves split K, lanes stride over k, every lane keeps the 32 x 4
+// partial sums of its k subset in registers (weights read exactly once from HBM, X rows from L2, 32
+// independent loads in flight per step); one butterfly reduction per output at the end.  No MFMA: 40 MFLOP.
+template <typename T>
+__global__ __launch_bounds__(256) void pw_skinny_kernel(PwArgs a) {
+  constexpr int RB = 32;
+  __shared__ float part[4][RB][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n0 = blockIdx.x * 4;
+  const int m0 = blockIdx.y * RB;
+  const int rows = min(RB, (int)a.M - m0);
+  const T* X = (const T*)a.X + (int64_t)m0 * a.K;
+  T* Y = (T*)a.Y;
+  const int kq = ((a.K + 255) >> 8) << 6;            // K range of one wave, a multiple of 64
+  const int kbeg = wave * kq, kend = min(a.K, kbeg + kq);
+  float d[RB][4];
+#pragma unroll
+  for (int m = 0; m < RB; ++m)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) d[m][c] = 0.f;
+  const bool wvec = a.w_transposed && n0 + 3 < a.N && (a.ldw & 3) == 0;
+  for (int k = kbeg + lane; k < kend; k += 64) {
+    float w4[4];
+    if (wvec) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(a.W + (int64_t)k * a.ldw + n0);
+      w4[0] = t[0]; w4[1] = t[1]; w4[2] = t[2]; w4[3] = t[3];
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        w4[c] = n0 + c < a.N ? (a.w_transposed ? a.W[(int64_t)k * a.ldw + n0 + c] : a.W[(int64_t)(n0 + c) * a.ldw + k]) : 0.f;
+    }
+    float xv[RB];
+#pragma unroll
+    for (int m = 0; m < RB; ++m) xv[m] = m < rows ? to_f32(X[(int64_t)m * a.K + k]) : 0.f;
+#pragma unroll
+    for (int m = 0; m < RB; ++m)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) d[m][c] += xv[m] * w4[c];
+  }
+  // lane m ends up with row m's four sums of this wave's K range
+  float mine[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int m = 0; m < RB; ++m)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float v = wave_sum(d[m][c]);
+      if (lane == m) mine[c] = v;
+    }
+  if (lane < RB) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) part[wave][lane][c] = mine[c];
+  }
+  __syncthreads();
+  if (wave == 0 && lane < rows) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (n0 + c < a.N) {
+        float v = (part[0][lane][c] + part[1][lane][c]) + (part[2][lane][c] + part[3][lane][c]);
+        const float sc = a.out_scale ? a.out_scale[n0 + c] : 1.f;
+        const float sh = a.out_shift ? a.out_shift[n0 + c] : 0.f;
+        v = act_fwd(v * sc + sh, a.out_act, a.out_slope);
+        Y[(int64_t)(m0 + lane) * a.N + n0 + c] = from_f32<T>(v);
+      }
+    }
+  }
+}
+
 // LDS-DMA variant of the 128 x 128 weight-gradient tile (plain streams: no affine prologue, no conv):
 // the 32-row blocks of dY[:, 128] and X[:, 128] go HBM -> LDS by global_load_lds_dwordx4 into a ring of
 // NS stage buffers, NS-1 blocks ahead of the MFMAs, with no registers and no commit pass in between.
@@ -891,10 +960,14 @@ __global__ __launch_bounds__(256) void pw_wgrad128_kernel(WgArgs a) {
 // all the time.  LDS rows are 256 B, unpadded (a DMA instruction writes 1 KiB = 4 rows linearly); bank
 // conflicts of the transposing reads are avoided by an XOR swizzle of the 16-byte chunk index applied to
 // the *source* address: LDS chunk c of row r holds global chunk c ^ (swz(r) << 1).
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+// One LDS-DMA instruction: 16 bytes per lane from each lane's own global address to LDS at
+// (wave-uniform) lds_dst + lane * 16 (layout confirmed on MI355X by tools/probes/glds_probe.hip).  The
+// builtin lets the compiler manage M0; completion is NOT tracked by the compiler - wait with a counted
+// vmcnt, then a barrier, before any ds_read of the destination.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned char* lds_dst) {
+  typedef __attribute__((address_space(3))) unsigned char* lds_b;
+  typedef const __attribute__((address_space(1))) unsigned char* glb_b;
+  __builtin_amdgcn_global_load_lds((glb_b)gsrc, (lds_b)lds_dst, 16, 0, 0);
 }
 __device__ __forceinline__ int wg_swz(int r) { return ((r & 3) | (((r >> 3) & 1) << 2)) << 1; }
 
@@ -926,8 +999,6 @@ __global__ __launch_bounds__(256) void pw_wgrad128_dma_kernel(WgArgs a) {
   if (mbeg >= mend) return;                          // uniform
   const T* dY = (const T*)a.dY;
   const T* X = (const T*)a.X;
-  typedef __attribute__((address_space(3))) unsigned char* lds_b;
-  const unsigned lds0 = (unsigned)(uintptr_t)(lds_b)dsmem;
 
   // this thread's two chunks per operand and stage: f = i*256 + tid -> row f>>4, LDS chunk f&15
   int rr[2], ncol[2], kcol[2];
@@ -939,9 +1010,9 @@ __global__ __launch_bounds__(256) void pw_wgrad128_dma_kernel(WgArgs a) {
     ncol[i] = n0 + cs * 8 < a.N ? n0 + cs * 8 : n0;          // columns past the edge: any valid address,
     kcol[i] = k0 + cs * 8 < a.K ? k0 + cs * 8 : k0;          // they only feed outputs that are never stored
   }
-  const unsigned wave_off = (unsigned)__builtin_amdgcn_readfirstlane(wave * 1024);
+  const int wave_off = __builtin_amdgcn_readfirstlane(wave * 1024);
   auto issue = [&](int64_t mb, int buf) {
-    const unsigned base = lds0 + (unsigned)buf * (2 * SLAB) + wave_off;
+    unsigned char* base = dsmem + buf * (2 * SLAB) + wave_off;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int64_t m = min(mb + rr[i], mend - 1);           // rows past the range re-read the last row; zeroed below
@@ -963,7 +1034,7 @@ __global__ __launch_bounds__(256) void pw_wgrad128_dma_kernel(WgArgs a) {
 
   // transposing-read lane constants (see pw_wgrad128_kernel for the fragment layout)
   const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
-  const int sw = (q | (g << 2)) << 1;
+  const int sw = wg_swz(8 * g + q);                  // = swizzle of rows 8g+q and 8g+4+q alike
   const int row_off = (8 * g + q) * 256 + (pp & 1) * 8;
   int a_off[4], b_off[4];
 #pragma unroll
@@ -1138,6 +1209,14 @@ extern "C" int pb_pwconv_fwd(const void* x, const float* w, void* y, int64_t M, 
   a.row_scale = row_scale; a.rows_per_group = rows_per_group > 0 ? rows_per_group : 1;
   a.out_scale = out_scale; a.out_shift = out_shift; a.out_act = (int)out_act; a.out_slope = out_slope;
   a.stats = stats; a.n_tiles = 0; a.m_tiles = 0;
+  static const bool skinny_on = !(getenv("PB_SKINNY") && atoi(getenv("PB_SKINNY")) == 0);
+  if (skinny_on && M <= 64 && !in_scale && !in_shift && in_act == PB_ACT_NONE && !row_scale && !stats) {
+    const dim3 grid((unsigned)pb_cdiv(N, 4), (unsigned)pb_cdiv(M, 32));
+    if (dtype == PB_BF16) hipLaunchKernelGGL(pw_skinny_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(pw_skinny_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    PB_LAUNCH_CHECK();
+    return 0;
+  }
   int rc = dtype == PB_BF16 ? launch_gemm<bf16_t>(a, device, (hipStream_t)stream) : launch_gemm<float>(a, device, (hipStream_t)stream);
   if (rc) return rc;
   PB_LAUNCH_CHECK();
@@ -1199,7 +1278,8 @@ extern "C" int pb_pwconv_bwd_weight(const void* dy, const void* x, float* dw, in
     a.split = (int)split;
     const bool in_loop_prologue = a.ranges_per_group == 0 && (row_scale || in_scale || in_shift || in_act != PB_ACT_NONE);
     const dim3 grid((unsigned)(tiles128 * 8 * pb_cdiv(split, 8)));
-    if (!in_loop_prologue) {
+    static const bool dma_on = !(getenv("PB_WGRAD_DMA") && atoi(getenv("PB_WGRAD_DMA")) == 0);
+    if (!in_loop_prologue && dma_on) {
       static bool attr_done = false;
       if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)pw_wgrad128_dma_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 16384);

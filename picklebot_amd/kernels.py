@@ -5,6 +5,7 @@ hand-written kernel), allocates outputs with torch (plumbing) and launches on th
 stream of the tensor's device.  Activations are 2-D row matrices [M, C] or 5-D NDHWC tensors.
 """
 import ctypes
+import threading
 
 import torch
 
@@ -14,6 +15,47 @@ REPL = _C.STAT_REPLICAS     # stats buffers are [REPL, 2, C] (include/picklebot_
 
 ACT = {"none": _C.ACT_NONE, "relu": _C.ACT_RELU, "leaky_relu": _C.ACT_LEAKY_RELU, "hardswish": _C.ACT_HSWISH,
        "hardsigmoid": _C.ACT_HSIGMOID, "silu": _C.ACT_SILU}
+
+
+# ---- zero-initialised fp32 scratch (statistics, pools, gradient accumulators) -------------------
+class _ZeroArena:
+    """Hands out zero-filled fp32 buffers carved from 16 MB chunks that are zeroed by ONE fill kernel.
+    A training step needs ~90 small zero buffers (BN statistics replicas, SE pools, weight-gradient
+    accumulators for the atomics); as separate torch.zeros calls they were 91 fill launches = 0.44 ms of a
+    13.4 ms step on MI355X.  Every carved range is handed out once (the offset only advances), so it is
+    zero when handed out; a chunk is freed by the allocator when its last view dies."""
+    CHUNK = 16 << 20                 # bytes
+
+    def __init__(self):
+        self._lock = threading.Lock()
+        self._buf = {}               # device -> [flat tensor, offset in elements]
+
+    def take(self, numel, device):
+        n = (int(numel) + 63) // 64 * 64                      # 256-byte granules keep every view 16 B aligned
+        if n * 4 > self.CHUNK // 2:
+            return torch.zeros(int(numel), dtype=torch.float32, device=device)
+        with self._lock:
+            ent = self._buf.get(device)
+            if ent is None or ent[1] + n > ent[0].numel():
+                ent = [torch.zeros(self.CHUNK // 4, dtype=torch.float32, device=device), 0]
+                self._buf[device] = ent
+            off = ent[1]
+            ent[1] = off + n
+            return ent[0][off:off + int(numel)]
+
+
+_arena = _ZeroArena()
+
+
+def zeros(shape, device):
+    """Zero-filled fp32 tensor of `shape` on `device` (from the arena above)."""
+    shape = tuple(shape) if not isinstance(shape, int) else (shape,)
+    n = 1
+    for d in shape:
+        n *= int(d)
+    if torch.device(device).type != "cuda":
+        return torch.zeros(shape, dtype=torch.float32, device=device)
+    return _arena.take(n, torch.device(device)).view(shape)
 
 
 # ---- optional per-launch profiling (bench.py): HIP events recorded on the launch stream -------
@@ -115,8 +157,10 @@ def pw_fwd(x, w, *, w_transposed=False, in_scale=None, in_shift=None, in_act="no
         _f32(row_scale, (M // rows_per_group, K), "row_scale")
     y = torch.empty((M, N), dtype=x.dtype, device=x.device)
     dev, st = _dev_stream(x)
-    family = "pw_gemm_kernel"
-    if w_transposed and N * K >= 4096:
+    skinny = (M <= 64 and in_scale is None and in_shift is None and in_act == "none" and row_scale is None
+              and stats is None)
+    family = "pw_skinny_kernel" if skinny else "pw_gemm_kernel"
+    if w_transposed and N * K >= 4096 and not skinny:     # (the skinny kernel reads W in place)
         # backward-data reads W transposed; staging a transposed tile costs scattered 2-byte LDS writes in
         # every workgroup and K stage (2x on the wide layers), transposing the (<= 0.6 MB) matrix once is ~free
         wt = torch.empty((N, K), dtype=torch.float32, device=w.device)
@@ -143,7 +187,11 @@ def pw_bwd_weight(dy, x, dw, *, in_scale=None, in_shift=None, in_act="none", in_
             raise ValueError("pw_bwd_weight: rows_per_group must divide M")
         _f32(row_scale, (M // rows_per_group, K), "row_scale")
     dev, st = _dev_stream(x)
-    _launch("pw_wgrad_kernel", _nb(dy, x, dw), "pb_pwconv_bwd_weight", _p(dy), _p(x), _p(dw), M, K, N, _dt(x), _p(in_scale), _p(in_shift),
+    big = x.dtype == torch.bfloat16 and (N > 64 or K > 64) and N % 8 == 0 and K % 8 == 0
+    affine = in_scale is not None or in_shift is not None or in_act != "none"
+    se_inloop = row_scale is not None and (rows_per_group < 64 or M % max(rows_per_group, 1))
+    family = "pw_wgrad_kernel" if not big else ("pw_wgrad128_kernel" if (affine or se_inloop) else "pw_wgrad128_dma_kernel")
+    _launch(family, _nb(dy, x, dw), "pb_pwconv_bwd_weight", _p(dy), _p(x), _p(dw), M, K, N, _dt(x), _p(in_scale), _p(in_shift),
             ACT[in_act], float(in_slope), _p(row_scale), int(rows_per_group), dev, st, detail=f"M{M} K{K} N{N}")
     return dw
 
@@ -369,7 +417,7 @@ def rowgroup_reduce(a, b, G):
         _rows(b, "b")
         if b.shape != a.shape or b.dtype != a.dtype:
             raise ValueError("rowgroup_reduce: a/b mismatch")
-    out = torch.zeros((G, C), dtype=torch.float32, device=a.device)
+    out = zeros((G, C), a.device)
     dev, st = _dev_stream(a)
     _launch("rowgroup_kernel", _nb(a, b, out), "pb_rowgroup_reduce", _p(a), _p(b), _p(out), G, M // G, C, _dt(a), dev, st)
     return out
@@ -398,7 +446,7 @@ def se_fc_bwd(dscale, pool, inv_count, scale, hidden, w1, w2, want_bias=True):
         _f32(t, shp, n)
     dev_t = pool.device
     g_shift = torch.empty((G, C), dtype=torch.float32, device=dev_t)
-    flat = torch.zeros(2 * C * Cm + C + Cm, dtype=torch.float32, device=dev_t)
+    flat = zeros(2 * C * Cm + C + Cm, dev_t)
     dw1, dw2 = flat[:C * Cm].view(Cm, C), flat[C * Cm:2 * C * Cm].view(C, Cm)
     db1, db2 = flat[2 * C * Cm:2 * C * Cm + Cm], flat[2 * C * Cm + Cm:]
     work = torch.empty(G * (C + Cm), dtype=torch.float32, device=dev_t)
@@ -459,7 +507,7 @@ def conv3d_bwd_weight(dy, x, kernel, stride, pad_front):
     taps = kernel[0] * kernel[1] * kernel[2]
     if x.shape[0] != N or x.dtype != dy.dtype:
         raise ValueError("conv3d_bwd_weight: dy/x mismatch")
-    dwp = torch.zeros(cout * taps * cin, dtype=torch.float32, device=x.device)
+    dwp = zeros(cout * taps * cin, x.device)
     s = _conv_shape(N, cin, cout, tuple(x.shape[1:4]), (To, Ho, Wo), kernel, stride, pad_front)
     dev, st = _dev_stream(x)
     _launch("pw_wgrad_kernel<conv>", _nb(dy, x, dwp), "pb_conv3d_bwd_weight", _p(dy), _p(x), _p(dwp), ctypes.byref(s), _dt(x), dev, st,

@@ -62,9 +62,33 @@ def channel_dropout_mask(p, training, n, c, device):
     if not training or p <= 0.0:
         return None
     if p >= 1.0:
-        return torch.zeros((n, c), dtype=torch.float32, device=device)
-    keep = torch.full((n, c), 1.0 - p, dtype=torch.float32, device=device)
-    return torch.bernoulli(keep) * (1.0 / (1.0 - p))
+        return PF.K.zeros((n, c), device)
+    return _mask_pool.take(float(p), n * c, torch.device(device)).view(n, c)
+
+
+class _MaskPool:
+    """Dropout3d keep-masks (Bernoulli(1-p) / (1-p)) drawn a million at a time: a training step needs 15
+    masks of n*c <= 5k elements; drawing each one separately cost 3 tiny launches per block."""
+    SIZE = 1 << 20
+
+    def __init__(self):
+        self._pools = {}             # (device, p) -> [flat mask tensor, offset]
+
+    def take(self, p, numel, device):
+        if numel > self.SIZE // 4:
+            keep = torch.full((numel,), 1.0 - p, dtype=torch.float32, device=device)
+            return torch.bernoulli(keep) * (1.0 / (1.0 - p))
+        ent = self._pools.get((device, p))
+        if ent is None or ent[1] + numel > self.SIZE:
+            keep = torch.full((self.SIZE,), 1.0 - p, dtype=torch.float32, device=device)
+            ent = [torch.bernoulli(keep).mul_(1.0 / (1.0 - p)), 0]
+            self._pools[(device, p)] = ent
+        off = ent[1]
+        ent[1] = off + (numel + 3) // 4 * 4          # keep every mask 16-byte aligned
+        return ent[0][off:off + numel]
+
+
+_mask_pool = _MaskPool()
 
 
 def se_params(se_block):

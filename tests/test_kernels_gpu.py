@@ -83,6 +83,37 @@ def test_pw_bwd_weight(K, M, Kd, N, dtype):
     check("pw_bwd_weight", got, want, dtype)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,Kd,N,G", [(48, 16, 384, 0), (32, 128, 16, 0), (96, 128, 128, 0), (40, 72, 24, 0), (200, 16, 384, 0),
+                                      (150, 160, 960, 0), (5000, 24, 72, 4), (3000, 672, 112, 4), (7000, 112, 672, 7),
+                                      (1024, 960, 160, 2), (777, 40, 120, 0)])
+def test_pw_bwd_weight_training_paths(K, M, Kd, N, G, dtype):
+    """What the training step actually launches: no affine prologue (LDS-DMA ring kernel in bf16) and the
+    squeeze-excite scale alone (clip-aligned ranges, scale applied to the accumulators)."""
+    dy, x = rnd((M, N), dtype, 19), rnd((M, Kd), dtype, 20)
+    want = R.pw_bwd_weight(dy, x, torch.zeros(N, Kd))
+    got = K.pw_bwd_weight(dev(dy), dev(x), torch.zeros(N, Kd, device=DEV))
+    check("pw_bwd_weight_plain", got, want, dtype)
+    if G:
+        rs = torch.rand(G, Kd) + 0.5
+        want = R.pw_bwd_weight(dy, x, torch.zeros(N, Kd), row_scale=rs, rows_per_group=M // G)
+        got = K.pw_bwd_weight(dev(dy), dev(x), torch.zeros(N, Kd, device=DEV), row_scale=dev(rs), rows_per_group=M // G)
+        check("pw_bwd_weight_se", got, want, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,Kd,N,trans", [(32, 960, 1280, False), (32, 1280, 13, False), (32, 13, 1280, True), (2, 1280, 960, True),
+                                          (64, 200, 36, False), (7, 2048, 40, True)])
+def test_pw_fwd_skinny(K, M, Kd, N, trans, dtype):
+    """M <= 64 rows: the classifier head (bias + hardswish epilogue, backward-data with W read transposed)."""
+    x = rnd((M, Kd), dtype, 21)
+    w = rnd((Kd, N) if trans else (N, Kd), seed=22, scale=Kd ** -0.5)
+    bias = rnd((N,), seed=23)
+    want = R.pw_fwd(x, w, w_transposed=trans, out_shift=bias, out_act="hardswish")
+    got = K.pw_fwd(dev(x), dev(w), w_transposed=trans, out_shift=dev(bias), out_act="hardswish")
+    check("pw_fwd_skinny", got, want, dtype)
+
+
 DW_CASES = [  # N, C, (T,H,W), kernel, stride, pad
     (2, 16, (3, 14, 14), (1, 3, 3), (1, 1, 1), (1, 1, 1)),
     (2, 64, (4, 13, 13), (1, 3, 3), (2, 2, 2), (1, 1, 1)),
