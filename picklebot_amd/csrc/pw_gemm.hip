@@ -961,13 +961,17 @@ __global__ __launch_bounds__(256) void pw_skinny_kernel(PwArgs a) {
 // conflicts of the transposing reads are avoided by an XOR swizzle of the 16-byte chunk index applied to
 // the *source* address: LDS chunk c of row r holds global chunk c ^ (swz(r) << 1).
 // One LDS-DMA instruction: 16 bytes per lane from each lane's own global address to LDS at
-// (wave-uniform) lds_dst + lane * 16 (layout confirmed on MI355X by tools/probes/glds_probe.hip).  The
-// builtin lets the compiler manage M0; completion is NOT tracked by the compiler - wait with a counted
-// vmcnt, then a barrier, before any ds_read of the destination.
+// (wave-uniform) lds_dst + lane * 16 (layout confirmed on MI355X by tools/probes/glds_probe.hip).
+// Inline asm on purpose: hipcc tracks __builtin_amdgcn_global_load_lds as an LDS write and puts
+// s_waitcnt vmcnt(0) in front of the next ds_read, which drains the whole ring every step (measured:
+// +25 % on the weight-gradient kernel).  Hidden from the compiler, completion is ours to order: a counted
+// vmcnt in the issuing wave, then a barrier, before any ds_read of the destination.
 __device__ __forceinline__ void glds16(const void* gsrc, unsigned char* lds_dst) {
   typedef __attribute__((address_space(3))) unsigned char* lds_b;
-  typedef const __attribute__((address_space(1))) unsigned char* glb_b;
-  __builtin_amdgcn_global_load_lds((glb_b)gsrc, (lds_b)lds_dst, 16, 0, 0);
+  const unsigned dst = (unsigned)(uintptr_t)(lds_b)lds_dst;
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
 }
 __device__ __forceinline__ int wg_swz(int r) { return ((r & 3) | (((r >> 3) & 1) << 2)) << 1; }
 
@@ -1001,14 +1005,20 @@ __global__ __launch_bounds__(256) void pw_wgrad128_dma_kernel(WgArgs a) {
   const T* X = (const T*)a.X;
 
   // this thread's two chunks per operand and stage: f = i*256 + tid -> row f>>4, LDS chunk f&15
+  // Chunks past the edge of dY / X are not loaded at all: their LDS bytes stay stale and only feed
+  // outputs that are never stored (every DMA instruction keeps lanes with a valid chunk, so the per-wave
+  // instruction count that the vmcnt waits rely on does not change).
   int rr[2], ncol[2], kcol[2];
+  bool nok[2], kok[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int f = i * 256 + tid;
     rr[i] = f >> 4;
     const int cs = (f & 15) ^ wg_swz(rr[i]);
-    ncol[i] = n0 + cs * 8 < a.N ? n0 + cs * 8 : n0;          // columns past the edge: any valid address,
-    kcol[i] = k0 + cs * 8 < a.K ? k0 + cs * 8 : k0;          // they only feed outputs that are never stored
+    ncol[i] = n0 + cs * 8;
+    kcol[i] = k0 + cs * 8;
+    nok[i] = ncol[i] < a.N;
+    kok[i] = kcol[i] < a.K;
   }
   const int wave_off = __builtin_amdgcn_readfirstlane(wave * 1024);
   auto issue = [&](int64_t mb, int buf) {
@@ -1016,8 +1026,8 @@ __global__ __launch_bounds__(256) void pw_wgrad128_dma_kernel(WgArgs a) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int64_t m = min(mb + rr[i], mend - 1);           // rows past the range re-read the last row; zeroed below
-      glds16(dY + m * a.N + ncol[i], base + i * 4096);
-      glds16(X + m * a.K + kcol[i], base + SLAB + i * 4096);
+      if (nok[i]) glds16(dY + m * a.N + ncol[i], base + i * 4096);
+      if (kok[i]) glds16(X + m * a.K + kcol[i], base + SLAB + i * 4096);
     }
   };
 
