@@ -34,7 +34,7 @@ typedef enum {
   PB_ACT_HSIGMOID = 4, PB_ACT_SILU = 5
 } pb_act;
 
-#define PB_ABI_VERSION 4
+#define PB_ABI_VERSION 5
 
 /* Per-channel statistics buffers (`stats`, `sums` below) are PB_STAT_REPLICAS replicas of [2][C]
  * fp32, layout [replica][2][C], zero-filled by the caller.  A workgroup adds its partial sums into
@@ -64,6 +64,27 @@ int pb_pwconv_fwd(const void* x, const float* w, void* y, int64_t M, int K, int 
                   const float* row_scale, int64_t rows_per_group,
                   const float* out_scale, const float* out_shift, pb_act out_act, float out_slope,
                   float* stats, int device, void* stream);
+
+/* bf16 weight preparation for pb_pwconv_fwd_bf16w (once per optimiser step and orientation):
+ *   transpose == 0: out[g][n][k] = bf16(w[n][k] * row_scale[g][k])   (row_scale NULL, G = 1: plain convert;
+ *                   with row_scale: the squeeze-excite scale of clip g folded into the weights, so that
+ *                   (X_g * s_g) W^T = X_g (W * s_g)^T and the activation stream is never touched)
+ *   transpose != 0: out[k][n] = bf16(w[n][k])   (backward-data: dX = dY * W is the forward GEMM on W^T)
+ * w is fp32 [N][K] contiguous; the inner dimension of `out` must be a multiple of 8. */
+int pb_pw_weight_prep(const float* w, int N, int K, int transpose, const float* row_scale, int G, void* out_bf16,
+                      int device, void* stream);
+
+/* The same conversion for many weight matrices in ONE launch (a model's forward prepares all of its pointwise
+ * weights, both orientations, at once).  desc: device array of `count` records of four int64:
+ * {fp32 source pointer, bf16 destination pointer, (N << 32) | K, transpose}; no scaling. */
+int pb_pw_weight_prep_batch(const int64_t* desc, int count, int device, void* stream);
+
+/* Y[M,N] = X[M,K] * Wb[g(m)][N,K]^T, bf16, both operands streamed by LDS-DMA rings (pw_gemm_dma.hip); same
+ * epilogue as pb_pwconv_fwd (out_scale/out_shift/act, BN statistics).  Wb from pb_pw_weight_prep:
+ * [groups][N][K]; groups > 1: rows [g*rows_per_group, (g+1)*rows_per_group) use Wb[g].  K, N multiples of 8. */
+int pb_pwconv_fwd_bf16w(const void* x, const void* wb, void* y, int64_t M, int K, int N, int groups,
+                        int64_t rows_per_group, const float* out_scale, const float* out_shift, pb_act out_act,
+                        float out_slope, float* stats, int device, void* stream);
 
 /* Weight gradient  dW[N,K] += sum_m dY[m,n] * P(X)[m,k]   (same prologue P as above; fp32
  * atomics into dw, which the caller zero-fills or holds a running gradient).

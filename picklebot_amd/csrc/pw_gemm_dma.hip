@@ -1,0 +1,465 @@
+// Pointwise GEMM with both operands streamed by LDS-DMA:  Y[M,N] = X[M,K] * Wb[g(m)][N,K]^T  (bf16).
+//
+// pw_gemm.hip's kernel stages X through registers one K stage ahead; with K >= 480 (the projection and
+// the backward-data of the expansion convolutions of the last MobileNet stages) that is a chain of 8-15
+// dependent HBM round trips per tile - measured 0.35-1.0 TB/s.  Here every byte of a stage, the X block
+// AND the weight slice, goes HBM/L2 -> LDS by global_load_lds_dwordx4 into a ring of NS stage buffers,
+// NS-1 stages ahead of the MFMAs, also across tile boundaries (the ring does not drain for the
+// epilogue).  No registers, no commit pass, one barrier per stage.
+//
+// The weights arrive pre-converted to bf16 (pb_pw_weight_prep: once per optimiser step and orientation,
+// it also replaces the per-call transpose of backward-data) and, for the squeeze-excite projection,
+// pre-scaled per clip: Y_n = (X_n * s_n) W^T = X_n (W * s_n)^T, so the SE scale never touches the
+// activation stream.  Row panels are then clip-aligned (a panel never straddles two clips).
+//
+// LDS image of a stage: rows of 64 bf16 = 128 B, unpadded (one DMA instruction writes 1 KiB = 8 rows
+// linearly); ds_read_b128 bank conflicts are avoided by XOR-swizzling the 16-byte chunk index with
+// (row >> 1) & 7 on the SOURCE address.  Chunks past K are not loaded on the X side (stale but finite:
+// the whole ring is zeroed once at kernel start and afterwards only ever holds real data) and are zeroed
+// on the weight side, so they contribute exactly 0.
+#include "pb_common.h"
+#include <stdlib.h>
+
+namespace {
+
+constexpr int BM = 128;
+
+struct DmaArgs {
+  const bf16_t* X;
+  const bf16_t* WB;          // [groups][N][K]
+  bf16_t* Y;
+  int64_t M;
+  int K, N;
+  int64_t w_group_stride;    // N*K, or 0 when there is one weight matrix
+  int64_t rows_per_group;    // > 0: row panels are clip-aligned, panel p -> (clip, sub)
+  int panels_per_group;
+  const float* out_scale;
+  const float* out_shift;
+  int out_act;
+  float out_slope;
+  float* stats;
+  int n_tiles;
+  int m_tiles;
+};
+
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned char* lds_dst) {
+  typedef __attribute__((address_space(3))) unsigned char* lds_b;
+  const unsigned dst = (unsigned)(uintptr_t)(lds_b)lds_dst;
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt();
+#define PB_VMCNT(n) template <> __device__ __forceinline__ void wait_vmcnt<n>() { asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); }
+PB_VMCNT(0) PB_VMCNT(5) PB_VMCNT(6) PB_VMCNT(7) PB_VMCNT(8) PB_VMCNT(10) PB_VMCNT(12) PB_VMCNT(14) PB_VMCNT(16) PB_VMCNT(20)
+PB_VMCNT(15) PB_VMCNT(18) PB_VMCNT(21) PB_VMCNT(24) PB_VMCNT(30)
+#undef PB_VMCNT
+
+template <int NT, int NS>
+__global__ __launch_bounds__(256) void pw_gemm_dma_kernel(DmaArgs a) {
+  typedef bf16_t T;
+  constexpr int VEC = 8, KS = 64, MK = 32;
+  constexpr int BN = NT * 16;
+  constexpr int A_STAGE = BM * 128;                  // bytes
+  constexpr int W_STAGE = BN * 128;
+  constexpr int STAGE = A_STAGE + W_STAGE;
+  constexpr int WCH = NT / 2;                        // weight chunks (DMA instructions) per thread and stage
+  constexpr int GPS = 4 + WCH;                       // DMA instructions per thread and stage
+  constexpr int EPI_LD = BN + VEC;
+  constexpr int EPI_BYTES = 4 * 16 * EPI_LD * 2;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char dsmem[];
+  unsigned char* ring = dsmem;                                   // [NS][A | W]
+  T* epi_base = (T*)(dsmem + NS * STAGE);                        // [4 waves][16][EPI_LD]
+  float* sred = (float*)(dsmem + NS * STAGE + EPI_BYTES);        // [4][BN][2]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nk = (a.K + KS - 1) / KS;
+  const int n_tiles = a.n_tiles, m_tiles = a.m_tiles;
+  const int total = n_tiles == 1 ? m_tiles : ((m_tiles + 7) / 8) * 8 * n_tiles;
+  auto tile_mt = [&](int t) { return n_tiles == 1 ? t : ((t >> 3) / n_tiles) * 8 + (t & 7); };
+  auto tile_nt = [&](int t) { return n_tiles == 1 ? 0 : (t >> 3) % n_tiles; };
+  auto next_valid = [&](int t) {
+    while (t < total && tile_mt(t) >= m_tiles) t += gridDim.x;
+    return t;
+  };
+  // row panel -> first row, end row (exclusive) and weight group
+  auto panel = [&](int mt, int64_t& m0, int64_t& mend, int& grp) {
+    if (a.rows_per_group > 0) {
+      grp = mt / a.panels_per_group;
+      const int sub = mt - grp * a.panels_per_group;
+      m0 = (int64_t)grp * a.rows_per_group + (int64_t)sub * BM;
+      mend = min((int64_t)(grp + 1) * a.rows_per_group, m0 + BM);
+    } else {
+      grp = 0;
+      m0 = (int64_t)mt * BM;
+      mend = min(a.M, m0 + BM);
+    }
+  };
+
+  // ring starts out as zeros: from then on every byte in it is real (finite) data
+  for (int i = tid; i < NS * STAGE / 16; i += 256) *reinterpret_cast<u32x4*>(ring + i * 16) = u32x4{0u, 0u, 0u, 0u};
+
+  // this thread's chunks of a stage: A chunk f = i*256 + tid -> row f>>3, LDS chunk f&7 holds source chunk
+  // (f&7) ^ swz(row); same for the weight slice
+  int a_row[4], a_cs[4], w_row[WCH], w_cs[WCH];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int f = i * 256 + tid;
+    a_row[i] = f >> 3;
+    a_cs[i] = ((f & 7) ^ ((a_row[i] >> 1) & 7)) * VEC;
+  }
+#pragma unroll
+  for (int i = 0; i < WCH; ++i) {
+    const int f = i * 256 + tid;
+    w_row[i] = f >> 3;
+    w_cs[i] = ((f & 7) ^ ((w_row[i] >> 1) & 7)) * VEC;
+  }
+  const int wave_off = __builtin_amdgcn_readfirstlane(wave * 1024);
+
+  auto issue = [&](int t, int ks, int buf) {
+    int64_t m0, mend;
+    int grp;
+    panel(tile_mt(t), m0, mend, grp);
+    const int n0 = tile_nt(t) * BN, k0 = ks * KS;
+    unsigned char* A = ring + buf * STAGE + wave_off;
+    unsigned char* W = ring + buf * STAGE + A_STAGE + wave_off;
+    const T* wg = a.WB + (int64_t)grp * a.w_group_stride;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = k0 + a_cs[i];
+      const int64_t m = min(m0 + a_row[i], a.M - 1);         // rows past the panel: any valid row (never stored)
+      if (k < a.K) glds16(a.X + m * a.K + k, A + i * 4096);
+    }
+#pragma unroll
+    for (int i = 0; i < WCH; ++i) {
+      const int k = k0 + w_cs[i];
+      const int n = min(n0 + w_row[i], a.N - 1);             // columns past N: any valid row (never stored)
+      if (k < a.K) glds16(wg + (int64_t)n * a.K + k, W + i * 4096);
+      else *reinterpret_cast<u32x4*>(ring + buf * STAGE + A_STAGE + (i * 256 + tid) * 16) = u32x4{0u, 0u, 0u, 0u};
+    }
+  };
+
+  f32x4 acc[2][NT];
+  float csum[NT], csq[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    csum[j] = csq[j] = 0.f;
+    acc[0][j] = acc[1][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int frow = lane & 15, fk = lane >> 4;
+  const int ccol = lane & 15, rgrp = lane >> 4;
+  const bool plain = !a.out_scale && !a.out_shift && a.out_act == PB_ACT_NONE;
+  float osc[NT], osh[NT];
+  int osc_n0 = -1;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) { osc[j] = 1.f; osh[j] = 0.f; }
+  // fragment read offsets inside a stage (bytes): rows wave*32 + frow (+16) of A, rows j*16 + frow of W
+  const int a_rd = (wave * 32 + frow) * 128;
+  const int a_sw = ((wave * 32 + frow) >> 1) & 7;            // rows r and r+16 share the swizzle
+  const int w_sw = (frow >> 1) & 7;                          // rows j*16 + frow: (j*8 + frow/2) & 7 = frow/2
+
+  auto flush_stats = [&](int n0) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      float s = csum[j], q = csq[j];
+      s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+      q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+      if (lane < 16) {
+        sred[(wave * BN + j * 16 + lane) * 2 + 0] = s;
+        sred[(wave * BN + j * 16 + lane) * 2 + 1] = q;
+      }
+      csum[j] = csq[j] = 0.f;
+    }
+    lds_barrier();
+    float* st = a.stats + (size_t)(blockIdx.x % PB_STAT_REPLICAS) * 2 * a.N;
+    for (int c = tid; c < BN; c += 256) {
+      const int n = n0 + c;
+      if (n < a.N) {
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          s += sred[(w * BN + c) * 2 + 0];
+          q += sred[(w * BN + c) * 2 + 1];
+        }
+        atomicAdd(st + n, s);
+        atomicAdd(st + a.N + n, q);
+      }
+    }
+    lds_barrier();
+  };
+
+  int t = next_valid((int)blockIdx.x);
+  if (t >= total) return;                            // uniform
+  lds_barrier();                                     // ring zero-fill visible before the first DMA lands on it
+  // issue cursor: (ti, ksi) is the next stage to request; it runs NS-1 stages ahead of (t, ks)
+  int ti = t, ksi = 0, ahead = 0;
+  auto advance_cursor = [&]() {
+    if (++ksi == nk) {
+      ksi = 0;
+      ti = next_valid(ti + gridDim.x);
+    }
+  };
+#pragma unroll
+  for (int s0 = 0; s0 < NS - 1; ++s0) {
+    if (ti < total) {
+      issue(ti, ksi, s0);
+      advance_cursor();
+      ++ahead;
+    }
+  }
+  int ks = 0, buf = 0;
+  while (t < total) {
+    // stage (t, ks) is the oldest of `ahead` requested stages: leave the younger ones in flight
+    if (ahead >= 3) wait_vmcnt<2 * GPS>();
+    else if (ahead == 2) wait_vmcnt<GPS>();
+    else wait_vmcnt<0>();
+    lds_barrier();       // everybody's part of the stage has landed; everybody is done reading the previous stage
+    if (ti < total) {
+      int nb = buf + NS - 1;
+      if (nb >= NS) nb -= NS;
+      issue(ti, ksi, nb);
+      advance_cursor();
+    } else {
+      --ahead;
+    }
+    const unsigned char* As = ring + buf * STAGE;
+    const unsigned char* Ws = As + A_STAGE;
+#pragma unroll
+    for (int kk = 0; kk < KS; kk += MK) {
+      const int ca = (((kk >> 3) + fk) ^ a_sw) << 4, cw = (((kk >> 3) + fk) ^ w_sw) << 4;
+      const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(As + a_rd + ca);
+      const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(As + a_rd + 16 * 128 + ca);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const bf16x8 bw = *reinterpret_cast<const bf16x8*>(Ws + (j * 16 + frow) * 128 + cw);
+        acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bw, acc[0][j], 0, 0, 0);
+        acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bw, acc[1][j], 0, 0, 0);
+      }
+    }
+    if (++buf == NS) buf = 0;
+    if (ks == nk - 1) {
+      // ---- epilogue: affine/bias + activation, per-column statistics, LDS-transposed store (the ring
+      // keeps filling underneath: epi/sred are not part of it)
+      int64_t m0, mend;
+      int grp;
+      panel(tile_mt(t), m0, mend, grp);
+      const int n0 = tile_nt(t) * BN;
+      T* epi = epi_base + wave * 16 * EPI_LD;
+      if (!plain) {
+        if (n0 != osc_n0) {
+          osc_n0 = n0;
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            const int n = n0 + j * 16 + ccol;
+            osc[j] = (a.out_scale && n < a.N) ? a.out_scale[n] : 1.f;
+            osh[j] = (a.out_shift && n < a.N) ? a.out_shift[n] : 0.f;
+          }
+        }
+#define PB_EPI_LOOP(EXPR)                                             \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i)                       \
+  _Pragma("unroll") for (int j = 0; j < NT; ++j)                      \
+  _Pragma("unroll") for (int r = 0; r < 4; ++r) {                     \
+    const float x = acc[i][j][r] * osc[j] + osh[j];                   \
+    acc[i][j][r] = (EXPR);                                            \
+  }
+        switch (a.out_act) {
+          case PB_ACT_RELU: PB_EPI_LOOP(x > 0.f ? x : 0.f) break;
+          case PB_ACT_LEAKY_RELU: PB_EPI_LOOP(x > 0.f ? x : x * a.out_slope) break;
+          case PB_ACT_HSWISH: PB_EPI_LOOP(x * fminf(fmaxf(x + 3.f, 0.f), 6.f) * (1.f / 6.f)) break;
+          case PB_ACT_HSIGMOID: PB_EPI_LOOP(fminf(fmaxf(x * (1.f / 6.f) + 0.5f, 0.f), 1.f)) break;
+          case PB_ACT_SILU: PB_EPI_LOOP(x / (1.f + __expf(-x))) break;
+          default: PB_EPI_LOOP(x) break;
+        }
+#undef PB_EPI_LOOP
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int n = n0 + j * 16 + ccol;
+          const bool nok = n < a.N;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int rl = rgrp * 4 + r;
+            const int64_t m = m0 + wave * 32 + i * 16 + rl;
+            const T tv = from_f32<T>(acc[i][j][r]);
+            epi[rl * EPI_LD + j * 16 + ccol] = tv;
+            if (a.stats && nok && m < mend) {
+              const float fv = to_f32(tv);
+              csum[j] += fv;
+              csq[j] += fv * fv;
+            }
+          }
+          acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // epi tiles are wave-private: no workgroup barrier
+        __builtin_amdgcn_wave_barrier();
+        constexpr int CPR = BN / VEC;
+        for (int f = lane; f < 16 * CPR; f += 64) {
+          const int r = f / CPR, c = f - r * CPR;
+          const int64_t m = m0 + wave * 32 + i * 16 + r;
+          const int n = n0 + c * VEC;
+          if (m < mend && n < a.N) vec_store<T>(a.Y + m * a.N + n, vec_load<T>(epi + r * EPI_LD + c * VEC));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+      }
+      if (a.stats && n_tiles > 1) flush_stats(n0);
+      ks = 0;
+      t = next_valid(t + gridDim.x);
+    } else {
+      ++ks;
+    }
+  }
+  if (a.stats && n_tiles == 1) flush_stats(0);
+}
+
+// weight preparation: out[g][r][c] (bf16) = w[...] (* scale[g][k]); one thread per 8 output elements
+struct PrepArgs {
+  const float* w;        // [N][K] fp32
+  bf16_t* out;
+  const float* scale;    // [G][K] or null
+  int N, K, G, transpose;   // transpose: out is [K][N] (element (k, n) = w[n][k])
+};
+
+__global__ __launch_bounds__(256) void pw_weight_prep_kernel(PrepArgs a) {
+  const int R = a.transpose ? a.K : a.N, C = a.transpose ? a.N : a.K;
+  const int64_t per_g = (int64_t)R * C;
+  const int64_t total8 = (int64_t)a.G * per_g / 8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total8; i += (int64_t)gridDim.x * 256) {
+    const int64_t e = i * 8;
+    const int g = (int)(e / per_g);
+    const int64_t rem = e - (int64_t)g * per_g;
+    const int r = (int)(rem / C), c0 = (int)(rem - (int64_t)r * C);
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = c0 + j;
+      float v;
+      if (a.transpose) v = a.w[(int64_t)c * a.K + r];           // out[k = r][n = c]
+      else v = a.w[(int64_t)r * a.K + c] * (a.scale ? a.scale[(int64_t)g * a.K + c] : 1.f);
+      o[j] = (bf16_t)v;
+    }
+    *reinterpret_cast<bf16x8*>(a.out + e) = o;
+  }
+}
+
+// the same conversion for a whole model in one launch: desc[t] = {w, out, N << 32 | K, transpose} (device array)
+__global__ __launch_bounds__(256) void pw_weight_prep_batch_kernel(const int64_t* desc) {
+  const int64_t* d = desc + 4 * blockIdx.y;
+  PrepArgs a;
+  a.w = (const float*)d[0]; a.out = (bf16_t*)d[1]; a.scale = nullptr;
+  a.N = (int)(d[2] >> 32); a.K = (int)(d[2] & 0xffffffffLL); a.G = 1; a.transpose = (int)d[3];
+  const int R = a.transpose ? a.K : a.N, C = a.transpose ? a.N : a.K;
+  const int64_t total8 = (int64_t)R * C / 8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total8; i += (int64_t)gridDim.x * 256) {
+    const int64_t e = i * 8;
+    const int r = (int)(e / C), c0 = (int)(e - (int64_t)r * C);
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = c0 + j;
+      o[j] = (bf16_t)(a.transpose ? a.w[(int64_t)c * a.K + r] : a.w[(int64_t)r * a.K + c]);
+    }
+    *reinterpret_cast<bf16x8*>(a.out + e) = o;
+  }
+}
+
+int pick_nt_dma(int N) {
+  const int cand[5] = {2, 4, 6, 8, 12};
+  int best = 2;
+  int64_t best_cost = INT64_MAX;
+  for (int c : cand) {
+    const int bn = c * 16;
+    const int64_t tiles = pb_cdiv(N, bn);
+    const int64_t cost = tiles * bn + 16 * tiles;
+    if (cost < best_cost) { best = c; best_cost = cost; }
+  }
+  return best;
+}
+
+template <int NT, int NS>
+int launch_dma(const DmaArgs& a, int64_t total, int device, hipStream_t st) {
+  constexpr int BN = NT * 16;
+  constexpr size_t lds = (size_t)NS * (BM * 128 + BN * 128) + 4 * 16 * (BN + 8) * 2 + 4 * BN * 2 * 4;
+  static int resident = 0;
+  if (resident == 0) {
+    (void)hipFuncSetAttribute((const void*)pw_gemm_dma_kernel<NT, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pw_gemm_dma_kernel<NT, NS>, 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) cus = 256;
+    resident = per_cu * cus;
+  }
+  int64_t blocks = resident;
+  if (blocks > total) blocks = total;
+  blocks = pb_cdiv(blocks, 8) * 8;
+  hipLaunchKernelGGL((pw_gemm_dma_kernel<NT, NS>), dim3((unsigned)blocks), dim3(256), lds, st, a);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int pb_pw_weight_prep(const float* w, int N, int K, int transpose, const float* row_scale, int G,
+                                 void* out_bf16, int device, void* stream) {
+  PB_CHECK_ARG(w && out_bf16, "pb_pw_weight_prep: null pointer");
+  PB_CHECK_ARG(N > 0 && K > 0 && G >= 1, "pb_pw_weight_prep: bad sizes");
+  PB_CHECK_ARG(((int64_t)N * K) % 8 == 0 && (transpose ? N : K) % 8 == 0, "pb_pw_weight_prep: inner dimension must be a multiple of 8");
+  PB_CHECK_ARG(!(transpose && (row_scale || G != 1)), "pb_pw_weight_prep: no scaling with transpose");
+  PB_CHECK_ARG(((uintptr_t)out_bf16 % 16) == 0, "pb_pw_weight_prep: unaligned output");
+  PB_ENTER(device);
+  PrepArgs a;
+  a.w = w; a.out = (bf16_t*)out_bf16; a.scale = row_scale; a.N = N; a.K = K; a.G = G; a.transpose = transpose;
+  const int64_t total8 = (int64_t)G * N * K / 8;
+  int64_t blocks = pb_cdiv(total8, 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(pw_weight_prep_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  PB_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pb_pw_weight_prep_batch(const int64_t* desc, int count, int device, void* stream) {
+  PB_CHECK_ARG(desc && count > 0 && count <= 65535, "pb_pw_weight_prep_batch: bad arguments");
+  PB_ENTER(device);
+  hipLaunchKernelGGL(pw_weight_prep_batch_kernel, dim3(16, (unsigned)count), dim3(256), 0, (hipStream_t)stream, desc);
+  PB_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pb_pwconv_fwd_bf16w(const void* x, const void* wb, void* y, int64_t M, int K, int N, int groups,
+                                   int64_t rows_per_group, const float* out_scale, const float* out_shift,
+                                   pb_act out_act, float out_slope, float* stats, int device, void* stream) {
+  PB_CHECK_ARG(x && wb && y, "pb_pwconv_fwd_bf16w: null pointer");
+  PB_CHECK_ARG(M > 0 && K > 0 && N > 0 && K % 8 == 0 && N % 8 == 0, "pb_pwconv_fwd_bf16w: K and N must be multiples of 8 (M=%lld K=%d N=%d)",
+               (long long)M, K, N);
+  PB_CHECK_ARG(groups >= 1 && (groups == 1 || (rows_per_group > 0 && rows_per_group * groups == M)),
+               "pb_pwconv_fwd_bf16w: groups * rows_per_group must equal M");
+  PB_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)wb % 16) == 0, "pb_pwconv_fwd_bf16w: unaligned pointer");
+  PB_ENTER(device);
+  DmaArgs a;
+  a.X = (const bf16_t*)x; a.WB = (const bf16_t*)wb; a.Y = (bf16_t*)y; a.M = M; a.K = K; a.N = N;
+  a.out_scale = out_scale; a.out_shift = out_shift; a.out_act = (int)out_act; a.out_slope = out_slope; a.stats = stats;
+  if (groups > 1) {
+    a.w_group_stride = (int64_t)N * K;
+    a.rows_per_group = rows_per_group;
+    a.panels_per_group = (int)pb_cdiv(rows_per_group, BM);
+    a.m_tiles = a.panels_per_group * groups;
+  } else {
+    a.w_group_stride = 0; a.rows_per_group = 0; a.panels_per_group = 0;
+    a.m_tiles = (int)pb_cdiv(M, BM);
+  }
+  const int nt = pick_nt_dma(N);
+  a.n_tiles = (int)pb_cdiv(N, nt * 16);
+  const int64_t total = a.n_tiles == 1 ? a.m_tiles : pb_cdiv(a.m_tiles, 8) * 8 * a.n_tiles;
+  PB_CHECK_ARG(total <= 0x3fffffffLL, "pb_pwconv_fwd_bf16w: too many tiles");
+  hipStream_t st = (hipStream_t)stream;
+  switch (nt) {
+    case 2: launch_dma<2, 4>(a, total, device, st); break;
+    case 4: launch_dma<4, 4>(a, total, device, st); break;
+    case 6: launch_dma<6, 3>(a, total, device, st); break;
+    case 8: launch_dma<8, 3>(a, total, device, st); break;
+    default: launch_dma<12, 3>(a, total, device, st); break;
+  }
+  PB_LAUNCH_CHECK();
+  return 0;
+}

@@ -13,9 +13,37 @@ All activations are contiguous NDHWC tensors [N,T,H,W,C] (float32 or bfloat16); 
 the reference-shaped fp32 tensors.  `K` is the kernel namespace (picklebot_amd.kernels): tests
 swap it for the CPU mirror to check this file's dataflow without a GPU; the product never does.
 """
+import functools
+
 import torch
 
 from . import kernels as K
+
+
+def scoped(fn):
+    """Decorator for every module forward: the outermost one opens a new weight generation (kernels.weight_scope),
+    so that the bf16 weight copies derived inside it and in its backward are never reused after an optimiser step."""
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        scope = getattr(K, "weight_scope", None)
+        if scope is None:
+            return fn(*args, **kwargs)
+        with scope():
+            return fn(*args, **kwargs)
+    return wrapper
+
+
+def prepare_pointwise_weights(model, convs):
+    """One batched bf16 conversion (both orientations) of the given 1x1x1 convolutions' weights; call inside the
+    model's (scoped) forward when it computes in bf16 on the GPU."""
+    ws_cls = getattr(K, "WeightSet", None)
+    if ws_cls is None:
+        return
+    ws = model.__dict__.get("_pb_weightset")
+    if ws is None:
+        ws = ws_cls()
+        model.__dict__["_pb_weightset"] = ws
+    ws.prepare([c.weight.view(c.out_channels, c.in_channels) for c in convs])
 
 
 def _zeros(shape, ref):

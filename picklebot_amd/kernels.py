@@ -5,7 +5,9 @@ hand-written kernel), allocates outputs with torch (plumbing) and launches on th
 stream of the tensor's device.  Activations are 2-D row matrices [M, C] or 5-D NDHWC tensors.
 """
 import ctypes
+import os
 import threading
+import weakref
 
 import torch
 
@@ -45,6 +47,7 @@ class _ZeroArena:
 
 
 _arena = _ZeroArena()
+_USE_ARENA = os.environ.get("PB_ZERO_ARENA", "1") != "0"
 
 
 def zeros(shape, device):
@@ -53,7 +56,7 @@ def zeros(shape, device):
     n = 1
     for d in shape:
         n *= int(d)
-    if torch.device(device).type != "cuda":
+    if torch.device(device).type != "cuda" or not _USE_ARENA:
         return torch.zeros(shape, dtype=torch.float32, device=device)
     return _arena.take(n, torch.device(device)).view(shape)
 
@@ -136,6 +139,102 @@ def _rows(t, name="activation"):
 
 
 # ------------------------------------------------------------------------------ pointwise conv
+_GEMM_DMA = os.environ.get("PB_GEMM_DMA", "1") != "0"
+_GEMM_DMA_ALL = os.environ.get("PB_GEMM_DMA_ALL", "0") != "0"
+
+
+def _dma_gemm_pays(M, K, N):
+    """Measured per layer on MI355X (MobileNetLarge3D, batch 32; tools/bench_ab.sh): the LDS-DMA ring GEMM (one
+    workgroup per CU) is 1.2-2.3x faster wherever a tile has several K stages or the matrix is small; the
+    register-staged kernel (three workgroups per CU) keeps the huge-M, single-stage early layers and the wide
+    outputs of short reductions (three or more column tiles re-reading X)."""
+    if M <= 64:
+        return False
+    if _GEMM_DMA_ALL:
+        return True
+    return M < 500_000 and (N <= 256 or K >= 160)
+
+
+# bf16 weight copies live for one "weight scope" = one top-level module forward and its backward.  Version
+# counters cannot be trusted to invalidate them: torch's fused optimisers update parameters without bumping
+# `_version` (checked on this stack: AdamW(fused=True) leaves it at 0), so every top-level forward starts a new
+# generation and re-derives the copies (one batched launch per model forward, see prepare_weights).
+_wcache = {}
+_wgen = 0
+_wscope_depth = threading.local()
+
+
+class weight_scope:
+    """Entered by every module forward; the outermost one starts a new weight generation."""
+
+    def __enter__(self):
+        global _wgen
+        d = getattr(_wscope_depth, "d", 0)
+        if d == 0:
+            _wgen += 1
+        _wscope_depth.d = d + 1
+        return self
+
+    def __exit__(self, *exc):
+        _wscope_depth.d -= 1
+        return False
+
+
+def _prepped_weight(w, transposed):
+    """bf16 GEMM weights [N,K] of the fp32 parameter view `w` ([N,K], or [K,N] when `transposed`) for the current
+    weight generation."""
+    key = (w.data_ptr(), w.numel(), bool(transposed))
+    ent = _wcache.get(key)
+    # a cached copy is trusted only inside a weight scope or in the backward pass of one (autograd graph task):
+    # a bare kernels.pw_fwd call has no generation to tie it to (and the allocator recycles addresses)
+    scoped = getattr(_wscope_depth, "d", 0) > 0 or torch._C._current_graph_task_id() != -1
+    if scoped and ent is not None and ent[0] == _wgen and ent[1].device == w.device:
+        return ent[1]
+    R, C = w.shape
+    shape = (C, R) if transposed else (R, C)
+    out = ent[1] if (scoped and ent is not None and tuple(ent[1].shape) == shape and ent[1].device == w.device) else \
+        torch.empty(shape, dtype=torch.bfloat16, device=w.device)
+    dev, st = _dev_stream(w)
+    _launch("pw_weight_prep_kernel", _nb(w, out), "pb_pw_weight_prep", _p(w), R, C, int(bool(transposed)), None, 1, _p(out), dev, st)
+    if scoped:
+        _wcache[key] = (_wgen, out)
+    return out
+
+
+class WeightSet:
+    """All pointwise weights of a model, converted (both orientations) by ONE launch per forward."""
+
+    def __init__(self):
+        self.ptrs = None
+        self.desc = None
+        self.outs = None
+
+    def prepare(self, weights):
+        """weights: list of fp32 [N,K] parameter views (N*K % 8 == 0).  Must be called inside a weight_scope."""
+        weights = [w for w in weights if w.is_cuda and w.dtype == torch.float32 and w.dim() == 2 and w.is_contiguous()
+                   and w.shape[0] % 8 == 0 and w.shape[1] % 8 == 0]
+        if not weights:
+            return
+        ptrs = [w.data_ptr() for w in weights]
+        if ptrs != self.ptrs:
+            rows, outs = [], []
+            for w in weights:
+                N, K = w.shape
+                o0 = torch.empty((N, K), dtype=torch.bfloat16, device=w.device)
+                o1 = torch.empty((K, N), dtype=torch.bfloat16, device=w.device)
+                outs.append((o0, o1))
+                rows.append([w.data_ptr(), o0.data_ptr(), (N << 32) | K, 0])
+                rows.append([w.data_ptr(), o1.data_ptr(), (N << 32) | K, 1])
+            self.desc = torch.tensor(rows, dtype=torch.int64, device=weights[0].device)
+            self.ptrs, self.outs = ptrs, outs
+        dev, st = _dev_stream(weights[0])
+        _launch("pw_weight_prep_batch_kernel", sum(w.numel() * 8 for w in weights), "pb_pw_weight_prep_batch", _p(self.desc),
+                self.desc.shape[0], dev, st)
+        for w, (o0, o1) in zip(weights, self.outs):
+            _wcache[(w.data_ptr(), w.numel(), False)] = (_wgen, o0)      # forward: GEMM weights [N,K] = w
+            _wcache[(w.data_ptr(), w.numel(), True)] = (_wgen, o1)       # backward-data: GEMM weights [K,N] = w^T
+
+
 def pw_fwd(x, w, *, w_transposed=False, in_scale=None, in_shift=None, in_act="none", in_slope=0.0, row_scale=None,
            rows_per_group=0, out_scale=None, out_shift=None, out_act="none", out_slope=0.0, stats=None):
     """y[M,N] = P(x)[M,K] @ Wl[N,K]^T with fused prologue/epilogue (see pb_pwconv_fwd).
@@ -157,6 +256,23 @@ def pw_fwd(x, w, *, w_transposed=False, in_scale=None, in_shift=None, in_act="no
         _f32(row_scale, (M // rows_per_group, K), "row_scale")
     y = torch.empty((M, N), dtype=x.dtype, device=x.device)
     dev, st = _dev_stream(x)
+    if (_GEMM_DMA and x.dtype == torch.bfloat16 and _dma_gemm_pays(M, K, N) and K % 8 == 0 and N % 8 == 0
+            and in_scale is None and in_shift is None and in_act == "none" and w.is_contiguous()
+            and (row_scale is None or rows_per_group >= 128)):
+        # both operands by LDS-DMA: bf16 weights (cached per optimiser step; the squeeze-excite scale is
+        # folded into per-clip weights, so the activation stream is read untouched)
+        wb = _prepped_weight(w, w_transposed)
+        groups = 1
+        if row_scale is not None:
+            groups = M // rows_per_group
+            wbs = torch.empty((groups, N, K), dtype=torch.bfloat16, device=x.device)
+            _launch("pw_weight_prep_kernel", _nb(w, row_scale, wbs), "pb_pw_weight_prep", _p(w), N, K, 0, _p(row_scale), groups,
+                    _p(wbs), dev, st)
+            wb = wbs
+        _launch("pw_gemm_dma_kernel", _nb(x, y) + N * K * 2, "pb_pwconv_fwd_bf16w", _p(x), _p(wb), _p(y), M, K, N, groups,
+                int(rows_per_group) if groups > 1 else 0, _p(out_scale), _p(out_shift), ACT[out_act], float(out_slope),
+                _p(stats), dev, st, detail=f"M{M} K{K} N{N}")
+        return y
     skinny = (M <= 64 and in_scale is None and in_shift is None and in_act == "none" and row_scale is None
               and stats is None)
     family = "pw_skinny_kernel" if skinny else "pw_gemm_kernel"

@@ -106,6 +106,7 @@ class SEBlock3D(nn.Module):
                                 nn.Conv3d(mid, channels, kernel_size=1), nn.Hardsigmoid())
 
     @torch.compiler.disable
+    @PF.scoped
     def forward(self, x):
         x5 = to_ndhwc(x, compute_dtype(x))
         return from_ndhwc(PF.se_block(x5, se_params(self)))
@@ -127,6 +128,7 @@ class Bottleneck3D(nn.Module):
         self.dropout = nn.Dropout3d(p=dropout)
 
     @torch.compiler.disable
+    @PF.scoped
     def forward(self, x):
         x5 = to_ndhwc(x, compute_dtype(x))
         dwc = self.depthwise_conv
@@ -171,8 +173,17 @@ class _MobileNet3D(nn.Module):
                                         nn.Hardswish(), nn.Conv3d(tb["head_hidden"], num_classes, kernel_size=1))
 
     @torch.compiler.disable
+    @PF.scoped
     def forward(self, x):
         dt = compute_dtype(x)
+        if x.is_cuda and dt == torch.bfloat16:
+            # bf16 copies (both orientations) of every pointwise weight for this forward/backward: one launch
+            convs = self.__dict__.get("_pb_pw_convs")
+            if convs is None:
+                convs = [c for m in self.modules() if isinstance(m, Bottleneck3D) for c in (m.pointwise_conv1, m.pointwise_conv2)]
+                convs.append(getattr(self, self._last)[0])
+                self.__dict__["_pb_pw_convs"] = convs
+            PF.prepare_pointwise_weights(self, convs)
         conv, bn, act_m = self.block1
         act, slope = act_of(act_m)
         y5 = PF.stem_bn_act(x, conv, bn, act=act, slope=slope, training=bn.training, dtype=dt,

@@ -56,6 +56,7 @@ class FeedForward(nn.Module):
         return PF.ff_block(rows, self.net[0].weight, self.net[3].weight)
 
     @torch.compiler.disable
+    @PF.scoped
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         rows = x.reshape(-1, x.shape[-1]).to(compute_dtype(x))
         return (self.rows(rows) - rows).view(x.shape)          # module contract is net(x) without the residual
@@ -83,6 +84,7 @@ class Attention(nn.Module):
         return PF.attn_block(rows, self.to_qkv.weight, self.to_out[0].weight, G, n, self.scale, self.norm.eps)
 
     @torch.compiler.disable
+    @PF.scoped
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         b, p, n, d = x.shape
         rows = x.reshape(-1, d).to(compute_dtype(x))
@@ -96,6 +98,7 @@ class Transformer(nn.Module):
                                                     FeedForward(embed_dim, ffw_dim, dropout)]) for _ in range(depth)])
 
     @torch.compiler.disable
+    @PF.scoped
     def forward(self, x):
         b, p, n, d = x.shape
         rows = x.reshape(-1, d)
@@ -119,6 +122,7 @@ class MobileViTBlock(nn.Module):
         self.conv4 = conv_nxn_bn(2 * channel, channel, kernel_size)
 
     @torch.compiler.disable
+    @PF.scoped
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         y5 = to_ndhwc(x, compute_dtype(x))
         a5 = run_conv_1x1_bn(self.conv2, run_conv_nxn_bn(self.conv1, y5))
@@ -161,6 +165,7 @@ class MobileViT(nn.Module):
         self.to_logits = nn.Sequential(conv_1x1_bn(ch[-2], ch[-1]), _MeanTHW(), nn.Linear(ch[-1], num_classes, bias=False))
 
     @torch.compiler.disable
+    @PF.scoped
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         dt = compute_dtype(x)
         conv, bn, act_m = self.conv1

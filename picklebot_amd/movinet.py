@@ -32,6 +32,7 @@ class CausalConv3d(nn.Module):
         self.conv3d = nn.Conv3d(in_channels, out_channels, ks, stride=stride, dilation=dl, **kwargs)
 
     @torch.compiler.disable
+    @PF.scoped
     def forward(self, x):
         c = self.conv3d
         if self.stream_buffer != 0:
@@ -69,6 +70,7 @@ class MoviNetBottleneck(nn.Module):
         self.dropout = nn.Dropout3d(p=dropout)        # constructed, never applied (movinet.py:67 vs :69-77)
 
     @torch.compiler.disable
+    @PF.scoped
     def forward(self, x):
         x5 = to_ndhwc(x, compute_dtype(x))
         dwc = self.conv
@@ -102,6 +104,7 @@ class MoViNetA2(nn.Module):
                                         nn.BatchNorm1d(hid), nn.Hardswish(), nn.Dropout(0.2), nn.Linear(hid, num_classes))
 
     @torch.compiler.disable
+    @PF.scoped
     def forward(self, x):
         dt = compute_dtype(x)
         conv, bn, act_m = self.block1

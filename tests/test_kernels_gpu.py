@@ -84,6 +84,25 @@ def test_pw_bwd_weight(K, M, Kd, N, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,Kd,N,G", [(4 * 196, 672, 112, 4), (3 * 130, 120, 40, 3), (2 * 3136, 72, 24, 2), (5 * 128, 960, 160, 5),
+                                      (2 * 1000, 240, 80, 2), (6 * 200, 184, 80, 6)])
+def test_pw_fwd_training_projection(K, M, Kd, N, G, dtype):
+    """The projection conv of a training step: squeeze-excite scale alone on the input (bf16: folded into per-clip
+    weights, LDS-DMA GEMM with clip-aligned row panels) + BatchNorm statistics of the output; and its
+    backward-data twin (plain GEMM on the transposed weights)."""
+    x, w = rnd((M, Kd), dtype, 31), rnd((N, Kd), seed=32, scale=Kd ** -0.5)
+    rs = torch.rand(G, Kd) + 0.5
+    st_ref = torch.zeros(R.REPL, 2, N)
+    want = R.pw_fwd(x, w, row_scale=rs, rows_per_group=M // G, stats=st_ref)
+    st = torch.zeros(R.REPL, 2, N, device=DEV)
+    got = K.pw_fwd(dev(x), dev(w), row_scale=dev(rs), rows_per_group=M // G, stats=st)
+    check("pw_fwd_se", got, want, dtype)
+    check("pw_fwd_se_stats", st.sum(0), st_ref.sum(0), dtype)
+    dy = rnd((M, N), dtype, 33)
+    check("pw_fwd_dgrad", K.pw_fwd(dev(dy), dev(w), w_transposed=True), R.pw_fwd(dy, w, w_transposed=True), dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,Kd,N,G", [(48, 16, 384, 0), (32, 128, 16, 0), (96, 128, 128, 0), (40, 72, 24, 0), (200, 16, 384, 0),
                                       (150, 160, 960, 0), (5000, 24, 72, 4), (3000, 672, 112, 4), (7000, 112, 672, 7),
                                       (1024, 960, 160, 2), (777, 40, 120, 0)])

