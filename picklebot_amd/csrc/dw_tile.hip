@@ -47,22 +47,38 @@ template <> __device__ __forceinline__ void store_quad<bf16_t>(bf16_t* p, const 
 
 struct TileCoord {
   int n, td0, r0;
+  int ft, rt;         // frame-group and row-band indices (for the division-free step to the next tile)
   bool any_ok;        // some frame of the tile reads src
 };
 __device__ __forceinline__ bool frame_reads(const TileArgs& a, int td) {
   const int ts = td * a.t_mul + a.t_off;
   return td < a.Tdst && ts >= 0 && ts < a.Tsrc;
 }
+__device__ __forceinline__ void tile_finish(const TileArgs& a, TileCoord& t) {
+  t.td0 = t.ft * a.F;
+  t.r0 = t.rt * a.R;
+  t.any_ok = false;
+  for (int f = 0; f < a.F; ++f) t.any_ok |= frame_reads(a, t.td0 + f);
+}
 __device__ __forceinline__ TileCoord tile_coord(const TileArgs& a, int it) {
   TileCoord t;
   const int zz = it / a.row_tiles;
-  const int rt = it - zz * a.row_tiles;
+  t.rt = it - zz * a.row_tiles;
   t.n = zz / a.ftiles;
-  t.td0 = (zz - t.n * a.ftiles) * a.F;
-  t.r0 = rt * a.R;
-  t.any_ok = false;
-  for (int f = 0; f < a.F; ++f) t.any_ok |= frame_reads(a, t.td0 + f);
+  t.ft = zz - t.n * a.ftiles;
+  tile_finish(a, t);
   return t;
+}
+// tile index + 1 (tiles are ordered clip-major, then frame group, then row band)
+__device__ __forceinline__ void tile_next(const TileArgs& a, TileCoord& t) {
+  if (++t.rt == a.row_tiles) {
+    t.rt = 0;
+    if (++t.ft == a.ftiles) {
+      t.ft = 0;
+      ++t.n;
+    }
+  }
+  tile_finish(a, t);
 }
 
 // ----------------------------------------------------------------------------- staging
@@ -75,10 +91,12 @@ template <typename T, int NCH>
 struct Stager {
   Vec16<T> v[NCH];
   int rf[NCH];         // row | frame slot << 16
-  int coff[NCH];       // column*C + channel (elements); -1: never valid (padding column / beyond the block)
+  int off[NCH];        // element offset from the tile's base pointer: slot*frame_step + row*row_stride + column*C +
+                       // channel; -1: never valid (padding column / beyond the block)
   unsigned ok;
+  // frame_step: elements between the frames of consecutive slots (t_mul * H * W * C for the src tensor)
   __device__ __forceinline__ void init(int tid, int W, int rows_per_frame, int F, int colshift, int Wsrc, int C, int c,
-                                       bool cok) {
+                                       bool cok, int frame_step, int row_stride) {
     constexpr int VEC = ElemTraits<T>::VEC, LPP = 32 / VEC;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
@@ -87,20 +105,19 @@ struct Stager {
       const int f = vrow / rows_per_frame, r = vrow - f * rows_per_frame;
       const int ws = wcol - colshift;
       rf[i] = r | (f << 16);
-      coff[i] = (cok && f < F && ws >= 0 && ws < Wsrc) ? ws * C + c : -1;
+      off[i] = (cok && f < F && ws >= 0 && ws < Wsrc) ? f * frame_step + r * row_stride + ws * C + c : -1;
     }
     ok = 0;
   }
-  // fidx[f]: global frame index (n*T + t) of frame slot f, or -1 when that slot reads nothing
-  __device__ __forceinline__ void fetch(const T* base, int64_t frame_stride, int row_stride, int Hsrc, int row_base,
-                                        const int (&fidx)[MAXF]) {
+  // base: address of (frame of slot 0, row `row_base`, column 0, channel 0) - may lie outside the tensor for
+  // halo rows, those are never dereferenced; fmask: bit f set when slot f reads at all
+  __device__ __forceinline__ void fetch(const T* base, int Hsrc, int row_base, unsigned fmask) {
     ok = 0;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int f = rf[i] >> 16, h = row_base + (rf[i] & 0xffff);
-      const int fi = f == 0 ? fidx[0] : (f == 1 ? fidx[1] : (f == 2 ? fidx[2] : fidx[3]));
-      const bool o = coff[i] >= 0 && fi >= 0 && h >= 0 && h < Hsrc;
-      v[i] = o ? vec_load<T>(base + (int64_t)fi * frame_stride + (int64_t)h * row_stride + coff[i]) : vec_zero<T>();
+      const bool o = off[i] >= 0 && ((fmask >> f) & 1u) && (unsigned)h < (unsigned)Hsrc;
+      v[i] = o ? vec_load<T>(base + off[i]) : vec_zero<T>();
       ok |= o ? (1u << i) : 0u;
     }
   }
@@ -126,14 +143,13 @@ struct Stager {
   }
 };
 
-__device__ __forceinline__ void frame_indices(const TileArgs& a, const TileCoord& t, int (&src_idx)[MAXF], int (&dst_idx)[MAXF]) {
+// bit f set when frame slot f of the tile exists and reads the source tensor
+__device__ __forceinline__ unsigned frame_mask(const TileArgs& a, const TileCoord& t) {
+  unsigned m = 0;
 #pragma unroll
-  for (int f = 0; f < MAXF; ++f) {
-    const int td = t.td0 + f, ts = td * a.t_mul + a.t_off;
-    const bool o = f < a.F && td < a.Tdst && ts >= 0 && ts < a.Tsrc;
-    src_idx[f] = o ? t.n * a.Tsrc + ts : -1;
-    dst_idx[f] = o ? t.n * a.Tdst + td : -1;
-  }
+  for (int f = 0; f < MAXF; ++f)
+    if (f < a.F && frame_reads(a, t.td0 + f)) m |= 1u << f;
+  return m;
 }
 
 template <typename T>
@@ -204,12 +220,12 @@ __global__ __launch_bounds__(256) void dw_tile_fwd_kernel(TileArgs a) {
   const int ntiles = (int)a.tiles;
 
   Stager<T, XCH> xr;
-  xr.init(tid, a.Wp, a.rows_x, a.F, a.pad, a.Ws, a.C, c_st, cok_st);
+  xr.init(tid, a.Wp, a.rows_x, a.F, a.pad, a.Ws, a.C, c_st, cok_st, (int)(a.t_mul * src_fs), src_rs);
   float gs[VEC], gh[VEC];
-  int sidx[MAXF], didx[MAXF];
   auto fetch = [&](const TileCoord& t) {
-    frame_indices(a, t, sidx, didx);
-    xr.fetch(src, src_fs, src_rs, a.Hs, t.r0 * S - a.pad, sidx);
+    const int hs_base = t.r0 * S - a.pad;
+    const T* base = src + ((int64_t)t.n * a.Tsrc + (t.td0 * a.t_mul + a.t_off)) * src_fs + (int64_t)hs_base * src_rs;
+    xr.fetch(base, a.Hs, hs_base, frame_mask(a, t));
     if (affine) {
       load_gvec<T>(a.g_scale, a, t.n, c_st, cok_st, 1.f, gs);
       load_gvec<T>(a.g_shift, a, t.n, c_st, cok_st, 0.f, gh);
@@ -253,7 +269,7 @@ __global__ __launch_bounds__(256) void dw_tile_fwd_kernel(TileArgs a) {
     lds_barrier();
     const int nx = it + 1;
     if (nx < it_end) {
-      tc = tile_coord(a, nx);
+      tile_next(a, tc);
       fetch(tc);
     }
     const int rows_here = min(a.R, a.Hd - cur.r0);
@@ -335,40 +351,46 @@ __global__ __launch_bounds__(256) void dw_tile_wgrad_kernel(TileArgs a) {
 
   Stager<T, XCH> xr;
   Stager<T, GCH> gr;
-  xr.init(tid, a.Wp, a.rows_x, a.F, a.pad, a.Ws, a.C, c_st, cok_st);
-  gr.init(tid, a.Wdp, a.R, a.F, 0, a.Wd, a.C, c_st, cok_st);
+  xr.init(tid, a.Wp, a.rows_x, a.F, a.pad, a.Ws, a.C, c_st, cok_st, (int)(a.t_mul * x_fs), x_rs);
+  gr.init(tid, a.Wdp, a.R, a.F, 0, a.Wd, a.C, c_st, cok_st, (int)g_fs, g_rs);
   float gs[VEC], gh[VEC];
   auto fetch = [&](const TileCoord& t) {
-    int sidx[MAXF], didx[MAXF];
-    frame_indices(a, t, sidx, didx);
-    xr.fetch(x, x_fs, x_rs, a.Hs, t.r0 * S - a.pad, sidx);
-    gr.fetch(dy, g_fs, g_rs, a.Hd, t.r0, didx);
+    const unsigned fm = frame_mask(a, t);
+    const int hs_base = t.r0 * S - a.pad;
+    xr.fetch(x + ((int64_t)t.n * a.Tsrc + (t.td0 * a.t_mul + a.t_off)) * x_fs + (int64_t)hs_base * x_rs, a.Hs, hs_base, fm);
+    gr.fetch(dy + ((int64_t)t.n * a.Tdst + t.td0) * g_fs + (int64_t)t.r0 * g_rs, a.Hd, t.r0, fm);
     if (affine) {
       load_gvec<T>(a.g_scale, a, t.n, c_st, cok_st, 1.f, gs);
       load_gvec<T>(a.g_shift, a, t.n, c_st, cok_st, 0.f, gh);
     }
   };
   // next tile with a frame that reads x at all (zero frames contribute nothing)
-  auto next_valid = [&](int i, TileCoord& t) {
-    while (i < ntiles) {
-      t = tile_coord(a, i);
-      if (t.any_ok) break;
-      i += gridDim.x;
+  // each workgroup walks a contiguous range of tiles (division-free stepping)
+  const int per_wg = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int it_begin = min(ntiles, (int)blockIdx.x * per_wg), it_end = min(ntiles, it_begin + per_wg);
+  auto skip_invalid = [&](int i, TileCoord& t) {
+    while (i < it_end && !t.any_ok) {
+      ++i;
+      if (i < it_end) tile_next(a, t);
     }
     return i;
   };
   StripWalk w0;
   w0.init(j, J, a.nseg, a.R);
-  TileCoord tc;
-  int it = next_valid(blockIdx.x, tc);
-  if (it < ntiles) fetch(tc);
-  while (it < ntiles) {
+  TileCoord tc = tile_coord(a, min(it_begin, ntiles - 1));
+  int it = skip_invalid(it_begin, tc);
+  if (it < it_end) fetch(tc);
+  while (it < it_end) {
     const TileCoord cur = tc;
     xr.commit(xS, tid, xlimit, nullptr, nullptr, false);
     gr.commit(gS, tid, glimit, gs, gh, affine);
     lds_barrier();
-    const int nx = next_valid(it + gridDim.x, tc);
-    if (nx < ntiles) fetch(tc);
+    int nx = it + 1;
+    if (nx < it_end) {
+      tile_next(a, tc);
+      nx = skip_invalid(nx, tc);
+    }
+    if (nx < it_end) fetch(tc);
     if (j < J) {
       const int rows_here = min(a.R, a.Hd - cur.r0);
       StripWalk sw = w0;                              // frame slots beyond the clip are staged as zeros

@@ -226,8 +226,14 @@ int launch_ew(EwArgs a, hipStream_t st) {
   // >= 4 rows per thread; reducing launches stay <= ~512 workgroups per channel chunk so that, with the
   // 16 stats replicas, an address sees <= 32 same-address atomics
   PB_CHECK_ARG(a.M < 0x7fffffffLL, "elementwise kernels: M must fit 31 bits");
-  int64_t gx = pb_cdiv(a.M, (int64_t)a.map.P * 8);
-  const int64_t cap = a.sums ? pb_cdiv(512, 1) : pb_cdiv(8192, a.map.chunks);
+  // as many workgroups as there are row groups, up to the cap: small tensors (the 7x7 / 14x14 stages) were
+  // running 1 workgroup per CU with 8 dependent rows per thread - latency-bound at ~1 TB/s
+  int64_t gx = pb_cdiv(a.M, (int64_t)a.map.P * 8);           // 8 rows per thread on large tensors (measured best)
+  if (gx * a.map.chunks < 1024) {
+    gx = pb_cdiv(a.M, (int64_t)a.map.P);                      // small tensor: spread it over ~1024 workgroups
+    if (gx * a.map.chunks > 1024) gx = pb_cdiv(1024, a.map.chunks);
+  }
+  const int64_t cap = a.sums ? 512 : pb_cdiv(8192, a.map.chunks);
   if (gx > cap) gx = cap;
   if (gx < 1) gx = 1;
   dim3 grid((unsigned)gx, (unsigned)a.map.chunks);

@@ -47,6 +47,12 @@ class _ZeroArena:
 
 
 _arena = _ZeroArena()
+
+
+def reset_zero_arena():
+    """Forget the current chunk (call after capturing a HIP graph: the chunk belongs to the graph's memory pool)."""
+    with _arena._lock:
+        _arena._buf.clear()
 _USE_ARENA = os.environ.get("PB_ZERO_ARENA", "1") != "0"
 
 
@@ -466,7 +472,7 @@ def affine_act_fwd(x, scale=None, shift=None, act="none", slope=0.0, row_scale=N
     y = torch.empty_like(x)
     dev, st = _dev_stream(x)
     _launch("ew_kernel<affine_act>", _nb(x, y), "pb_affine_act_fwd", _p(x), _p(y), M, C, _dt(x), _p(scale), _p(shift), _p(mean), ACT[act], float(slope),
-            _p(row_scale), _p(row_shift), int(rows_per_group), _p(stats), dev, st)
+            _p(row_scale), _p(row_shift), int(rows_per_group), _p(stats), dev, st, detail=f"M{M} C{C}")
     return y
 
 
@@ -493,7 +499,7 @@ def act_bwd_reduce(dy, z, *, scale=None, shift=None, act="none", slope=0.0, row_
     dev, st = _dev_stream(z)
     _launch("ew_kernel<act_bwd>", _nb(dy, z, g), "pb_act_bwd_reduce", _p(dy), _p(z), _p(g), M, C, _dt(z), _p(scale), _p(shift), ACT[act], float(slope),
             _p(row_scale), int(rows_per_group), int(dy_rows_per_group), float(dy_mul), _p(mean), _p(rstd), _p(sums),
-            dev, st)
+            dev, st, detail=f"M{M} C{C}")
     return g
 
 
@@ -519,7 +525,7 @@ def affine2(g, z, A, B=None, Cc=None, mean=None):
     _f32(A, (C,), "A"); _f32(B, (C,), "B"); _f32(Cc, (C,), "Cc"); _f32(mean, (C,), "mean")
     out = torch.empty_like(g)
     dev, st = _dev_stream(g)
-    _launch("ew_kernel<affine2>", _nb(g, z, out), "pb_affine2", _p(g), _p(z), _p(out), M, C, _dt(g), _p(A), _p(B), _p(Cc), _p(mean), dev, st)
+    _launch("ew_kernel<affine2>", _nb(g, z, out), "pb_affine2", _p(g), _p(z), _p(out), M, C, _dt(g), _p(A), _p(B), _p(Cc), _p(mean), dev, st, detail=f"M{M} C{C}")
     return out
 
 
@@ -535,7 +541,7 @@ def rowgroup_reduce(a, b, G):
             raise ValueError("rowgroup_reduce: a/b mismatch")
     out = zeros((G, C), a.device)
     dev, st = _dev_stream(a)
-    _launch("rowgroup_kernel", _nb(a, b, out), "pb_rowgroup_reduce", _p(a), _p(b), _p(out), G, M // G, C, _dt(a), dev, st)
+    _launch("rowgroup_kernel", _nb(a, b, out), "pb_rowgroup_reduce", _p(a), _p(b), _p(out), G, M // G, C, _dt(a), dev, st, detail=f"M{M} C{C} G{G}")
     return out
 
 

@@ -75,7 +75,8 @@ class _MaskPool:
         self._pools = {}             # (device, p) -> [flat mask tensor, offset]
 
     def take(self, p, numel, device):
-        if numel > self.SIZE // 4:
+        if numel > self.SIZE // 4 or torch.cuda.is_current_stream_capturing():
+            # (under HIP-graph capture a pooled slice would replay the same mask for ever: draw in-graph)
             keep = torch.full((numel,), 1.0 - p, dtype=torch.float32, device=device)
             return torch.bernoulli(keep) * (1.0 / (1.0 - p))
         ent = self._pools.get((device, p))
