@@ -15,3 +15,12 @@ __attribute__((visibility("hidden"))) int pb_dw_tile_fwd(const void* src, const 
 
 // would the tile kernels take this correlation (same test the launchers apply)?
 __attribute__((visibility("hidden"))) bool pb_dw_tile_eligible(const pb_dwconv_shape* s, pb_dtype dtype, bool wgrad);
+
+// whole-frame-in-registers kernels for 7x7 frames (dw7.hip); same return convention
+__attribute__((visibility("hidden"))) bool pb_dw7_eligible(const pb_dwconv_shape* s);
+__attribute__((visibility("hidden"))) int pb_dw7_fwd(const void* src, const float* w, void* dst, const pb_dwconv_shape* s,
+                                                     pb_dtype dtype, int flip, const float* g_scale, const float* g_shift,
+                                                     float* pool, hipStream_t st);
+__attribute__((visibility("hidden"))) int pb_dw7_wgrad(const void* dy, const void* x, float* dw, const pb_dwconv_shape* s,
+                                                       pb_dtype dtype, const float* g_scale, const float* g_shift,
+                                                       hipStream_t st);

@@ -145,6 +145,8 @@ DW_CASES = [  # N, C, (T,H,W), kernel, stride, pad
     (1, 96, (4, 9, 9), (5, 3, 3), (1, 2, 2), (2, 1, 1)),
     (1, 48, (3, 9, 9), (1, 5, 5), (1, 2, 2), (0, 2, 2)),
     (1, 6, (3, 4, 4), (3, 3, 3), (1, 1, 1), (1, 1, 1)),           # scalar channel path
+    (2, 40, (3, 7, 7), (1, 3, 3), (1, 1, 1), (1, 1, 1)),          # 7x7 whole-frame-in-registers kernels, k=3
+    (3, 66, (4, 7, 7), (1, 5, 5), (2, 1, 1), (2, 2, 2)),          # ... with temporal stride/padding (zero frames)
 ]
 
 
