@@ -26,24 +26,6 @@ struct D7Args {
   int frames_per_wg;   // wgrad: consecutive dst frames walked by one workgroup
 };
 
-template <typename T> struct Pair;
-template <> struct Pair<bf16_t> {
-  typedef unsigned raw_t;
-  static __device__ __forceinline__ f32x2 up(unsigned r) {
-    return f32x2{__builtin_bit_cast(float, r << 16), __builtin_bit_cast(float, r & 0xffff0000u)};
-  }
-  static __device__ __forceinline__ unsigned down(f32x2 v) {
-    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-    bf16x2 o = {(bf16_t)v[0], (bf16_t)v[1]};
-    return __builtin_bit_cast(unsigned, o);
-  }
-};
-template <> struct Pair<float> {
-  typedef f32x2 raw_t;
-  static __device__ __forceinline__ f32x2 up(f32x2 r) { return r; }
-  static __device__ __forceinline__ f32x2 down(f32x2 v) { return v; }
-};
-
 template <typename T, int K, bool FLIP>
 __global__ __launch_bounds__(256) void dw7_fwd_kernel(D7Args a) {
   typedef typename Pair<T>::raw_t raw_t;

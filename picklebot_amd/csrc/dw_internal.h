@@ -2,6 +2,26 @@
 #pragma once
 #include "pb_common.h"
 
+// two adjacent channels of T as one register: bf16 pairs are a dword, unpacked with a shift / a mask
+template <typename T> struct Pair;
+template <> struct Pair<bf16_t> {
+  typedef unsigned raw_t;
+  static __device__ __forceinline__ f32x2 up(unsigned r) {
+    return f32x2{__builtin_bit_cast(float, r << 16), __builtin_bit_cast(float, r & 0xffff0000u)};
+  }
+  static __device__ __forceinline__ unsigned down(f32x2 v) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    bf16x2 o = {(bf16_t)v[0], (bf16_t)v[1]};
+    return __builtin_bit_cast(unsigned, o);
+  }
+};
+template <> struct Pair<float> {
+  typedef f32x2 raw_t;
+  static __device__ __forceinline__ f32x2 up(f32x2 r) { return r; }
+  static __device__ __forceinline__ f32x2 down(f32x2 v) { return v; }
+};
+
+
 // LDS-tiled kernels for small frames (dw_tile.hip).  Return 0 on launch, 1 on error, and -1 when the
 // shape is not eligible (caller falls through to the strip / generic kernels).
 __attribute__((visibility("hidden"))) int pb_dw_tile_wgrad(const void* dy, const void* x, float* dw,
@@ -24,3 +44,12 @@ __attribute__((visibility("hidden"))) int pb_dw7_fwd(const void* src, const floa
 __attribute__((visibility("hidden"))) int pb_dw7_wgrad(const void* dy, const void* x, float* dw, const pb_dwconv_shape* s,
                                                        pb_dtype dtype, const float* g_scale, const float* g_shift,
                                                        hipStream_t st);
+
+// rolling-window kernels with lanes along channel pairs (dw_rows.hip); same return convention
+__attribute__((visibility("hidden"))) bool pb_dw_rows_eligible(const pb_dwconv_shape* s, bool wgrad);
+__attribute__((visibility("hidden"))) int pb_dw_rows_fwd(const void* src, const float* w, void* dst, const pb_dwconv_shape* s,
+                                                         pb_dtype dtype, int flip, const float* g_scale, const float* g_shift,
+                                                         float* pool, hipStream_t st);
+__attribute__((visibility("hidden"))) int pb_dw_rows_wgrad(const void* dy, const void* x, float* dw, const pb_dwconv_shape* s,
+                                                           pb_dtype dtype, const float* g_scale, const float* g_shift,
+                                                           hipStream_t st);

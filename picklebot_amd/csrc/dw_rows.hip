@@ -1,0 +1,393 @@
+// Depthwise (1,k,k) "same" convolution with lanes along CHANNEL PAIRS and a rolling window of input rows in
+// registers.  A thread owns two channels of a WSEG-wide column segment and walks down a band of output rows:
+// every input element it needs is loaded exactly once (4 bytes per lane; a wave's load is one contiguous 256-byte
+// run of an NDHWC pixel), converted to fp32 once (with the squeeze-excite prologue and the zero padding) when
+// its row enters the k-row window, and the next step's rows are already in flight while a row is computed.
+// No LDS, no cross-lane traffic, all tap indices static (the row loop is unrolled by k so that window slots are
+// compile-time).  The strip kernels (lanes along x, one output column per thread) re-load every input column k
+// times through L1, the tile kernels pay an LDS round trip and per-tile bookkeeping; this form reaches the same
+// 3-4 TB/s on the 14x14 / 28x28 stages that dw7.hip reaches on 7x7.
+#include "dw_internal.h"
+#include <stdlib.h>
+
+namespace {
+
+struct RowsArgs {
+  const void* src;
+  void* dst;
+  const float* w;
+  const float* g_scale;
+  const float* g_shift;
+  float* pool;
+  int N, C, Tsrc, Hs, Ws, Tdst, Hd, Wd, t_mul, t_off;
+  int nseg, nbands, band_rows, CP;
+};
+
+template <typename T, int K, int S, int WSEG, bool FLIP>
+__global__ __launch_bounds__(256) void dw_rows_fwd_kernel(RowsArgs a) {
+  typedef typename Pair<T>::raw_t raw_t;
+  constexpr int P = K / 2;
+  constexpr int IW = (WSEG - 1) * S + K;
+  // work units (frame-band, segment, channel pair) are flattened over the grid: a frame with few channel pairs
+  // does not leave most of a 256-thread workgroup idle; lanes still run along the channel pairs
+  const int64_t gu = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int per_frame = a.CP * a.nseg;
+  const int64_t zb = gu / per_frame;
+  if (zb >= (int64_t)a.N * a.Tdst * a.nbands) return;
+  const int u = (int)(gu - zb * per_frame);
+  const int sg = u / a.CP, cp = u - sg * a.CP;
+  const int c0 = cp * 2;
+  const int z = (int)(zb / a.nbands), band = (int)(zb - (int64_t)z * a.nbands);
+  const int n = z / a.Tdst, td = z - n * a.Tdst;
+  const int ts = td * a.t_mul + a.t_off;
+  const int h0 = band * a.band_rows;
+  const int nrows = min(a.Hd, h0 + a.band_rows) - h0;
+  if (nrows <= 0) return;
+  const int w0 = sg * WSEG;
+  const int ps = a.C / 2;                                   // pixel stride in raw_t units
+  raw_t* dst = (raw_t*)a.dst + (((int64_t)z * a.Hd + h0) * a.Wd * a.C + c0) / 2 + (int64_t)w0 * ps;
+  if (ts < 0 || ts >= a.Tsrc) {                             // the reference's zero frames
+    const raw_t zero = Pair<T>::down(f32x2{0.f, 0.f});
+    for (int t = 0; t < nrows; ++t)
+#pragma unroll
+      for (int j = 0; j < WSEG; ++j)
+        if (w0 + j < a.Wd) dst[((int64_t)t * a.Wd + j) * ps] = zero;
+    return;
+  }
+  const raw_t* src = (const raw_t*)a.src + ((((int64_t)n * a.Tsrc + ts) * a.Hs) * a.Ws * a.C + c0) / 2;
+  const int ws0 = w0 * S - P;
+  unsigned cmask = 0;
+  int coloff[IW];
+#pragma unroll
+  for (int j = 0; j < IW; ++j) {
+    const int ws = ws0 + j;
+    cmask |= (ws >= 0 && ws < a.Ws) ? (1u << j) : 0u;
+    coloff[j] = min(max(ws, 0), a.Ws - 1) * ps;
+  }
+  float wt[2 * K * K];
+#pragma unroll
+  for (int i = 0; i < 2 * K * K; ++i) wt[i] = a.w[(int64_t)c0 * (K * K) + i];
+  f32x2 gs = {1.f, 1.f}, gh = {0.f, 0.f};
+  if (a.g_scale) gs = *reinterpret_cast<const f32x2*>(a.g_scale + (int64_t)n * a.C + c0);
+  if (a.g_shift) gh = *reinterpret_cast<const f32x2*>(a.g_shift + (int64_t)n * a.C + c0);
+
+  f32x2 win[K][IW];            // slot of input row i (relative to the band's first window row) = i mod K
+  raw_t raw[S][IW];            // the next step's new rows, in flight
+  const int hs_base = h0 * S - P;                           // input row of window row 0 (band_rows % K == 0)
+  auto load_row = [&](int hs, raw_t (&r)[IW]) {
+    const raw_t* base = src + (int64_t)min(max(hs, 0), a.Hs - 1) * a.Ws * ps;
+#pragma unroll
+    for (int j = 0; j < IW; ++j) r[j] = base[coloff[j]];
+  };
+  auto insert_row = [&](int hs, const raw_t (&r)[IW], f32x2 (&slot)[IW]) {
+    const bool rowok = hs >= 0 && hs < a.Hs;
+#pragma unroll
+    for (int j = 0; j < IW; ++j) {
+      const bool ok = rowok && ((cmask >> j) & 1u);
+      slot[j] = ok ? Pair<T>::up(r[j]) * gs + gh : f32x2{0.f, 0.f};
+    }
+  };
+  // first step: all K window rows
+  {
+    raw_t r0[K][IW];
+#pragma unroll
+    for (int kh = 0; kh < K; ++kh) load_row(hs_base + kh, r0[kh]);
+#pragma unroll
+    for (int kh = 0; kh < K; ++kh) insert_row(hs_base + kh, r0[kh], win[kh % K]);
+  }
+  if (nrows > 1) {
+#pragma unroll
+    for (int s = 0; s < S; ++s) load_row(hs_base + K + s, raw[s]);      // new rows of step 1: window rows K .. K+S-1
+  }
+  f32x2 psum = {0.f, 0.f};
+  for (int tk = 0; tk < nrows; tk += K) {
+#pragma unroll
+    for (int r = 0; r < K; ++r) {
+      const int t = tk + r;
+      if (t < nrows) {
+        // window rows of step t: t*S .. t*S+K-1; new ones (t > 0): t*S+K-S .. t*S+K-1
+        if (t > 0) {
+#pragma unroll
+          for (int s = 0; s < S; ++s) insert_row(hs_base + t * S + K - S + s, raw[s], win[(r * S + K - S + s) % K]);
+        }
+        if (t + 1 < nrows) {
+#pragma unroll
+          for (int s = 0; s < S; ++s) load_row(hs_base + (t + 1) * S + K - S + s, raw[s]);
+        }
+        raw_t* orow = dst + (int64_t)t * a.Wd * ps;
+#pragma unroll
+        for (int j = 0; j < WSEG; ++j) {
+          f32x2 acc = {0.f, 0.f};
+#pragma unroll
+          for (int kh = 0; kh < K; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw) {
+              const int tap = FLIP ? (K - 1 - kh) * K + (K - 1 - kw) : kh * K + kw;
+              acc += win[(r * S + kh) % K][j * S + kw] * f32x2{wt[tap], wt[K * K + tap]};
+            }
+          if (w0 + j < a.Wd) {
+            const raw_t o = Pair<T>::down(acc);
+            orow[(int64_t)j * ps] = o;
+            if (a.pool) psum += Pair<T>::up(o);
+          }
+        }
+      }
+    }
+  }
+  if (a.pool) {
+    atomicAdd(a.pool + (int64_t)n * a.C + c0, psum[0]);
+    atomicAdd(a.pool + (int64_t)n * a.C + c0 + 1, psum[1]);
+  }
+}
+
+struct RowsWgArgs {
+  const void* x;       // [N, Tsrc, Hs, Ws, C]
+  const void* dy;      // [N, Tdst, Hd, Wd, C]
+  float* dw;           // [C][K*K]
+  const float* g_scale;
+  const float* g_shift;
+  int N, C, Tsrc, Hs, Ws, Tdst, Hd, Wd, t_mul, t_off;
+  int nseg, nbands, band_rows, CP, FG;     // FG frame groups: a thread walks the frames z = fg, fg + FG, ...
+};
+
+// Weight gradient with the same thread layout: the k*k taps of the thread's two channels accumulate in
+// registers over all the frames of its group; at the end every wave transposes its block (64 channel pairs x
+// 2 x k*k floats, contiguous in dw) through LDS so that the atomics hit consecutive floats.
+template <typename T, int K, int S, int WSEG>
+__global__ __launch_bounds__(256) void dw_rows_wgrad_kernel(RowsWgArgs a) {
+  typedef typename Pair<T>::raw_t raw_t;
+  constexpr int P = K / 2;
+  constexpr int IW = (WSEG - 1) * S + K;
+  constexpr int KK = K * K;
+  __shared__ float red[4][64 * 2 * KK];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t gu = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int per_frame = a.CP * a.nseg;
+  const int64_t units = (int64_t)a.FG * a.nbands * per_frame;
+  const bool active = gu < units;
+  const int64_t guc = active ? gu : 0;
+  const int fb = (int)(guc / per_frame);                    // (frame group, band)
+  const int u = (int)(guc - (int64_t)fb * per_frame);
+  const int sg = u / a.CP, cp = u - sg * a.CP;
+  const int c0 = cp * 2;
+  const int fg = fb / a.nbands, band = fb - fg * a.nbands;
+  const int h0 = band * a.band_rows;
+  const int nrows = min(a.Hd, h0 + a.band_rows) - h0;
+  const int w0 = sg * WSEG;
+  const int ps = a.C / 2;
+  const int ws0 = w0 * S - P;
+  unsigned cmask = 0;
+  int coloff[IW];
+#pragma unroll
+  for (int j = 0; j < IW; ++j) {
+    const int ws = ws0 + j;
+    cmask |= (ws >= 0 && ws < a.Ws) ? (1u << j) : 0u;
+    coloff[j] = min(max(ws, 0), a.Ws - 1) * ps;
+  }
+  f32x2 acc[KK];
+#pragma unroll
+  for (int i = 0; i < KK; ++i) acc[i] = f32x2{0.f, 0.f};
+  const int hs_base = h0 * S - P;
+  const int nframes = a.N * a.Tdst;
+  if (active && nrows > 0) {
+    for (int z = fg; z < nframes; z += a.FG) {
+      const int n = z / a.Tdst, td = z - n * a.Tdst;
+      const int ts = td * a.t_mul + a.t_off;
+      if (ts < 0 || ts >= a.Tsrc) continue;                 // zero frames do not depend on x
+      const raw_t* xs = (const raw_t*)a.x + ((((int64_t)n * a.Tsrc + ts) * a.Hs) * a.Ws * a.C + c0) / 2;
+      const raw_t* gy = (const raw_t*)a.dy + (((int64_t)z * a.Hd + h0) * a.Wd * a.C + c0) / 2 + (int64_t)w0 * ps;
+      f32x2 gs = {1.f, 1.f}, gh = {0.f, 0.f};
+      if (a.g_scale) gs = *reinterpret_cast<const f32x2*>(a.g_scale + (int64_t)n * a.C + c0);
+      if (a.g_shift) gh = *reinterpret_cast<const f32x2*>(a.g_shift + (int64_t)n * a.C + c0);
+      f32x2 win[K][IW];
+      raw_t raw[S][IW], graw[WSEG];
+      auto load_row = [&](int hs, raw_t (&r)[IW]) {
+        const raw_t* base = xs + (int64_t)min(max(hs, 0), a.Hs - 1) * a.Ws * ps;
+#pragma unroll
+        for (int j = 0; j < IW; ++j) r[j] = base[coloff[j]];
+      };
+      auto insert_row = [&](int hs, const raw_t (&r)[IW], f32x2 (&slot)[IW]) {
+        const bool rowok = hs >= 0 && hs < a.Hs;
+#pragma unroll
+        for (int j = 0; j < IW; ++j) slot[j] = (rowok && ((cmask >> j) & 1u)) ? Pair<T>::up(r[j]) : f32x2{0.f, 0.f};
+      };
+      auto load_g = [&](int t) {
+        const raw_t* base = gy + (int64_t)t * a.Wd * ps;
+#pragma unroll
+        for (int j = 0; j < WSEG; ++j) graw[j] = base[(int64_t)min(j, a.Wd - 1 - w0) * ps];
+      };
+      {
+        raw_t r0[K][IW];
+#pragma unroll
+        for (int kh = 0; kh < K; ++kh) load_row(hs_base + kh, r0[kh]);
+        load_g(0);
+#pragma unroll
+        for (int kh = 0; kh < K; ++kh) insert_row(hs_base + kh, r0[kh], win[kh % K]);
+      }
+      if (nrows > 1) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) load_row(hs_base + K + s, raw[s]);
+      }
+      for (int tk = 0; tk < nrows; tk += K) {
+#pragma unroll
+        for (int r = 0; r < K; ++r) {
+          const int t = tk + r;
+          if (t < nrows) {
+            f32x2 g[WSEG];
+#pragma unroll
+            for (int j = 0; j < WSEG; ++j) g[j] = (w0 + j < a.Wd) ? Pair<T>::up(graw[j]) * gs + gh : f32x2{0.f, 0.f};
+            if (t > 0) {
+#pragma unroll
+              for (int s = 0; s < S; ++s) insert_row(hs_base + t * S + K - S + s, raw[s], win[(r * S + K - S + s) % K]);
+            }
+            if (t + 1 < nrows) {
+#pragma unroll
+              for (int s = 0; s < S; ++s) load_row(hs_base + (t + 1) * S + K - S + s, raw[s]);
+              load_g(t + 1);
+            }
+#pragma unroll
+            for (int kh = 0; kh < K; ++kh)
+#pragma unroll
+              for (int kw = 0; kw < K; ++kw)
+#pragma unroll
+                for (int j = 0; j < WSEG; ++j) acc[kh * K + kw] += g[j] * win[(r * S + kh) % K][j * S + kw];
+          }
+        }
+      }
+    }
+  }
+  // wave-private transposition: lane l holds the 2*KK consecutive floats [c0*KK, (c0+2)*KK) of dw
+  float* rw = red[wave];
+#pragma unroll
+  for (int i = 0; i < KK; ++i) {
+    rw[lane * 2 * KK + i] = acc[i][0];
+    rw[lane * 2 * KK + KK + i] = acc[i][1];
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  const int64_t gu0 = gu - lane;                            // unit of lane 0
+#pragma unroll
+  for (int k = 0; k < 2 * KK; ++k) {
+    const int e = lane + 64 * k;                            // element of the wave's block
+    const int l2 = e / (2 * KK), off = e - l2 * (2 * KK);   // source lane, offset inside its 2*KK floats
+    const int64_t g2 = gu0 + l2;
+    if (g2 < units) {
+      const int u2 = (int)(g2 % per_frame);
+      const int cp2 = u2 % a.CP;
+      const float v = rw[e];
+      if (v != 0.f) atomicAdd(a.dw + (int64_t)cp2 * 2 * KK + off, v);
+    }
+  }
+}
+
+// (K, S) -> segment width: the fp32 window K x ((WSEG-1)*S + K) x 2 must stay near 100 registers
+constexpr int wseg_of(int K, int S) { return K == 3 ? (S == 1 ? 14 : 7) : (S == 1 ? 7 : 4); }
+
+bool rows_ok(const pb_dwconv_shape* s) {
+  static const bool enabled = !(getenv("PB_DW_ROWS") && atoi(getenv("PB_DW_ROWS")) == 0);
+  static const int min_c = getenv("PB_DW_ROWS_MINC") ? atoi(getenv("PB_DW_ROWS_MINC")) : 64;
+  return enabled && s->kt == 1 && s->kh == s->kw && (s->kh == 3 || s->kh == 5) && s->sh == s->sw && (s->sh == 1 || s->sh == 2) &&
+         s->ph == s->kh / 2 && s->pw == s->kw / 2 && s->C % 2 == 0 && s->C >= min_c &&
+         s->Ho == (s->Hi + 2 * s->ph - s->kh) / s->sh + 1 && s->Wo == (s->Wi + 2 * s->pw - s->kw) / s->sw + 1 &&
+         (int64_t)s->Wi * s->C < (1 << 24);
+}
+
+template <typename T, int K, int S>
+int launch_rows_fwd(RowsArgs a, int flip, hipStream_t st) {
+  constexpr int WSEG = wseg_of(K, S);
+  a.CP = a.C / 2;
+  a.nseg = (int)pb_cdiv(a.Wd, WSEG);
+  const int64_t per_frame = (int64_t)a.CP * a.nseg;
+  const int64_t frames = (int64_t)a.N * a.Tdst;
+  // enough threads for ~8 waves per SIMD... bands of rows (multiples of K) when the frames alone are too few
+  int nbands = (int)pb_cdiv(160 * 1024, per_frame * frames);
+  const int max_bands = (int)pb_cdiv(a.Hd, 2 * K);
+  if (nbands > max_bands) nbands = max_bands;
+  if (nbands < 1) nbands = 1;
+  a.band_rows = (int)pb_cdiv(pb_cdiv(a.Hd, nbands), K) * K;
+  a.nbands = (int)pb_cdiv(a.Hd, a.band_rows);
+  const dim3 grid((unsigned)pb_cdiv(frames * a.nbands * per_frame, 256));
+  if (flip) hipLaunchKernelGGL((dw_rows_fwd_kernel<T, K, S, WSEG, true>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((dw_rows_fwd_kernel<T, K, S, WSEG, false>), grid, dim3(256), 0, st, a);
+  if (hipGetLastError() != hipSuccess) { pb_set_error("dw_rows forward launch failed"); return 1; }
+  return 0;
+}
+
+template <typename T, int K, int S>
+int launch_rows_wgrad(RowsWgArgs a, hipStream_t st) {
+  constexpr int WSEG = wseg_of(K, S);
+  a.CP = a.C / 2;
+  a.nseg = (int)pb_cdiv(a.Wd, WSEG);
+  const int64_t per_frame = (int64_t)a.CP * a.nseg;
+  const int64_t frames = (int64_t)a.N * a.Tdst;
+  // ~96K threads (6 waves per SIMD at most fit the registers anyway); row bands before frame groups, and at most
+  // 128 accumulating threads per filter tap (same-address float atomics serialise)
+  int nbands = 1;
+  const int max_bands = (int)pb_cdiv(a.Hd, 2 * K);
+  int64_t fgroups = pb_cdiv(96 * 1024, per_frame);
+  if (fgroups > frames) {
+    nbands = (int)pb_cdiv(fgroups, frames);
+    if (nbands > max_bands) nbands = max_bands;
+    fgroups = frames;
+  }
+  const int64_t writer_cap = pb_cdiv(128, (int64_t)a.nseg * nbands);
+  if (fgroups > writer_cap) fgroups = writer_cap;
+  if (fgroups < 1) fgroups = 1;
+  a.band_rows = (int)pb_cdiv(pb_cdiv(a.Hd, nbands), K) * K;
+  a.nbands = (int)pb_cdiv(a.Hd, a.band_rows);
+  a.FG = (int)fgroups;
+  const dim3 grid((unsigned)pb_cdiv(fgroups * a.nbands * per_frame, 256));
+  hipLaunchKernelGGL((dw_rows_wgrad_kernel<T, K, S, WSEG>), grid, dim3(256), 0, st, a);
+  if (hipGetLastError() != hipSuccess) { pb_set_error("dw_rows weight-gradient launch failed"); return 1; }
+  return 0;
+}
+
+}  // namespace
+
+bool pb_dw_rows_eligible(const pb_dwconv_shape* s, bool wgrad) {
+  // weight gradient: threads = channel pairs x (at most 128 accumulating writers per filter tap), so only wide
+  // layers fill the chip (measured: 1.3-1.45x over the tile kernel at C >= 480, far slower below)
+  static const int wg_min_c = getenv("PB_DW_ROWS_WGRAD_MINC") ? atoi(getenv("PB_DW_ROWS_WGRAD_MINC")) : 480;
+  return rows_ok(s) && (!wgrad || (s->C >= wg_min_c && s->sh == 1));
+}
+
+int pb_dw_rows_wgrad(const void* dy, const void* x, float* dw, const pb_dwconv_shape* s, pb_dtype dtype,
+                     const float* g_scale, const float* g_shift, hipStream_t st) {
+  if (!pb_dw_rows_eligible(s, true)) return -1;
+  RowsWgArgs a = {};
+  a.x = x; a.dy = dy; a.dw = dw; a.g_scale = g_scale; a.g_shift = g_shift;
+  a.N = s->N; a.C = s->C; a.Tsrc = s->Ti; a.Hs = s->Hi; a.Ws = s->Wi; a.Tdst = s->To; a.Hd = s->Ho; a.Wd = s->Wo;
+  a.t_mul = s->st; a.t_off = -s->pt;
+  const int K = s->kh, S = s->sh;
+#define PB_ROWSW(TT)                                                          \
+  do {                                                                        \
+    if (K == 3 && S == 1) return launch_rows_wgrad<TT, 3, 1>(a, st);          \
+    if (K == 3 && S == 2) return launch_rows_wgrad<TT, 3, 2>(a, st);          \
+    if (K == 5 && S == 1) return launch_rows_wgrad<TT, 5, 1>(a, st);          \
+    return launch_rows_wgrad<TT, 5, 2>(a, st);                                \
+  } while (0)
+  if (dtype == PB_BF16) PB_ROWSW(bf16_t);
+  PB_ROWSW(float);
+#undef PB_ROWSW
+}
+
+int pb_dw_rows_fwd(const void* src, const float* w, void* dst, const pb_dwconv_shape* s, pb_dtype dtype, int flip,
+                   const float* g_scale, const float* g_shift, float* pool, hipStream_t st) {
+  if (!rows_ok(s)) return -1;
+  PB_CHECK_ARG((int64_t)s->N * s->To * s->Ho * s->Wo * s->C < (1LL << 40), "dw_rows: tensor too large");
+  RowsArgs a = {};
+  a.src = src; a.dst = dst; a.w = w; a.g_scale = g_scale; a.g_shift = g_shift; a.pool = pool;
+  a.N = s->N; a.C = s->C; a.Tsrc = s->Ti; a.Hs = s->Hi; a.Ws = s->Wi; a.Tdst = s->To; a.Hd = s->Ho; a.Wd = s->Wo;
+  a.t_mul = s->st; a.t_off = -s->pt;
+  const int K = s->kh, S = s->sh;
+#define PB_ROWS(TT)                                                              \
+  do {                                                                           \
+    if (K == 3 && S == 1) return launch_rows_fwd<TT, 3, 1>(a, flip, st);         \
+    if (K == 3 && S == 2) return launch_rows_fwd<TT, 3, 2>(a, flip, st);         \
+    if (K == 5 && S == 1) return launch_rows_fwd<TT, 5, 1>(a, flip, st);         \
+    return launch_rows_fwd<TT, 5, 2>(a, flip, st);                               \
+  } while (0)
+  if (dtype == PB_BF16) PB_ROWS(bf16_t);
+  PB_ROWS(float);
+#undef PB_ROWS
+}

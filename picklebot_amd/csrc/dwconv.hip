@@ -803,6 +803,7 @@ extern "C" const char* pb_dwconv3d_kernel_name(const pb_dwconv_shape* s, pb_dtyp
   if (!s) return "";
   if (which == 0) {
     if (pb_dw7_eligible(s)) return "dw7_fwd_kernel";
+    if (pb_dw_rows_eligible(s, false)) return "dw_rows_fwd_kernel";
     if (pb_dw_tile_eligible(s, dtype, false)) return "dw_tile_fwd_kernel";
     return strip_ok(*s) ? "dw_strip_fwd_kernel" : "dw_gen_fwd_kernel";
   }
@@ -810,12 +811,14 @@ extern "C" const char* pb_dwconv3d_kernel_name(const pb_dwconv_shape* s, pb_dtyp
     if (bwd_is_s1_corr(*s)) {
       const pb_dwconv_shape c = bwd_corr_shape(*s);
       if (pb_dw7_eligible(&c)) return "dw7_fwd_kernel";
+      if (pb_dw_rows_eligible(&c, false)) return "dw_rows_fwd_kernel";
       return pb_dw_tile_eligible(&c, dtype, false) ? "dw_tile_fwd_kernel" : "dw_strip_fwd_kernel";
     }
     if (strip_ok(*s) && s->sh == 2 && s->ph == s->kh / 2) return "dw_strip_bwd_s2_kernel";
     return "dw_gen_bwd_data_kernel";
   }
   if (pb_dw7_eligible(s)) return "dw7_wgrad_kernel";
+  if (pb_dw_rows_eligible(s, true)) return "dw_rows_wgrad_kernel";
   if (pb_dw_tile_eligible(s, dtype, true)) return "dw_tile_wgrad_kernel";
   return strip_ok(*s) ? "dw_strip_wgrad_kernel" : "dw_gen_wgrad_kernel";
 }
@@ -829,6 +832,8 @@ extern "C" int pb_dwconv3d_fwd(const void* x, const float* w, void* y, const pb_
   hipStream_t st = (hipStream_t)stream;
   {
     int rc = pb_dw7_fwd(x, w, y, s, dtype, 0, nullptr, nullptr, pool, st);
+    if (rc >= 0) return rc;
+    rc = pb_dw_rows_fwd(x, w, y, s, dtype, 0, nullptr, nullptr, pool, st);
     if (rc >= 0) return rc;
     rc = pb_dw_tile_fwd(x, w, y, s, dtype, 0, nullptr, nullptr, pool, st);
     if (rc >= 0) return rc;
@@ -889,6 +894,8 @@ extern "C" int pb_dwconv3d_bwd_data(const void* dy, const float* w, void* dx, co
   if (bwd_is_s1_corr(*s)) {
     const pb_dwconv_shape c = bwd_corr_shape(*s);
     int rc = pb_dw7_fwd(dy, w, dx, &c, dtype, 1, g_scale, g_shift, nullptr, st);
+    if (rc >= 0) return rc;
+    rc = pb_dw_rows_fwd(dy, w, dx, &c, dtype, 1, g_scale, g_shift, nullptr, st);
     if (rc >= 0) return rc;
     rc = pb_dw_tile_fwd(dy, w, dx, &c, dtype, 1, g_scale, g_shift, nullptr, st);
     if (rc >= 0) return rc;
@@ -955,6 +962,8 @@ extern "C" int pb_dwconv3d_bwd_weight(const void* dy, const void* x, float* dw, 
   hipStream_t st = (hipStream_t)stream;
   {
     int rc = pb_dw7_wgrad(dy, x, dw, s, dtype, g_scale, g_shift, st);
+    if (rc >= 0) return rc;
+    rc = pb_dw_rows_wgrad(dy, x, dw, s, dtype, g_scale, g_shift, st);
     if (rc >= 0) return rc;
     rc = pb_dw_tile_wgrad(dy, x, dw, s, dtype, g_scale, g_shift, st);
     if (rc >= 0) return rc;
