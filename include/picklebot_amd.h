@@ -34,7 +34,7 @@ typedef enum {
   PB_ACT_HSIGMOID = 4, PB_ACT_SILU = 5
 } pb_act;
 
-#define PB_ABI_VERSION 5
+#define PB_ABI_VERSION 6
 
 /* Per-channel statistics buffers (`stats`, `sums` below) are PB_STAT_REPLICAS replicas of [2][C]
  * fp32, layout [replica][2][C], zero-filled by the caller.  A workgroup adds its partial sums into
@@ -211,9 +211,15 @@ int pb_bn_bwd_finalize(const float* sums, double count, const float* gamma, cons
                        int training, float* coefA, float* coefB, float* coefC, float* dgamma, float* dbeta,
                        int C, int device, void* stream);
 
-/* out = A[c]*g + B[c]*(z - mean[c]) + Cc[c]   (B, Cc, mean may be NULL) */
+/* out = A[c]*geff + B[c]*(z - mean[c]) + Cc[c],
+ *   geff = g * row_scale[m/rows_per_group, c] * act'((z - mean[c])*act_scale[c] + act_shift[c])
+ * (B, Cc, mean, row_scale, act_scale, act_shift may be NULL; act = PB_ACT_NONE: geff = g*row_scale).
+ * With the activation passed here, BatchNorm+activation backward reads the incoming gradient directly: the
+ * masked, activation-differentiated gradient is never materialised (pb_act_bwd_reduce with g_out = NULL
+ * supplies the two sums). */
 int pb_affine2(const void* g, const void* z, void* out, int64_t M, int C, pb_dtype dtype, const float* A,
-               const float* B, const float* Cc, const float* mean, int device, void* stream);
+               const float* B, const float* Cc, const float* mean, const float* row_scale, int64_t rows_per_group,
+               const float* act_scale, const float* act_shift, pb_act act, float slope, int device, void* stream);
 
 /* ---------------------------------------------------------------- squeeze-excite / pooling
  * SEBlock3D (mobilenet.py:11-26) and the classifier's AdaptiveAvgPool3d (mobilenet.py:186,252;

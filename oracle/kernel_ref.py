@@ -253,8 +253,19 @@ def bn_bwd_finalize(sums, count, gamma, mean, rstd, training, want_affine_grads)
             sg.float() if want_affine_grads else None)
 
 
-def affine2(g, z, A, B=None, Cc=None, mean=None):
-    out = g.float() * A
+def affine2(g, z, A, B=None, Cc=None, mean=None, row_scale=None, rows_per_group=0, act_scale=None, act_shift=None,
+            act="none", slope=0.0):
+    gf = g.float()
+    if row_scale is not None:
+        gf = gf * row_scale.repeat_interleave(rows_per_group, 0)
+    if act != "none":
+        pre = z.float() if mean is None else z.float() - mean
+        if act_scale is not None:
+            pre = pre * act_scale
+        if act_shift is not None:
+            pre = pre + act_shift
+        gf = gf * _act_grad(pre, act, slope)
+    out = gf * A
     if B is not None:
         zf = z.float() if mean is None else z.float() - mean
         out = out + zf * B

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libpicklebot_amd.so")
 
 PB_F32, PB_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY_RELU, ACT_HSWISH, ACT_HSIGMOID, ACT_SILU = range(6)
-ABI_VERSION = 5
+ABI_VERSION = 6
 STAT_REPLICAS = 16
 
 
@@ -48,7 +48,7 @@ SIGNATURES = {
     "pb_affine_act_fwd": [P, P, L, I, I, P, P, P, I, F, P, P, L, P, I, P],
     "pb_act_bwd_reduce": [P, P, P, L, I, I, P, P, I, F, P, L, L, F, P, P, P, I, P],
     "pb_bn_bwd_finalize": [P, D, P, P, P, I, P, P, P, P, P, I, I, P],
-    "pb_affine2": [P, P, P, L, I, I, P, P, P, P, I, P],
+    "pb_affine2": [P, P, P, L, I, I, P, P, P, P, P, L, P, P, I, F, I, P],
     "pb_rowgroup_reduce": [P, P, P, L, L, I, I, I, P],
     "pb_se_fc_fwd": [P, F, P, P, P, P, P, P, I, I, I, I, P],
     "pb_se_fc_bwd": [P, P, F, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P],

@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs a) {
             for (int i = 0; i < CH; ++i) vb[u][i] = 0.f;
           }
         }
-        if constexpr (MODE == 1 || MODE == 2) {
+        if constexpr (MODE == 1 || MODE == 2 || MODE == 3) {
 #pragma unroll
           for (int i = 0; i < CH; ++i) { rsc[u][i] = 1.f; rsh[u][i] = 0.f; }
           if (has_row) {
@@ -200,7 +200,11 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs a) {
             acc[0][i] += gr;
             acc[1][i] += gr * (vb[u][i] - mu[i]) * rs[i];
           } else {
-            vo[i] = kA[i] * va[u][i] + kB[i] * (vb[u][i] - mu[i]) + kC[i];
+            // g = dy * mask * act'((z - mean)*scale + shift) recomputed here when the caller passes the
+            // activation (BatchNorm backward then never materialises g)
+            const float zc = vb[u][i] - mu[i];
+            const float gg = va[u][i] * rsc[u][i] * act_bwd(zc * sc[i] + sh[i], a.act, a.slope);
+            vo[i] = kA[i] * gg + kB[i] * zc + kC[i];
           }
         }
         if constexpr (MODE != 0) {
@@ -440,14 +444,20 @@ extern "C" int pb_bn_bwd_finalize(const float* sums, double count, const float* 
 }
 
 extern "C" int pb_affine2(const void* g, const void* z, void* out, int64_t M, int C, pb_dtype dtype, const float* A,
-                          const float* B, const float* Cc, const float* mean, int device, void* stream) {
+                          const float* B, const float* Cc, const float* mean, const float* row_scale,
+                          int64_t rows_per_group, const float* act_scale, const float* act_shift, pb_act act,
+                          float slope, int device, void* stream) {
+  PB_CHECK_ARG(act == PB_ACT_NONE || z, "pb_affine2: an activation needs z");
   PB_CHECK_ARG(g && out && A, "pb_affine2: null pointer");
   PB_CHECK_ARG(z || !B, "pb_affine2: B given without z");
+  PB_CHECK_ARG(!row_scale || rows_per_group > 0, "pb_affine2: row_scale needs rows_per_group > 0");
   if (int rc = check_mc(M, C, dtype, "pb_affine2")) return rc;
   if (M == 0) return 0;
   PB_ENTER(device);
   EwArgs a = {};
-  a.a = g; a.b = z; a.out = out; a.M = M; a.C = C; a.cA = A; a.cB = B; a.cC = Cc; a.mean = mean; a.rows_per_group = 1;
+  a.a = g; a.b = z; a.out = out; a.M = M; a.C = C; a.cA = A; a.cB = B; a.cC = Cc; a.mean = mean;
+  a.row_scale = row_scale; a.rows_per_group = rows_per_group > 0 ? rows_per_group : 1;
+  a.scale = act_scale; a.shift = act_shift; a.act = (int)act; a.slope = slope;
   a.dy_mul = 1.f;
   launch_ew_dt<3>(a, dtype, (hipStream_t)stream);
   PB_LAUNCH_CHECK();

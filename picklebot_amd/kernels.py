@@ -515,17 +515,27 @@ def bn_bwd_finalize(sums, count, gamma, mean, rstd, training, want_affine_grads)
     return out[0], out[1], out[2], (out[3] if want_affine_grads else None), (out[4] if want_affine_grads else None)
 
 
-def affine2(g, z, A, B=None, Cc=None, mean=None):
+def affine2(g, z, A, B=None, Cc=None, mean=None, row_scale=None, rows_per_group=0, act_scale=None, act_shift=None,
+            act="none", slope=0.0):
+    """out = A*(g*row_scale*act'((z-mean)*act_scale+act_shift)) + B*(z - mean) + Cc."""
     _rows(g, "g")
     M, C = g.shape
+    if row_scale is not None:
+        if rows_per_group <= 0 or M % rows_per_group:
+            raise ValueError("affine2: rows_per_group must divide M")
+        _f32(row_scale, (M // rows_per_group, C), "row_scale")
     if z is not None:
         _rows(z, "z")
         if z.shape != g.shape or z.dtype != g.dtype:
             raise ValueError("affine2: g/z mismatch")
     _f32(A, (C,), "A"); _f32(B, (C,), "B"); _f32(Cc, (C,), "Cc"); _f32(mean, (C,), "mean")
+    _f32(act_scale, (C,), "act_scale"); _f32(act_shift, (C,), "act_shift")
+    if act != "none" and z is None:
+        raise ValueError("affine2: an activation needs z")
     out = torch.empty_like(g)
     dev, st = _dev_stream(g)
-    _launch("ew_kernel<affine2>", _nb(g, z, out), "pb_affine2", _p(g), _p(z), _p(out), M, C, _dt(g), _p(A), _p(B), _p(Cc), _p(mean), dev, st, detail=f"M{M} C{C}")
+    _launch("ew_kernel<affine2>", _nb(g, z, out), "pb_affine2", _p(g), _p(z), _p(out), M, C, _dt(g), _p(A), _p(B), _p(Cc), _p(mean), _p(row_scale),
+            int(rows_per_group), _p(act_scale), _p(act_shift), ACT[act], float(slope), dev, st, detail=f"M{M} C{C}")
     return out
 
 

@@ -266,6 +266,21 @@ def test_norm_act_family(K, M, C, G, dtype):
         check("bn_bwd_fin_" + n, a, b, torch.float32)
     A, B, Cc = fin_ref[:3]
     check("affine2", K.affine2(dev(g_ref), dev(x), dev(A), dev(B), dev(Cc), dev(mean)), R.affine2(g_ref, x, A, B, Cc, mean), dtype)
+    # the bottleneck's BatchNorm backward: sums without materialising g, mask applied by the final pass
+    sm_ref, sm = torch.zeros(R.REPL, 2, C), torch.zeros(R.REPL, 2, C, device=DEV)
+    assert R.act_bwd_reduce(dy, x, scale=scale, shift=shift, row_scale=rs, rows_per_group=M // G, mean=mean, rstd=rstd,
+                            sums=sm_ref, want_g=False) is None
+    assert K.act_bwd_reduce(dev(dy), dev(x), scale=dev(scale), shift=dev(shift), row_scale=dev(rs), rows_per_group=M // G,
+                            mean=dev(mean), rstd=dev(rstd), sums=sm, want_g=False) is None
+    check("act_bwd_sums_only", sm.sum(0), sm_ref.sum(0), dtype, 3.0)
+    check("affine2_masked", K.affine2(dev(dy), dev(x), dev(A), dev(B), dev(Cc), dev(mean), row_scale=dev(rs), rows_per_group=M // G),
+          R.affine2(dy, x, A, B, Cc, mean, row_scale=rs, rows_per_group=M // G), dtype)
+    for act in ("hardswish", "relu"):
+        check("affine2_act_" + act,
+              K.affine2(dev(dy), dev(x), dev(A), dev(B), dev(Cc), dev(mean), row_scale=dev(rs), rows_per_group=M // G,
+                        act_scale=dev(scale), act_shift=dev(shift), act=act, slope=0.01),
+              R.affine2(dy, x, A, B, Cc, mean, row_scale=rs, rows_per_group=M // G, act_scale=scale, act_shift=shift,
+                        act=act, slope=0.01), dtype)
     check("rowgroup_sum", K.rowgroup_reduce(dev(x), None, G), R.rowgroup_reduce(x, None, G), dtype)
     check("rowgroup_dot", K.rowgroup_reduce(dev(x), dev(dy), G), R.rowgroup_reduce(x, dy, G), dtype)
 
