@@ -151,14 +151,14 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs a) {
         } else {
           ld<T, CH>(A + off, va[u]);
         }
-        if constexpr (MODE == 2 || MODE == 3) {
+        if constexpr (MODE == 2 || MODE == 3 || MODE == 4) {
           if (B) ld<T, CH>(B + off, vb[u]);
           else {
 #pragma unroll
             for (int i = 0; i < CH; ++i) vb[u][i] = 0.f;
           }
         }
-        if constexpr (MODE == 1 || MODE == 2 || MODE == 3) {
+        if constexpr (MODE == 1 || MODE == 2 || MODE == 4) {
 #pragma unroll
           for (int i = 0; i < CH; ++i) { rsc[u][i] = 1.f; rsh[u][i] = 0.f; }
           if (has_row) {
@@ -200,11 +200,15 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs a) {
             acc[0][i] += gr;
             acc[1][i] += gr * (vb[u][i] - mu[i]) * rs[i];
           } else {
-            // g = dy * mask * act'((z - mean)*scale + shift) recomputed here when the caller passes the
-            // activation (BatchNorm backward then never materialises g)
-            const float zc = vb[u][i] - mu[i];
-            const float gg = va[u][i] * rsc[u][i] * act_bwd(zc * sc[i] + sh[i], a.act, a.slope);
-            vo[i] = kA[i] * gg + kB[i] * zc + kC[i];
+            if constexpr (MODE == 3) {
+              vo[i] = kA[i] * va[u][i] + kB[i] * (vb[u][i] - mu[i]) + kC[i];
+            } else {
+              // g = dy * mask * act'((z - mean)*scale + shift) recomputed here (BatchNorm backward then never
+              // materialises g)
+              const float zc = vb[u][i] - mu[i];
+              const float gg = va[u][i] * rsc[u][i] * act_bwd(zc * sc[i] + sh[i], a.act, a.slope);
+              vo[i] = kA[i] * gg + kB[i] * zc + kC[i];
+            }
           }
         }
         if constexpr (MODE != 0) {
@@ -213,7 +217,7 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs a) {
       }
     }
   }
-  if constexpr (MODE != 3) {
+  if constexpr (MODE != 3 && MODE != 4) {
     if (want_sums) {
       float* rep = a.sums + (size_t)((blockIdx.x + blockIdx.y) % PB_STAT_REPLICAS) * 2 * a.C;
       float* const outs[2] = {rep, rep + a.C};
@@ -459,7 +463,8 @@ extern "C" int pb_affine2(const void* g, const void* z, void* out, int64_t M, in
   a.row_scale = row_scale; a.rows_per_group = rows_per_group > 0 ? rows_per_group : 1;
   a.scale = act_scale; a.shift = act_shift; a.act = (int)act; a.slope = slope;
   a.dy_mul = 1.f;
-  launch_ew_dt<3>(a, dtype, (hipStream_t)stream);
+  if (row_scale || act != PB_ACT_NONE) launch_ew_dt<4>(a, dtype, (hipStream_t)stream);
+  else launch_ew_dt<3>(a, dtype, (hipStream_t)stream);
   PB_LAUNCH_CHECK();
   return 0;
 }

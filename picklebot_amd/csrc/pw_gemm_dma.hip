@@ -453,6 +453,16 @@ extern "C" int pb_pwconv_fwd_bf16w(const void* x, const void* wb, void* y, int64
   const int64_t total = a.n_tiles == 1 ? a.m_tiles : pb_cdiv(a.m_tiles, 8) * 8 * a.n_tiles;
   PB_CHECK_ARG(total <= 0x3fffffffLL, "pb_pwconv_fwd_bf16w: too many tiles");
   hipStream_t st = (hipStream_t)stream;
+  // narrow tiles (BN <= 96): a 2-stage ring leaves room for two workgroups per CU, whose epilogues overlap each
+  // other's streaming (measured -7 % on the family); wide tiles need the LDS for a 3-stage ring of one workgroup
+  static const int ns2 = getenv("PB_GEMM_DMA_NS2") ? atoi(getenv("PB_GEMM_DMA_NS2")) : 1;
+  if (ns2 && nt <= 6) {
+    if (nt == 2) launch_dma<2, 2>(a, total, device, st);
+    else if (nt == 4) launch_dma<4, 2>(a, total, device, st);
+    else launch_dma<6, 2>(a, total, device, st);
+    PB_LAUNCH_CHECK();
+    return 0;
+  }
   switch (nt) {
     case 2: launch_dma<2, 4>(a, total, device, st); break;
     case 4: launch_dma<4, 4>(a, total, device, st); break;
