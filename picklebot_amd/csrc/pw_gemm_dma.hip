@@ -67,7 +67,8 @@ __global__ __launch_bounds__(256) void pw_gemm_dma_kernel(DmaArgs a) {
   constexpr int WCH = NT / 2;                        // weight chunks (DMA instructions) per thread and stage
   constexpr int GPS = 4 + WCH;                       // DMA instructions per thread and stage
   constexpr int EPI_LD = BN + VEC;
-  constexpr int EPI_BYTES = 4 * 16 * EPI_LD * 2;
+  constexpr int ER = (NT >= 8 && NS == 2) ? 8 : 16;  // rows per epilogue pass (8: the staging tile halves, two workgroups fit a CU)
+  constexpr int EPI_BYTES = 4 * ER * EPI_LD * 2;
   extern __shared__ __attribute__((aligned(1024))) unsigned char dsmem[];
   unsigned char* ring = dsmem;                                   // [NS][A | W]
   T* epi_base = (T*)(dsmem + NS * STAGE);                        // [4 waves][16][EPI_LD]
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(256) void pw_gemm_dma_kernel(DmaArgs a) {
       int grp;
       panel(tile_mt(t), m0, mend, grp);
       const int n0 = tile_nt(t) * BN;
-      T* epi = epi_base + wave * 16 * EPI_LD;
+      T* epi = epi_base + wave * ER * EPI_LD;
       if (!plain) {
         if (n0 != osc_n0) {
           osc_n0 = n0;
@@ -276,34 +277,40 @@ __global__ __launch_bounds__(256) void pw_gemm_dma_kernel(DmaArgs a) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          const int n = n0 + j * 16 + ccol;
-          const bool nok = n < a.N;
+        for (int h = 0; h < 16 / ER; ++h) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int rl = rgrp * 4 + r;
-            const int64_t m = m0 + wave * 32 + i * 16 + rl;
-            const T tv = from_f32<T>(acc[i][j][r]);
-            epi[rl * EPI_LD + j * 16 + ccol] = tv;
-            if (a.stats && nok && m < mend) {
-              const float fv = to_f32(tv);
-              csum[j] += fv;
-              csq[j] += fv * fv;
+          for (int j = 0; j < NT; ++j) {
+            const int n = n0 + j * 16 + ccol;
+            const bool nok = n < a.N;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int rl = rgrp * 4 + r;
+              if (ER == 16 || rl / ER == h) {
+                const int64_t m = m0 + wave * 32 + i * 16 + rl;
+                const T tv = from_f32<T>(acc[i][j][r]);
+                epi[(rl % ER) * EPI_LD + j * 16 + ccol] = tv;
+                if (a.stats && nok && m < mend) {
+                  const float fv = to_f32(tv);
+                  csum[j] += fv;
+                  csq[j] += fv * fv;
+                }
+              }
             }
           }
-          acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // epi tiles are wave-private: no workgroup barrier
+          __builtin_amdgcn_wave_barrier();
+          constexpr int CPR = BN / VEC;
+          for (int f = lane; f < ER * CPR; f += 64) {
+            const int r = f / CPR, c = f - r * CPR;
+            const int64_t m = m0 + wave * 32 + i * 16 + h * ER + r;
+            const int n = n0 + c * VEC;
+            if (m < mend && n < a.N) vec_store<T>(a.Y + m * a.N + n, vec_load<T>(epi + r * EPI_LD + c * VEC));
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_wave_barrier();
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // epi tiles are wave-private: no workgroup barrier
-        __builtin_amdgcn_wave_barrier();
-        constexpr int CPR = BN / VEC;
-        for (int f = lane; f < 16 * CPR; f += 64) {
-          const int r = f / CPR, c = f - r * CPR;
-          const int64_t m = m0 + wave * 32 + i * 16 + r;
-          const int n = n0 + c * VEC;
-          if (m < mend && n < a.N) vec_store<T>(a.Y + m * a.N + n, vec_load<T>(epi + r * EPI_LD + c * VEC));
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
       if (a.stats && n_tiles > 1) flush_stats(n0);
       ks = 0;
@@ -382,7 +389,8 @@ int pick_nt_dma(int N) {
 template <int NT, int NS>
 int launch_dma(const DmaArgs& a, int64_t total, int device, hipStream_t st) {
   constexpr int BN = NT * 16;
-  constexpr size_t lds = (size_t)NS * (BM * 128 + BN * 128) + 4 * 16 * (BN + 8) * 2 + 4 * BN * 2 * 4;
+  constexpr int ER = (NT >= 8 && NS == 2) ? 8 : 16;
+  constexpr size_t lds = (size_t)NS * (BM * 128 + BN * 128) + 4 * ER * (BN + 8) * 2 + 4 * BN * 2 * 4;
   static int resident = 0;
   if (resident == 0) {
     (void)hipFuncSetAttribute((const void*)pw_gemm_dma_kernel<NT, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -460,6 +468,17 @@ extern "C" int pb_pwconv_fwd_bf16w(const void* x, const void* wb, void* y, int64
     if (nt == 2) launch_dma<2, 2>(a, total, device, st);
     else if (nt == 4) launch_dma<4, 2>(a, total, device, st);
     else launch_dma<6, 2>(a, total, device, st);
+    PB_LAUNCH_CHECK();
+    return 0;
+  }
+  static const int ns2w = getenv("PB_GEMM_DMA_NS2W") ? atoi(getenv("PB_GEMM_DMA_NS2W")) : 0;
+  if (ns2w == 1 && nt == 8) {
+    launch_dma<8, 2>(a, total, device, st);
+    PB_LAUNCH_CHECK();
+    return 0;
+  }
+  if (ns2w == 4 && nt == 8) {
+    launch_dma<8, 4>(a, total, device, st);
     PB_LAUNCH_CHECK();
     return 0;
   }

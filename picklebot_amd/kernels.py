@@ -150,15 +150,14 @@ _GEMM_DMA_ALL = os.environ.get("PB_GEMM_DMA_ALL", "0") != "0"
 
 
 def _dma_gemm_pays(M, K, N):
-    """Measured per layer on MI355X (MobileNetLarge3D, batch 32; tools/bench_ab.sh): the LDS-DMA ring GEMM (one
-    workgroup per CU) is 1.2-2.3x faster wherever a tile has several K stages or the matrix is small; the
-    register-staged kernel (three workgroups per CU) keeps the huge-M, single-stage early layers and the wide
-    outputs of short reductions (three or more column tiles re-reading X)."""
+    """Measured per layer on MI355X (MobileNetLarge3D, batch 32; tools/bench_ab.sh): the LDS-DMA ring GEMM wins
+    everywhere (1.1-2.3x) except on the K = 16 layers of the first stage, where a K stage is a quarter full and
+    the register-staged kernel's three workgroups per CU stream 4M rows at 3-3.4 TB/s."""
     if M <= 64:
         return False
     if _GEMM_DMA_ALL:
         return True
-    return M < 500_000 and (N <= 256 or K >= 160)
+    return K >= 24
 
 
 # bf16 weight copies live for one "weight scope" = one top-level module forward and its backward.  Version
