@@ -256,6 +256,27 @@ __global__ __launch_bounds__(256) void dw_rows_wgrad_kernel(RowsWgArgs a) {
       }
     }
   }
+  if (a.CP <= 256) {
+    // narrow layers: the whole [C][k*k] gradient fits the workgroup's LDS - every lane adds its taps there (lanes of
+    // different segments / bands / frame groups share channels), then ONE contiguous atomic pass per workgroup
+    float* ra = &red[0][0];
+    const int nall = 2 * a.CP * KK;
+    for (int i = threadIdx.x; i < nall; i += 256) ra[i] = 0.f;
+    __syncthreads();
+    if (active && nrows > 0) {
+#pragma unroll
+      for (int i = 0; i < KK; ++i) {
+        atomicAdd(&ra[c0 * KK + i], acc[i][0]);
+        atomicAdd(&ra[(c0 + 1) * KK + i], acc[i][1]);
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nall; i += 256) {
+      const float v = ra[i];
+      if (v != 0.f) atomicAdd(a.dw + i, v);
+    }
+    return;
+  }
   // wave-private transposition: lane l holds the 2*KK consecutive floats [c0*KK, (c0+2)*KK) of dw
   float* rw = red[wave];
 #pragma unroll
@@ -320,18 +341,20 @@ int launch_rows_wgrad(RowsWgArgs a, hipStream_t st) {
   a.nseg = (int)pb_cdiv(a.Wd, WSEG);
   const int64_t per_frame = (int64_t)a.CP * a.nseg;
   const int64_t frames = (int64_t)a.N * a.Tdst;
-  // ~96K threads (6 waves per SIMD at most fit the registers anyway); row bands before frame groups, and at most
+  // ~64K threads (the kernel's registers admit one wave per SIMD); row bands before frame groups, and at most
   // 128 accumulating threads per filter tap (same-address float atomics serialise)
   int nbands = 1;
   const int max_bands = (int)pb_cdiv(a.Hd, 2 * K);
-  int64_t fgroups = pb_cdiv(96 * 1024, per_frame);
+  int64_t fgroups = pb_cdiv(64 * 1024, per_frame);
   if (fgroups > frames) {
     nbands = (int)pb_cdiv(fgroups, frames);
     if (nbands > max_bands) nbands = max_bands;
     fgroups = frames;
   }
-  const int64_t writer_cap = pb_cdiv(128, (int64_t)a.nseg * nbands);
-  if (fgroups > writer_cap) fgroups = writer_cap;
+  if (a.CP > 256) {                 // (narrow layers reduce in LDS first: one atomic writer per workgroup)
+    const int64_t writer_cap = pb_cdiv(128, (int64_t)a.nseg * nbands);
+    if (fgroups > writer_cap) fgroups = writer_cap;
+  }
   if (fgroups < 1) fgroups = 1;
   a.band_rows = (int)pb_cdiv(pb_cdiv(a.Hd, nbands), K) * K;
   a.nbands = (int)pb_cdiv(a.Hd, a.band_rows);
@@ -345,10 +368,13 @@ int launch_rows_wgrad(RowsWgArgs a, hipStream_t st) {
 }  // namespace
 
 bool pb_dw_rows_eligible(const pb_dwconv_shape* s, bool wgrad) {
-  // weight gradient: threads = channel pairs x (at most 128 accumulating writers per filter tap), so only wide
-  // layers fill the chip (measured: 1.3-1.45x over the tile kernel at C >= 480, far slower below)
-  static const int wg_min_c = getenv("PB_DW_ROWS_WGRAD_MINC") ? atoi(getenv("PB_DW_ROWS_WGRAD_MINC")) : 480;
-  return rows_ok(s) && (!wgrad || (s->C >= wg_min_c && s->sh == 1));
+  // weight gradient, measured per layer on MI355X (MobileNetLarge3D, batch 32): this kernel wins on the wide layers
+  // (C >= 480: 1.3-1.7x over the tile kernel) and on frames of 28x28 outputs or more (1.4-2.1x); the tile kernel
+  // keeps the narrow 14x14 layers, the strip kernel the 112-wide inputs
+  static const bool all = getenv("PB_DW_ROWS_WGRAD_ALL") && atoi(getenv("PB_DW_ROWS_WGRAD_ALL")) != 0;
+  if (!rows_ok(s)) return false;
+  if (!wgrad || all) return true;
+  return s->C >= 480 || (s->Ho * s->Wo >= 28 * 28 && s->Wi < 112);
 }
 
 int pb_dw_rows_wgrad(const void* dy, const void* x, float* dw, const pb_dwconv_shape* s, pb_dtype dtype,
