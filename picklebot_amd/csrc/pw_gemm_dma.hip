@@ -373,11 +373,18 @@ __global__ __launch_bounds__(256) void pw_weight_prep_batch_kernel(const int64_t
   }
 }
 
-int pick_nt_dma(int N) {
+// column-tile width: padded MFMA width + 16 per tile (every extra tile re-reads the X panel through L2).  Only
+// tiles of <= 96 columns leave LDS for two workgroups per CU, whose epilogues overlap each other's streaming:
+// measured on the whole step (tools/bench_ab.sh) that beats the 128/192-wide tiles with a deeper ring for every
+// K (11.34 -> 11.06 ms/step), so the wide instantiations are only reachable through PB_GEMM_DMA_NARROWK.
+int pick_nt_dma(int N, int K) {
+  static const int narrow_k = getenv("PB_GEMM_DMA_NARROWK") ? atoi(getenv("PB_GEMM_DMA_NARROWK")) : 1 << 20;
+  static const int max_nt = getenv("PB_GEMM_DMA_MAXNT") ? atoi(getenv("PB_GEMM_DMA_MAXNT")) : 6;
   const int cand[5] = {2, 4, 6, 8, 12};
   int best = 2;
   int64_t best_cost = INT64_MAX;
   for (int c : cand) {
+    if (K <= narrow_k && c > max_nt) continue;
     const int bn = c * 16;
     const int64_t tiles = pb_cdiv(N, bn);
     const int64_t cost = tiles * bn + 16 * tiles;
@@ -456,7 +463,7 @@ extern "C" int pb_pwconv_fwd_bf16w(const void* x, const void* wb, void* y, int64
     a.w_group_stride = 0; a.rows_per_group = 0; a.panels_per_group = 0;
     a.m_tiles = (int)pb_cdiv(M, BM);
   }
-  const int nt = pick_nt_dma(N);
+  const int nt = pick_nt_dma(N, K);
   a.n_tiles = (int)pb_cdiv(N, nt * 16);
   const int64_t total = a.n_tiles == 1 ? a.m_tiles : pb_cdiv(a.m_tiles, 8) * 8 * a.n_tiles;
   PB_CHECK_ARG(total <= 0x3fffffffLL, "pb_pwconv_fwd_bf16w: too many tiles");
