@@ -5,6 +5,7 @@
 // bound by reading the clip and writing the 16-channel map, so it is a plain VALU stencil with
 // the (wave-uniform) filter broadcast from LDS.
 #include "pb_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -414,6 +415,150 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemArgs a) {
   }
 }
 
+// ----------------------------------------------------------------------------- 3-channel / stride-2 / kw=3 fast path
+// The reference stem (Conv3d(3, 16, 3, stride 2, padding 1) on an NDHWC bf16 clip, train.py:106).  An output pixel
+// wo reads input pixels 2wo-1 .. 2wo+1: per window row that is 9 contiguous bf16.  The generic kernels above gather
+// them element by element (8 ds_read_u16 + packing per MFMA fragment, 36 two-byte global loads per lane and item).
+// Here a window row is staged as 16-byte SLOTS, slot p = the 6 elements of input pixels (2p-1, 2p) + [one, zero]:
+//   * fill: one (unaligned) 12-byte global load + one ds_write_b128 per slot;
+//   * the 9 taps of output pixel p are slot p's elements 0..5 and slot p+1's elements 0..2, so the im2col matrix
+//     [pixel][8] of a (row, shift) pair IS a slot row: forward A fragments are one ds_read_b128 each, weight-
+//     gradient B fragments two transposing reads, in a K order of 18 groups of 8 (9 window rows x {shift 0, 1});
+//   * junk positions (elements 6..7 of shift 0 = the constant [1, 0]; elements 3..7 of shift 1 = the next pixel's
+//     data) meet zero weights in the forward and are never stored by the weight gradient - except element 6 of
+//     window row 0 (the ones), which carries the bias.
+constexpr int S3_SP = 34;             // slots per window row (32 outputs + shifted neighbour + 1)
+constexpr int S3_MAXROWS = 9;
+
+struct S3Geom {
+  int nrows, ti0, hi0, wi0;
+};
+
+// stage the window rows of output pixels [wo0, wo0+32) of output row (n, to, ho): all global loads first
+template <int DUMMY = 0>
+__device__ __forceinline__ void s3_fill(bf16_t* win, const bf16_t* x, const pb_stem_shape& s, int n, int to, int ho, int wo0,
+                                        int lane) {
+  const int nrows = s.kt * s.kh;
+  const int ti0 = to * s.st - s.pt, hi0 = ho * s.sh - s.ph, wi0 = wo0 * 2 - s.pw;
+  const bf16_t* xn = x + (int64_t)n * s.xs_n;
+  constexpr int NT = (S3_MAXROWS * S3_SP + 63) / 64;       // 5 slot tasks per lane
+  u32x4 v[NT];
+#pragma unroll
+  for (int k = 0; k < NT; ++k) {
+    const int t = lane + 64 * k;
+    const int r = t / S3_SP, sp = t - r * S3_SP;
+    const int at = r / s.kh, ah = r - at * s.kh;
+    const int ti = ti0 + at, hi = hi0 + ah;
+    const bool rowok = r < nrows && ti >= 0 && ti < s.Ti && hi >= 0 && hi < s.Hi;
+    const int wa = wi0 + 2 * sp, wb = wa + 1;
+    const bool oka = rowok && wa >= 0 && wa < s.Wi, okb = rowok && wb >= 0 && wb < s.Wi;
+    const bf16_t* p = xn + (int64_t)ti * s.xs_t + (int64_t)hi * s.xs_h + (int64_t)wa * 3;
+    u32x4 o = {0u, 0u, 0u, r == 0 ? 0x3f80u : 0u};        // element 6 = 1.0 on window row 0 (bias), element 7 = 0
+    if (oka && okb) {
+      typedef __attribute__((ext_vector_type(3))) unsigned u32x3;
+      const u32x3 q = *reinterpret_cast<const u32x3*>(p);  // 12 bytes at a 2-byte-aligned address
+      o[0] = q[0]; o[1] = q[1]; o[2] = q[2];
+    } else if (oka || okb) {
+      const unsigned short* ps = reinterpret_cast<const unsigned short*>(p);
+      unsigned e[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+      if (oka) { e[0] = ps[0]; e[1] = ps[1]; e[2] = ps[2]; }
+      if (okb) { e[3] = ps[3]; e[4] = ps[4]; e[5] = ps[5]; }
+      o[0] = e[0] | (e[1] << 16); o[1] = e[2] | (e[3] << 16); o[2] = e[4] | (e[5] << 16);
+    }
+    v[k] = o;
+  }
+#pragma unroll
+  for (int k = 0; k < NT; ++k) {
+    const int t = lane + 64 * k;
+    if (t < nrows * S3_SP) *reinterpret_cast<u32x4*>(win + t * 8) = v[k];
+  }
+}
+
+__global__ __launch_bounds__(256) void stem3_wgrad_kernel(StemArgs a) {
+  typedef bf16_t T;
+  __shared__ __attribute__((aligned(16))) T win_s[4][S3_MAXROWS * S3_SP * 8];
+  __shared__ __attribute__((aligned(16))) T dy_s[4][SW_PIX * OCB];
+  __shared__ float red[OCB * S3_MAXROWS * 16];
+  const pb_stem_shape& s = a.s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nrows = s.kt * s.kh, taps = nrows * 3, CT = 3 * taps;
+  const int oc0 = blockIdx.y * OCB;
+  const int wblocks = (s.Wo + SW_PIX - 1) / SW_PIX;
+  const int64_t nitems = (int64_t)s.N * s.To * s.Ho * wblocks;
+  const T* dy = (const T*)a.y;
+  const T* x = (const T*)a.x;
+  T* win = win_s[wave];
+  T* dyt = dy_s[wave];
+  f32x4 acc[S3_MAXROWS];
+#pragma unroll
+  for (int r = 0; r < S3_MAXROWS; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int g = lane >> 4, q = (lane & 15) >> 2, p4 = lane & 3;
+  // B fragment source of this lane inside a window row: slot (8g + q [+4]) + shift, element quad
+  const int boff = ((8 * g + q) + (p4 >> 1)) * 8 + (p4 & 1) * 4;
+
+  for (int64_t it = (int64_t)blockIdx.x * 4 + wave; it < nitems; it += (int64_t)gridDim.x * 4) {
+    int64_t rr = it;
+    const int wb = (int)(rr % wblocks); rr /= wblocks;
+    const int ho = (int)(rr % s.Ho); rr /= s.Ho;
+    const int to = (int)(rr % s.To);
+    const int n = (int)(rr / s.To);
+    const int wo0 = wb * SW_PIX;
+    const int npx = min(SW_PIX, s.Wo - wo0);
+    {
+      const int64_t pix0 = (((int64_t)n * s.To + to) * s.Ho + ho) * s.Wo + wo0;
+      for (int e = lane; e < SW_PIX * OCB / 8; e += 64) {
+        const int p = e * 8 / OCB;
+        vec_store<T>(dyt + e * 8, p < npx ? vec_load<T>(dy + pix0 * OCB + (int64_t)e * 8) : vec_zero<T>());
+      }
+    }
+    s3_fill(win, x, s, n, to, ho, wo0, lane);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    typedef __attribute__((address_space(3))) bf16x4* lds_p;
+    const bf16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(dyt + (8 * g + q) * OCB + 4 * p4));
+    const bf16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(dyt + (8 * g + 4 + q) * OCB + 4 * p4));
+    const bf16x8 fa = bf16x8{alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
+#pragma unroll
+    for (int r = 0; r < S3_MAXROWS; ++r) {
+      if (r < nrows) {
+        const bf16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(win + r * S3_SP * 8 + boff));
+        const bf16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(win + r * S3_SP * 8 + boff + 4 * 8));
+        const bf16x8 fb = bf16x8{blo[0], blo[1], blo[2], blo[3], bhi[0], bhi[1], bhi[2], bhi[3]};
+        acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc[r], 0, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  }
+  // D[oc][n] per window row: n < 6 -> tap (aw = n/3, ci = n%3); 8 <= n < 11 -> (aw = 2, ci = n-8); row 0, n = 6 -> bias
+  for (int i = tid; i < OCB * S3_MAXROWS * 16; i += 256) red[i] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < S3_MAXROWS; ++r)
+    if (r < nrows)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) atomicAdd(&red[((lane >> 4) * 4 + i) * (S3_MAXROWS * 16) + r * 16 + (lane & 15)], acc[r][i]);
+  __syncthreads();
+  for (int i = tid; i < OCB * (CT + 1); i += 256) {
+    const int oc = i / (CT + 1), c = i - oc * (CT + 1);
+    if (oc0 + oc >= s.Cout) continue;
+    if (c < CT) {
+      const int ci = c / taps, tp = c - ci * taps;
+      const int r = tp / 3, aw = tp - r * 3;
+      const int nn = aw < 2 ? aw * 3 + ci : 8 + ci;
+      atomicAdd(a.dw + (int64_t)(oc0 + oc) * CT + c, red[oc * (S3_MAXROWS * 16) + r * 16 + nn]);
+    } else if (a.dbias) {
+      atomicAdd(a.dbias + oc0 + oc, red[oc * (S3_MAXROWS * 16) + 6]);
+    }
+  }
+}
+
+bool stem3_ok(const pb_stem_shape* s, int x_dtype, pb_dtype dtype) {
+  static const bool enabled = !(getenv("PB_STEM3") && atoi(getenv("PB_STEM3")) == 0);
+  return enabled && x_dtype == 1 && dtype == PB_BF16 && s->Cin == 3 && s->kw == 3 && s->sw == 2 && s->pw == 1 &&
+         s->xs_c == 1 && s->xs_w == 3 && s->kt * s->kh <= S3_MAXROWS && s->Cout == OCB;
+}
+
 int check_stem(const pb_stem_shape* s, int x_dtype, pb_dtype dtype, const char* who) {
   PB_CHECK_ARG(s, "%s: null shape", who);
   PB_CHECK_ARG(s->N > 0 && s->Cin > 0 && s->Cout > 0 && s->Ti > 0 && s->Hi > 0 && s->Wi > 0 && s->To > 0 &&
@@ -485,7 +630,8 @@ extern "C" int pb_stem_conv3d_bwd_weight(const void* dy, const void* x, int x_dt
   int64_t gx = pb_cdiv(items, 4);
   if (gx > 1024) gx = 1024;
   dim3 grid((unsigned)gx, (unsigned)pb_cdiv(s->Cout, OCB));
-  PB_STEM_DISPATCH(stem_wgrad_kernel, grid);
+  if (stem3_ok(s, x_dtype, dtype)) hipLaunchKernelGGL(stem3_wgrad_kernel, grid, dim3(256), 0, st, a);
+  else PB_STEM_DISPATCH(stem_wgrad_kernel, grid);
   PB_LAUNCH_CHECK();
   return 0;
 }

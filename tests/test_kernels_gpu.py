@@ -184,6 +184,32 @@ def test_dwconv_temporal_growth_zero_frames(K):
     assert float(y[:, 2:4].abs().max()) > 0.0
 
 
+@pytest.mark.parametrize("kernel,stride,pad,bias", [((3, 3, 3), (2, 2, 2), (1, 1, 1), True), ((1, 3, 3), (1, 2, 2), (0, 1, 1), False),
+                                                    ((3, 3, 3), (1, 2, 2), (1, 1, 1), True)])
+def test_stem_bf16_wide_rows(K, kernel, stride, pad, bias):
+    """The reference's input format (bf16, channels-last-3d) on rows longer than one 32-pixel block: the
+    slot-staged stem kernels (interior 12-byte loads, block seams, right edge)."""
+    N, T, H, W, Cout = 2, 4, 9, 150, 16
+    base = torch.rand(N, T, H, W, 3, generator=torch.Generator().manual_seed(6)).to(torch.bfloat16)
+    x = base.permute(0, 4, 1, 2, 3)
+    w = rnd((Cout, 3, *kernel), seed=27, scale=0.2)
+    b = rnd((Cout,), seed=28, scale=0.1) if bias else None
+    st_ref, st = torch.zeros(R.REPL, 2, Cout), torch.zeros(R.REPL, 2, Cout, device=DEV)
+    y_ref = R.stem_fwd(x, w, b, kernel, stride, pad, torch.bfloat16, 1.0, st_ref)
+    xd = base.to(DEV).permute(0, 4, 1, 2, 3)
+    y = K.stem_fwd(xd, dev(w), dev(b), kernel, stride, pad, torch.bfloat16, 1.0, st)
+    check("stem_fwd_wide", y, y_ref, torch.bfloat16)
+    check("stem_stats_wide", st.sum(0), st_ref.sum(0), torch.bfloat16)
+    dy = rnd(tuple(y_ref.shape), torch.bfloat16, 29)
+    dw_ref, db_ref = torch.zeros_like(w), (torch.zeros(Cout) if bias else None)
+    R.stem_bwd_weight(dy, x, dw_ref, db_ref, kernel, stride, pad, 1.0)
+    dw, db = torch.zeros_like(w, device=DEV), (torch.zeros(Cout, device=DEV) if bias else None)
+    K.stem_bwd_weight(dev(dy), xd, dw, db, kernel, stride, pad, 1.0)
+    check("stem_dw_wide", dw, dw_ref, torch.bfloat16)
+    if bias:
+        check("stem_db_wide", db, db_ref, torch.bfloat16)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("xdtype,layout", [(torch.float32, "ndhwc"), (torch.bfloat16, "ndhwc"), (torch.uint8, "ndhwc"),
                                            (torch.float32, "ncdhw")])
