@@ -553,6 +553,109 @@ __global__ __launch_bounds__(256) void stem3_wgrad_kernel(StemArgs a) {
   }
 }
 
+// Forward on the same slot image: K runs over 18 groups of 8 (window row r, shift) = 144 (+16 zero) columns, an A
+// fragment (16 pixels x 8 columns of one group) is ONE ds_read_b128 per lane, the filter (with the bias on the ones
+// element) sits in registers for the whole walk.
+__global__ __launch_bounds__(256) void stem3_fwd_kernel(StemArgs a) {
+  typedef bf16_t T;
+  __shared__ __attribute__((aligned(16))) T win_s[4][S3_MAXROWS * S3_SP * 8];
+  __shared__ __attribute__((aligned(16))) T out_s[4][SW_PIX * OCB];
+  __shared__ float red[2 * OCB];
+  const pb_stem_shape& s = a.s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nrows = s.kt * s.kh, taps = nrows * 3, CT = 3 * taps;
+  const int wblocks = (s.Wo + SW_PIX - 1) / SW_PIX;
+  const int64_t nitems = (int64_t)s.N * s.To * s.Ho * wblocks;
+  const T* x = (const T*)a.x;
+  T* y = (T*)a.y;
+  T* win = win_s[wave];
+  T* outt = out_s[wave];
+  if (tid < 2 * OCB) red[tid] = 0.f;
+  __syncthreads();
+  const int row = lane & 15, g = lane >> 4;
+  constexpr int NKS = 5;                                   // 5 x 32 = 160 >= 18 groups x 8
+  bf16x8 wf[NKS];
+  int aoff[NKS];                                           // slot offset (elements) of this lane's group, pixel 0
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    const int grp = 4 * ks + g, r = grp >> 1, shift = grp & 1;
+    const bool gv = r < nrows;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float v = 0.f;
+      if (gv) {
+        if (shift == 0 && j < 6) v = a.w[(int64_t)row * CT + (j % 3) * taps + r * 3 + j / 3];
+        else if (shift == 0 && j == 6 && r == 0 && a.bias) v = a.bias[row];
+        else if (shift == 1 && j < 3) v = a.w[(int64_t)row * CT + j * taps + r * 3 + 2];
+      }
+      wf[ks][j] = (bf16_t)v;
+    }
+    aoff[ks] = ((gv ? r : 0) * S3_SP + shift) * 8;
+  }
+  float ssum = 0.f, ssq = 0.f;
+
+  for (int64_t it = (int64_t)blockIdx.x * 4 + wave; it < nitems; it += (int64_t)gridDim.x * 4) {
+    int64_t rr = it;
+    const int wb = (int)(rr % wblocks); rr /= wblocks;
+    const int ho = (int)(rr % s.Ho); rr /= s.Ho;
+    const int to = (int)(rr % s.To);
+    const int n = (int)(rr / s.To);
+    const int wo0 = wb * SW_PIX;
+    const int npx = min(SW_PIX, s.Wo - wo0);
+    s3_fill(win, x, s, n, to, ho, wo0, lane);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    f32x4 acc[2];
+    acc[0] = acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const bf16x8 fa = *reinterpret_cast<const bf16x8*>(win + aoff[ks] + (mt * 16 + row) * 8);
+        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, wf[ks], acc[mt], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int p = mt * 16 + g * 4 + i;
+        const T tv = from_f32<T>(acc[mt][i]);
+        outt[p * OCB + row] = tv;
+        if (a.stats && p < npx) {
+          const float fv = to_f32(tv);
+          ssum += fv;
+          ssq += fv * fv;
+        }
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    {
+      const int64_t pix0 = (((int64_t)n * s.To + to) * s.Ho + ho) * s.Wo + wo0;
+      for (int e = lane; e < SW_PIX * OCB / 8; e += 64) {
+        const int p = e * 8 / OCB;
+        if (p < npx) vec_store<T>(y + pix0 * OCB + (int64_t)e * 8, vec_load<T>(outt + e * 8));
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (a.stats) {
+    ssum += __shfl_xor(ssum, 16, 64); ssum += __shfl_xor(ssum, 32, 64);
+    ssq += __shfl_xor(ssq, 16, 64); ssq += __shfl_xor(ssq, 32, 64);
+    if (lane < 16) {
+      atomicAdd(&red[lane], ssum);
+      atomicAdd(&red[OCB + lane], ssq);
+    }
+    __syncthreads();
+    if (tid < OCB) {
+      float* st = a.stats + (size_t)(blockIdx.x % PB_STAT_REPLICAS) * 2 * s.Cout;
+      atomicAdd(st + tid, red[tid]);
+      atomicAdd(st + s.Cout + tid, red[OCB + tid]);
+    }
+  }
+}
+
 bool stem3_ok(const pb_stem_shape* s, int x_dtype, pb_dtype dtype) {
   static const bool enabled = !(getenv("PB_STEM3") && atoi(getenv("PB_STEM3")) == 0);
   return enabled && x_dtype == 1 && dtype == PB_BF16 && s->Cin == 3 && s->kw == 3 && s->sw == 2 && s->pw == 1 &&
@@ -604,7 +707,8 @@ extern "C" int pb_stem_conv3d_fwd(const void* x, int x_dtype, float x_scale, con
     int64_t gx = pb_cdiv(items, 4);
     if (gx > 2048) gx = 2048;
     dim3 grid((unsigned)gx, (unsigned)pb_cdiv(s->Cout, OCB));
-    PB_STEM_DISPATCH(stem_fwd_mfma_kernel, grid);
+    if (stem3_ok(s, x_dtype, dtype) && x_scale == 1.f) hipLaunchKernelGGL(stem3_fwd_kernel, grid, dim3(256), 0, st, a);
+    else PB_STEM_DISPATCH(stem_fwd_mfma_kernel, grid);
   } else {
     dim3 grid((unsigned)pb_cdiv(a.npix, 256), (unsigned)pb_cdiv(s->Cout, OCB));
     PB_STEM_DISPATCH(stem_fwd_kernel, grid);
@@ -630,7 +734,7 @@ extern "C" int pb_stem_conv3d_bwd_weight(const void* dy, const void* x, int x_dt
   int64_t gx = pb_cdiv(items, 4);
   if (gx > 1024) gx = 1024;
   dim3 grid((unsigned)gx, (unsigned)pb_cdiv(s->Cout, OCB));
-  if (stem3_ok(s, x_dtype, dtype)) hipLaunchKernelGGL(stem3_wgrad_kernel, grid, dim3(256), 0, st, a);
+  if (stem3_ok(s, x_dtype, dtype) && x_scale == 1.f) hipLaunchKernelGGL(stem3_wgrad_kernel, grid, dim3(256), 0, st, a);
   else PB_STEM_DISPATCH(stem_wgrad_kernel, grid);
   PB_LAUNCH_CHECK();
   return 0;

@@ -409,6 +409,16 @@ def _stem_shape(x, cout, out_thw, kernel, stride, pad):
     return s
 
 
+def _stem_kernel_name(what, x, cout, kernel, stride, pad, dtype, x_scale):
+    """Mirror of stem3_ok() in csrc/stem.hip (profiling labels only)."""
+    fast = (x.dtype == torch.bfloat16 and dtype == torch.bfloat16 and x.shape[1] == 3 and kernel[2] == 3 and stride[2] == 2
+            and pad[2] == 1 and x.stride(1) == 1 and x.stride(4) == 3 and kernel[0] * kernel[1] <= 9 and cout == 16
+            and x_scale == 1.0)
+    if what == "fwd":
+        return "stem3_fwd_kernel" if fast else "stem_fwd_mfma_kernel"
+    return "stem3_wgrad_kernel" if fast else "stem_wgrad_kernel"
+
+
 def stem_fwd(x, w, bias, kernel, stride, pad, out_dtype, x_scale=1.0, stats=None):
     """x logical (N,Cin,T,H,W), any strides, float32/bfloat16/uint8 -> y [N,To,Ho,Wo,Cout] in out_dtype."""
     if x.dim() != 5 or x.dtype not in _XDT:
@@ -419,7 +429,7 @@ def stem_fwd(x, w, bias, kernel, stride, pad, out_dtype, x_scale=1.0, stats=None
     y = torch.empty((x.shape[0],) + out + (cout,), dtype=out_dtype, device=x.device)
     s = _stem_shape(x, cout, out, kernel, stride, pad)
     dev, st = _dev_stream(x)
-    _launch("stem_fwd_mfma_kernel", _nb(x, y, w), "pb_stem_conv3d_fwd", _p(x), _XDT[x.dtype], float(x_scale), _p(w), _p(bias), _p(y), ctypes.byref(s),
+    _launch(_stem_kernel_name("fwd", x, w.shape[0], kernel, stride, pad, out_dtype, x_scale), _nb(x, y, w), "pb_stem_conv3d_fwd", _p(x), _XDT[x.dtype], float(x_scale), _p(w), _p(bias), _p(y), ctypes.byref(s),
             _dt(y), _p(stats), dev, st)
     return y
 
@@ -430,7 +440,7 @@ def stem_bwd_weight(dy, x, dw, dbias, kernel, stride, pad, x_scale=1.0):
     _f32(dw, (cout, x.shape[1], *kernel), "dw"); _f32(dbias, (cout,), "dbias")
     s = _stem_shape(x, cout, tuple(dy.shape[1:4]), kernel, stride, pad)
     dev, st = _dev_stream(dy)
-    _launch("stem_wgrad_kernel", _nb(dy, x, dw), "pb_stem_conv3d_bwd_weight", _p(dy), _p(x), _XDT[x.dtype], float(x_scale), _p(dw), _p(dbias),
+    _launch(_stem_kernel_name("wgrad", x, dw.shape[0], kernel, stride, pad, dy.dtype, x_scale), _nb(dy, x, dw), "pb_stem_conv3d_bwd_weight", _p(dy), _p(x), _XDT[x.dtype], float(x_scale), _p(dw), _p(dbias),
             ctypes.byref(s), _dt(dy), dev, st)
     return dw
 
