@@ -75,11 +75,15 @@ def main():
     from picklebot_amd import kernels as K
     from picklebot_amd.parallel import GradReducer, setup_distributed
 
+    if os.environ.get("PB_BENCH_FORCE_DP") and "RANK" not in os.environ:
+        # exercise the data-parallel code path (process group, bucketed reducer, graph + eager all-reduce) on one GPU
+        os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29517")
+    dp_path = "RANK" in os.environ and ("PB_BENCH_FORCE_DP" in os.environ or int(os.environ.get("WORLD_SIZE", "1")) > 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
-    local_rank, rank, _ = setup_distributed("nccl") if world > 1 else (0, 0, 1)
+    local_rank, rank, _ = setup_distributed("nccl") if dp_path else (0, 0, 1)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
@@ -87,8 +91,8 @@ def main():
     model = picklebot_amd.MobileNetLarge3D(NCLS).to(device)
     model.initialize_weights()                                # train.py:177 (a no-op for this model)
     model.train()
-    reducer = GradReducer(model) if world > 1 else None
-    use_graph = world == 1 and not args.no_graph
+    reducer = GradReducer(model) if dp_path else None
+    use_graph = not dp_path and not args.no_graph
     opt = torch.optim.AdamW(model.parameters(), lr=3e-4, weight_decay=5e-4, fused=True, capturable=use_graph)
     x, y = synthetic_batch(args.batch, device, 1234 + rank)
 
@@ -106,9 +110,25 @@ def main():
         return loss
 
     def sync():
-        if world > 1:
+        if dp_path:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def capture(fn):
+        """Warm up on a side stream, then capture fn() into a HIP graph; returns (graph, fn's result)."""
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        K.reset_zero_arena()              # the zero-filled scratch must be allocated AND filled inside the graph
+        with torch.cuda.graph(g):
+            out = fn()
+        K.reset_zero_arena()
+        return g, out
 
     # One training step = ~340 kernel launches through ctypes (6-8 ms of host time on a quiet box, 20+ ms on a
     # busy one, against ~12 ms of GPU work): on one GPU the whole step (forward, loss, backward, fused AdamW) is
@@ -117,25 +137,41 @@ def main():
     eager_step = step
     if use_graph:
         try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(3):
-                    step()
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
             opt.zero_grad(set_to_none=True)
-            K.reset_zero_arena()          # the zero-filled scratch must be allocated AND filled inside the graph
-            with torch.cuda.graph(graph):
-                graph_loss = step()
-            K.reset_zero_arena()
+            graph, graph_loss = capture(step)
 
             def step():  # noqa: F811
                 graph.replay()
                 return graph_loss
             launch_mode = "hipgraph"
         except Exception as e:  # capture is an optimisation: fall back to eager submission
+            print(f"[bench] HIP graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            torch.cuda.synchronize()
+            K.reset_zero_arena()
+            step = eager_step
+    elif dp_path and not args.no_graph:
+        # data parallel: forward + backward (gradients accumulate into the reducer's flat buckets, exchange hooks off)
+        # replayed from a HIP graph; then the 3 bucket all-reduces over RCCL and the fused optimiser, eagerly.  The
+        # exchange no longer overlaps backward (16.8 MB: a few hundred microseconds over xGMI), in return the ranks
+        # are not bound by 8 ms of Python launch overhead each.
+        try:
+            def fwd_bwd():
+                reducer.zero_grad()
+                with reducer.no_sync():
+                    with torch.autocast("cuda", dtype=torch.bfloat16):
+                        loss = torch.nn.functional.cross_entropy(model(x).float(), y)
+                    loss.backward()
+                return loss
+            step()                                            # creates the RCCL communicator outside any capture
+            graph, graph_loss = capture(fwd_bwd)
+
+            def step():  # noqa: F811
+                graph.replay()
+                reducer.reduce_now()
+                opt.step()
+                return graph_loss
+            launch_mode = "hipgraph(fwd+bwd) + eager all-reduce/optimizer"
+        except Exception as e:
             print(f"[bench] HIP graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
             torch.cuda.synchronize()
             K.reset_zero_arena()
@@ -149,7 +185,7 @@ def main():
     host_enqueue_ms = (time.perf_counter() - t0) / args.steps * 1e3     # host time to submit a step (GPU runs behind)
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dp_path:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -160,6 +196,15 @@ def main():
     roofline, families = None, {}
     if rank == 0:
         prof_step = eager_step                                              # HIP events need eager launches
+        if dp_path:
+            def prof_step():      # rank 0 profiles alone: no collective may be issued here (the other ranks are waiting)
+                reducer.zero_grad()
+                with reducer.no_sync():
+                    with torch.autocast("cuda", dtype=torch.bfloat16):
+                        loss = torch.nn.functional.cross_entropy(model(x).float(), y)
+                    loss.backward()
+                opt.step()
+                return loss
         K.start_profile()
         for _ in range(args.steps):
             prof_step()
@@ -194,7 +239,7 @@ def main():
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "bytes_per_launch": int(d["bytes"] / d["launches"]), "avg_launch_us": round(d["ms"] / d["launches"] * 1e3, 2),
                     "launches": d["launches"], "measured_over": f"{args.steps} steps re-run with HIP events around every launch"}
-    if world > 1:
+    if dp_path:
         dist.barrier()
 
     if rank == 0:
@@ -215,7 +260,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
-    if world > 1:
+    if dp_path:
         dist.destroy_process_group()
 
 

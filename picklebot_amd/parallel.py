@@ -102,6 +102,16 @@ class GradReducer:
         self._pending = []
         self._ready = [0] * len(self.buckets)
 
+    def reduce_now(self):
+        """All-reduce (and average) every bucket on the spot, stream-ordered behind whatever filled them - for steps
+        whose backward ran with the hooks off (e.g. replayed from a HIP graph captured under no_sync())."""
+        for flat in self.flat:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            if self.average and self.world > 1:
+                flat.mul_(1.0 / self.world)
+        self._pending = []
+        self._ready = [0] * len(self.buckets)
+
     @contextlib.contextmanager
     def no_sync(self):
         old, self._enabled = self._enabled, False
