@@ -35,6 +35,29 @@ __device__ __forceinline__ void ld(const T* p, float (&o)[CH]) {
     for (int i = 0; i < CH; ++i) o[i] = to_f32(p[i]);
   }
 }
+// A row chunk kept as loaded (16 bytes) until it is consumed: converting at load time would hold CH floats per
+// in-flight row in registers (64 VGPRs for 4 rows x 2 tensors of bf16)
+template <typename T, int CH, bool VECTOR = (CH == ElemTraits<T>::VEC)>
+struct RawRow {
+  float f[CH];
+  __device__ __forceinline__ void load(const T* p) {
+#pragma unroll
+    for (int i = 0; i < CH; ++i) f[i] = to_f32(p[i]);
+  }
+  __device__ __forceinline__ void zero() {
+#pragma unroll
+    for (int i = 0; i < CH; ++i) f[i] = 0.f;
+  }
+  __device__ __forceinline__ float get(int i) const { return f[i]; }
+};
+template <typename T, int CH>
+struct RawRow<T, CH, true> {
+  Vec16<T> v;
+  __device__ __forceinline__ void load(const T* p) { v = vec_load<T>(p); }
+  __device__ __forceinline__ void zero() { v = vec_zero<T>(); }
+  __device__ __forceinline__ float get(int i) const { return v.get(i); }
+};
+
 template <typename T, int CH>
 __device__ __forceinline__ void stv(T* p, const float (&o)[CH]) {
   if constexpr (CH == ElemTraits<T>::VEC) {
@@ -136,8 +159,15 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs a) {
     const int64_t rows_wg = (a.M + gridDim.x - 1) / gridDim.x;
     const int64_t mlo = (int64_t)blockIdx.x * rows_wg, mhi = min(a.M, mlo + rows_wg);
     const bool has_row = a.row_scale || a.row_shift;
+    // per-clip row scale / shift (dropout mask, SE terms): a thread's rows only ever move forward, so the vectors
+    // are re-read when a row crosses into the next clip, not per row (they used to cost 64 registers and 4 integer
+    // divisions per iteration: 155-169 VGPRs = 2-3 waves per SIMD on these streaming kernels)
+    float rsc[CH], rsh[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) { rsc[i] = 1.f; rsh[i] = 0.f; }
+    int64_t g_end = -1;                                     // first row of the next clip (-1: nothing loaded yet)
     for (int64_t mb = mlo + p; mb < mhi; mb += (int64_t)UNR * mp.P) {
-      float va[UNR][CH], vb[UNR][CH], rsc[UNR][CH], rsh[UNR][CH];
+      RawRow<T, CH> ra[UNR], rb[UNR];
       bool ok[UNR];
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
@@ -146,67 +176,68 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs a) {
         const int64_t mc = ok[u] ? m : mlo + p;          // shadow a valid row, discard later
         const int64_t off = mc * a.C + c0;
         if constexpr (MODE == 2) {
-          if (a.dy_rows_per_group > 0) ld<T, CH>(A + (int64_t)((uint32_t)mc / (uint32_t)a.dy_rows_per_group) * a.C + c0, va[u]);
-          else ld<T, CH>(A + off, va[u]);
+          if (a.dy_rows_per_group > 0) ra[u].load(A + (int64_t)((uint32_t)mc / (uint32_t)a.dy_rows_per_group) * a.C + c0);
+          else ra[u].load(A + off);
         } else {
-          ld<T, CH>(A + off, va[u]);
+          ra[u].load(A + off);
         }
         if constexpr (MODE == 2 || MODE == 3 || MODE == 4) {
-          if (B) ld<T, CH>(B + off, vb[u]);
-          else {
-#pragma unroll
-            for (int i = 0; i < CH; ++i) vb[u][i] = 0.f;
-          }
-        }
-        if constexpr (MODE == 1 || MODE == 2 || MODE == 4) {
-#pragma unroll
-          for (int i = 0; i < CH; ++i) { rsc[u][i] = 1.f; rsh[u][i] = 0.f; }
-          if (has_row) {
-            const int64_t grp = (int64_t)((uint32_t)mc / (uint32_t)a.rows_per_group);
-            if (a.row_scale) {
-              const float* rp = a.row_scale + grp * a.C + c0;
-#pragma unroll
-              for (int i = 0; i < CH; ++i) rsc[u][i] = rp[i];
-            }
-            if (a.row_shift) {
-              const float* rq = a.row_shift + grp * a.C + c0;
-#pragma unroll
-              for (int i = 0; i < CH; ++i) rsh[u][i] = rq[i];
-            }
-          }
+          if (B) rb[u].load(B + off);
+          else rb[u].zero();
         }
       }
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
         if (!ok[u]) continue;
-        const int64_t off = (mb + (int64_t)u * mp.P) * a.C + c0;
+        const int64_t m_u = mb + (int64_t)u * mp.P;
+        const int64_t off = m_u * a.C + c0;
+        if constexpr (MODE == 1 || MODE == 2 || MODE == 4) {
+          if (has_row && (g_end < 0 || m_u >= g_end)) {
+            const int64_t grp = (int64_t)((uint32_t)m_u / (uint32_t)a.rows_per_group);
+            g_end = (grp + 1) * a.rows_per_group;
+            if (a.row_scale) {
+              const float* rp = a.row_scale + grp * a.C + c0;
+#pragma unroll
+              for (int i = 0; i < CH; ++i) rsc[i] = rp[i];
+            }
+            if (a.row_shift) {
+              const float* rq = a.row_shift + grp * a.C + c0;
+#pragma unroll
+              for (int i = 0; i < CH; ++i) rsh[i] = rq[i];
+            }
+          }
+        }
         float vo[CH];
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
+          const float va_ = ra[u].get(i);
+          float vb_ = 0.f;
+          if constexpr (MODE == 2 || MODE == 3 || MODE == 4) vb_ = rb[u].get(i);
+          (void)vb_;
           if constexpr (MODE == 0) {
-            acc[0][i] += va[u][i];
-            acc[1][i] += va[u][i] * va[u][i];
+            acc[0][i] += va_;
+            acc[1][i] += va_ * va_;
           } else if constexpr (MODE == 1) {
-            const float y = act_fwd((va[u][i] - mu[i]) * sc[i] + sh[i], a.act, a.slope) * rsc[u][i] + rsh[u][i];
+            const float y = act_fwd((va_ - mu[i]) * sc[i] + sh[i], a.act, a.slope) * rsc[i] + rsh[i];
             vo[i] = y;
             const float yr = to_f32(from_f32<T>(y));
             acc[0][i] += yr;
             acc[1][i] += yr * yr;
           } else if constexpr (MODE == 2) {
-            const float pre = (vb[u][i] - mu[i]) * sc[i] + sh[i];
-            const float g = va[u][i] * a.dy_mul * rsc[u][i] * act_bwd(pre, a.act, a.slope);
+            const float pre = (vb_ - mu[i]) * sc[i] + sh[i];
+            const float g = va_ * a.dy_mul * rsc[i] * act_bwd(pre, a.act, a.slope);
             vo[i] = g;
             const float gr = O ? to_f32(from_f32<T>(g)) : g;
             acc[0][i] += gr;
-            acc[1][i] += gr * (vb[u][i] - mu[i]) * rs[i];
+            acc[1][i] += gr * (vb_ - mu[i]) * rs[i];
           } else {
             if constexpr (MODE == 3) {
-              vo[i] = kA[i] * va[u][i] + kB[i] * (vb[u][i] - mu[i]) + kC[i];
+              vo[i] = kA[i] * va_ + kB[i] * (vb_ - mu[i]) + kC[i];
             } else {
               // g = dy * mask * act'((z - mean)*scale + shift) recomputed here (BatchNorm backward then never
               // materialises g)
-              const float zc = vb[u][i] - mu[i];
-              const float gg = va[u][i] * rsc[u][i] * act_bwd(zc * sc[i] + sh[i], a.act, a.slope);
+              const float zc = vb_ - mu[i];
+              const float gg = va_ * rsc[i] * act_bwd(zc * sc[i] + sh[i], a.act, a.slope);
               vo[i] = kA[i] * gg + kB[i] * zc + kC[i];
             }
           }
