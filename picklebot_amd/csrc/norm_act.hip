@@ -4,6 +4,7 @@
 // is one contiguous span; per-channel sums are reduced thread -> LDS -> one atomic per workgroup
 // and channel.
 #include "pb_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -166,6 +167,11 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs a) {
 #pragma unroll
     for (int i = 0; i < CH; ++i) { rsc[i] = 1.f; rsh[i] = 0.f; }
     int64_t g_end = -1;                                     // first row of the next clip (-1: nothing loaded yet)
+    // the activation is a compile-time constant inside the row loop (one uniform dispatch per kernel instead of a
+    // switch per element in the unrolled body)
+    auto run = [&](auto act_tag) {
+    constexpr int ACT_C = decltype(act_tag)::value;
+    const int act_ = ACT_C >= 0 ? ACT_C : a.act;
     for (int64_t mb = mlo + p; mb < mhi; mb += (int64_t)UNR * mp.P) {
       RawRow<T, CH> ra[UNR], rb[UNR];
       bool ok[UNR];
@@ -218,14 +224,14 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs a) {
             acc[0][i] += va_;
             acc[1][i] += va_ * va_;
           } else if constexpr (MODE == 1) {
-            const float y = act_fwd((va_ - mu[i]) * sc[i] + sh[i], a.act, a.slope) * rsc[i] + rsh[i];
+            const float y = act_fwd((va_ - mu[i]) * sc[i] + sh[i], act_, a.slope) * rsc[i] + rsh[i];
             vo[i] = y;
             const float yr = to_f32(from_f32<T>(y));
             acc[0][i] += yr;
             acc[1][i] += yr * yr;
           } else if constexpr (MODE == 2) {
             const float pre = (vb_ - mu[i]) * sc[i] + sh[i];
-            const float g = va_ * a.dy_mul * rsc[i] * act_bwd(pre, a.act, a.slope);
+            const float g = va_ * a.dy_mul * rsc[i] * act_bwd(pre, act_, a.slope);
             vo[i] = g;
             const float gr = O ? to_f32(from_f32<T>(g)) : g;
             acc[0][i] += gr;
@@ -237,7 +243,7 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs a) {
               // g = dy * mask * act'((z - mean)*scale + shift) recomputed here (BatchNorm backward then never
               // materialises g)
               const float zc = vb_ - mu[i];
-              const float gg = va_ * rsc[i] * act_bwd(zc * sc[i] + sh[i], a.act, a.slope);
+              const float gg = va_ * rsc[i] * act_bwd(zc * sc[i] + sh[i], act_, a.slope);
               vo[i] = kA[i] * gg + kB[i] * zc + kC[i];
             }
           }
@@ -246,6 +252,17 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs a) {
           if (O) stv<T, CH>(O + off, vo);
         }
       }
+    }
+    };
+    if constexpr (MODE == 1 || MODE == 2 || MODE == 4) {
+      switch (a.act) {
+        case PB_ACT_NONE: run(std::integral_constant<int, (int)PB_ACT_NONE>{}); break;
+        case PB_ACT_HSWISH: run(std::integral_constant<int, (int)PB_ACT_HSWISH>{}); break;
+        case PB_ACT_RELU: run(std::integral_constant<int, (int)PB_ACT_RELU>{}); break;
+        default: run(std::integral_constant<int, -1>{}); break;
+      }
+    } else {
+      run(std::integral_constant<int, -1>{});
     }
   }
   if constexpr (MODE != 3 && MODE != 4) {
