@@ -259,9 +259,14 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out))
+        line = json.dumps(out)
+    else:
+        line = None
     if dp_path:
         dist.destroy_process_group()
+    if line is not None:
+        sys.stdout.flush()
+        print(line, flush=True)           # the ONE JSON line, after anything RCCL may have written
 
 
 if __name__ == "__main__":
