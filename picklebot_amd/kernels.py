@@ -147,6 +147,7 @@ def _rows(t, name="activation"):
 # ------------------------------------------------------------------------------ pointwise conv
 _GEMM_DMA = os.environ.get("PB_GEMM_DMA", "1") != "0"
 _GEMM_DMA_ALL = os.environ.get("PB_GEMM_DMA_ALL", "0") != "0"
+_K16_FOLD = os.environ.get("PB_K16_FOLD", "1") != "0"
 
 
 def _dma_gemm_pays(M, K, N):
@@ -185,9 +186,20 @@ class weight_scope:
         return False
 
 
-def _prepped_weight(w, transposed):
+def _prepped_weight(w, transposed, fold4=False):
     """bf16 GEMM weights [N,K] of the fp32 parameter view `w` ([N,K], or [K,N] when `transposed`) for the current
-    weight generation."""
+    weight generation; fold4: blockdiag(W,W,W,W) [4N,4K] for the 4-rows-per-line form of K = 16 layers."""
+    if fold4:
+        key4 = (w.data_ptr(), w.numel(), bool(transposed), "fold4")
+        ent = _wcache.get(key4)
+        scoped = getattr(_wscope_depth, "d", 0) > 0 or torch._C._current_graph_task_id() != -1
+        if scoped and ent is not None and ent[0] == _wgen:
+            return ent[1]
+        wb = _prepped_weight(w, transposed)
+        out = torch.block_diag(wb, wb, wb, wb).contiguous()
+        if scoped:
+            _wcache[key4] = (_wgen, out)
+        return out
     key = (w.data_ptr(), w.numel(), bool(transposed))
     ent = _wcache.get(key)
     # a cached copy is trusted only inside a weight scope or in the backward pass of one (autograd graph task):
@@ -261,6 +273,17 @@ def pw_fwd(x, w, *, w_transposed=False, in_scale=None, in_shift=None, in_act="no
         _f32(row_scale, (M // rows_per_group, K), "row_scale")
     y = torch.empty((M, N), dtype=x.dtype, device=x.device)
     dev, st = _dev_stream(x)
+    if (_GEMM_DMA and _K16_FOLD and x.dtype == torch.bfloat16 and K == 16 and N % 8 == 0 and 4 * N <= 96 and M % 4 == 0 and M >= 4096
+            and in_scale is None and in_shift is None and in_act == "none" and row_scale is None and stats is None
+            and out_scale is None and out_shift is None and w.is_contiguous()):
+        # K = 16 (the first stage): a row is 32 bytes, a quarter of an LDS stage.  [M,16] is the same memory as
+        # [M/4,64], and Y[M,N] the same as [M/4,4N] = X' * blockdiag(W,W,W,W)^T: a full-width K = 64 GEMM on a quarter
+        # of the rows (4x the MFMA work, on zeros - the kernel is HBM-bound): 3.2 -> 4.6 TB/s on the 4M-row tensors when
+        # the folded output stays one column tile (N = 16); wider outputs (N = 64 -> 256 columns) measured slower
+        wb4 = _prepped_weight(w, w_transposed, fold4=True)
+        _launch("pw_gemm_dma_kernel", _nb(x, y) + 4 * N * 64 * 2, "pb_pwconv_fwd_bf16w", _p(x), _p(wb4), _p(y), M // 4, 64, 4 * N, 1,
+                0, None, None, ACT[out_act], float(out_slope), None, dev, st, detail=f"M{M} K{K} N{N} (4-row fold)")
+        return y
     if (_GEMM_DMA and x.dtype == torch.bfloat16 and _dma_gemm_pays(M, K, N) and K % 8 == 0 and N % 8 == 0
             and in_scale is None and in_shift is None and in_act == "none" and w.is_contiguous()
             and (row_scale is None or rows_per_group >= 128)):
