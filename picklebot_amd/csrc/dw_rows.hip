@@ -306,7 +306,7 @@ constexpr int wseg_of(int K, int S) { return K == 3 ? (S == 1 ? 14 : 7) : (S == 
 
 bool rows_ok(const pb_dwconv_shape* s) {
   static const bool enabled = !(getenv("PB_DW_ROWS") && atoi(getenv("PB_DW_ROWS")) == 0);
-  static const int min_c = getenv("PB_DW_ROWS_MINC") ? atoi(getenv("PB_DW_ROWS_MINC")) : 64;
+  static const int min_c = getenv("PB_DW_ROWS_MINC") ? atoi(getenv("PB_DW_ROWS_MINC")) : 16;
   return enabled && s->kt == 1 && s->kh == s->kw && (s->kh == 3 || s->kh == 5) && s->sh == s->sw && (s->sh == 1 || s->sh == 2) &&
          s->ph == s->kh / 2 && s->pw == s->kw / 2 && s->C % 2 == 0 && s->C >= min_c &&
          s->Ho == (s->Hi + 2 * s->ph - s->kh) / s->sh + 1 && s->Wo == (s->Wi + 2 * s->pw - s->kw) / s->sw + 1 &&
@@ -370,11 +370,11 @@ int launch_rows_wgrad(RowsWgArgs a, hipStream_t st) {
 bool pb_dw_rows_eligible(const pb_dwconv_shape* s, bool wgrad) {
   // weight gradient, measured per layer on MI355X (MobileNetLarge3D, batch 32): this kernel wins on the wide layers
   // (C >= 480: 1.3-1.7x over the tile kernel) and on frames of 28x28 outputs or more (1.4-2.1x); the tile kernel
-  // keeps the narrow 14x14 layers, the strip kernel the 112-wide inputs
+  // keeps the narrow 14x14 layers, the strip kernel the 64-channel 112-wide input
   static const bool all = getenv("PB_DW_ROWS_WGRAD_ALL") && atoi(getenv("PB_DW_ROWS_WGRAD_ALL")) != 0;
   if (!rows_ok(s)) return false;
   if (!wgrad || all) return true;
-  return s->C >= 480 || (s->Ho * s->Wo >= 28 * 28 && s->Wi < 112);
+  return s->C >= 480 || (s->Ho * s->Wo >= 28 * 28 && (s->Wi < 112 || s->C < 64));
 }
 
 int pb_dw_rows_wgrad(const void* dy, const void* x, float* dw, const pb_dwconv_shape* s, pb_dtype dtype,
