@@ -156,14 +156,16 @@ def main():
         # are not bound by 8 ms of Python launch overhead each.
         try:
             def fwd_bwd():
-                reducer.zero_grad()
+                reducer.detach_grads()                        # backward hands its gradient tensors over as they are ...
                 with reducer.no_sync():
                     with torch.autocast("cuda", dtype=torch.bfloat16):
                         loss = torch.nn.functional.cross_entropy(model(x).float(), y)
                     loss.backward()
+                reducer.pack_grads()                          # ... and one concatenation per bucket gathers them
                 return loss
             step()                                            # creates the RCCL communicator outside any capture
             graph, graph_loss = capture(fwd_bwd)
+            reducer.attach_grads()                            # the optimiser reads the (reduced) buckets from now on
 
             def step():  # noqa: F811
                 graph.replay()

@@ -67,6 +67,24 @@ def _worker(rank, world, port, q):
         dist.all_gather(outs, g)
     for got, outs in zip(mine, gathered):
         assert torch.allclose(got, sum(outs) / world, atol=1e-6), "accumulated gradient mismatch"
+    # 3) the HIP-graph form of a step: backward with the hooks off hands its gradients over as they are
+    #    (detach_grads), one concatenation per bucket packs them, reduce_now() exchanges, attach_grads() points the
+    #    optimiser at the buckets
+    red.detach_grads()
+    with red.no_sync():
+        nn.functional.mse_loss(model(data[rank, 1]), target[rank, 1]).backward()
+    assert all(p.grad is not None and p.grad.untyped_storage().data_ptr() != red.flat[0].untyped_storage().data_ptr()
+               for p in red.buckets[0])
+    red.pack_grads()
+    red.reduce_now()
+    red.attach_grads()
+    mine = [p.grad.clone() for p in model.parameters()]
+    want = local_grads([1])
+    gathered = [[torch.zeros_like(g) for _ in range(world)] for g in want]
+    for g, outs in zip(want, gathered):
+        dist.all_gather(outs, g)
+    for got, outs in zip(mine, gathered):
+        assert torch.allclose(got, sum(outs) / world, atol=1e-6), "packed gradient mismatch"
     # .grad tensors are still views of the flat buckets
     assert all(p.grad.data_ptr() >= red.flat[0].data_ptr() or True for p in model.parameters())
     dist.barrier()
