@@ -53,3 +53,9 @@ __attribute__((visibility("hidden"))) int pb_dw_rows_fwd(const void* src, const 
 __attribute__((visibility("hidden"))) int pb_dw_rows_wgrad(const void* dy, const void* x, float* dw, const pb_dwconv_shape* s,
                                                            pb_dtype dtype, const float* g_scale, const float* g_shift,
                                                            hipStream_t st);
+
+// (kt,3,3) kernels walking along time with a ring of kt output accumulators (dw3.hip); same return convention
+__attribute__((visibility("hidden"))) bool pb_dw3_eligible(const pb_dwconv_shape* s);
+__attribute__((visibility("hidden"))) int pb_dw3_fwd(const void* src, const float* w, void* dst, const pb_dwconv_shape* s,
+                                                     pb_dtype dtype, int flip, const float* g_scale, const float* g_shift,
+                                                     float* pool, hipStream_t st);

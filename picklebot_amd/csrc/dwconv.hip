@@ -797,17 +797,31 @@ pb_dwconv_shape bwd_corr_shape(const pb_dwconv_shape& s) {
   return c;
 }
 
+// (kt,3,3) kernels at stride 1: backward-data = correlation of dy with the filter flipped in all three dimensions
+bool bwd_is_dw3_corr(const pb_dwconv_shape& s) {
+  return pb_dw3_eligible(&s) && s.sh == 1 && s.sw == 1 && s.st == 1;
+}
+pb_dwconv_shape bwd_dw3_shape(const pb_dwconv_shape& s) {
+  pb_dwconv_shape c = s;
+  c.Ti = s.To; c.Hi = s.Ho; c.Wi = s.Wo;
+  c.To = s.Ti; c.Ho = s.Hi; c.Wo = s.Wi;
+  c.pt = s.kt - 1 - s.pt; c.ph = s.kh - 1 - s.ph; c.pw = s.kw - 1 - s.pw;
+  return c;
+}
+
 }  // namespace
 
 extern "C" const char* pb_dwconv3d_kernel_name(const pb_dwconv_shape* s, pb_dtype dtype, int which) {
   if (!s) return "";
   if (which == 0) {
+    if (pb_dw3_eligible(s)) return "dw3_fwd_kernel";
     if (pb_dw7_eligible(s)) return "dw7_fwd_kernel";
     if (pb_dw_rows_eligible(s, false)) return "dw_rows_fwd_kernel";
     if (pb_dw_tile_eligible(s, dtype, false)) return "dw_tile_fwd_kernel";
     return strip_ok(*s) ? "dw_strip_fwd_kernel" : "dw_gen_fwd_kernel";
   }
   if (which == 1) {
+    if (bwd_is_dw3_corr(*s)) return "dw3_fwd_kernel";
     if (bwd_is_s1_corr(*s)) {
       const pb_dwconv_shape c = bwd_corr_shape(*s);
       if (pb_dw7_eligible(&c)) return "dw7_fwd_kernel";
@@ -831,7 +845,9 @@ extern "C" int pb_dwconv3d_fwd(const void* x, const float* w, void* y, const pb_
   PB_ENTER(device);
   hipStream_t st = (hipStream_t)stream;
   {
-    int rc = pb_dw7_fwd(x, w, y, s, dtype, 0, nullptr, nullptr, pool, st);
+    int rc = pb_dw3_fwd(x, w, y, s, dtype, 0, nullptr, nullptr, pool, st);
+    if (rc >= 0) return rc;
+    rc = pb_dw7_fwd(x, w, y, s, dtype, 0, nullptr, nullptr, pool, st);
     if (rc >= 0) return rc;
     rc = pb_dw_rows_fwd(x, w, y, s, dtype, 0, nullptr, nullptr, pool, st);
     if (rc >= 0) return rc;
@@ -890,6 +906,11 @@ extern "C" int pb_dwconv3d_bwd_data(const void* dy, const float* w, void* dx, co
   PB_CHECK_ARG(dtype == PB_F32 || dtype == PB_BF16, "pb_dwconv3d_bwd_data: bad dtype");
   PB_ENTER(device);
   hipStream_t st = (hipStream_t)stream;
+  if (bwd_is_dw3_corr(*s)) {
+    const pb_dwconv_shape c = bwd_dw3_shape(*s);
+    int rc = pb_dw3_fwd(dy, w, dx, &c, dtype, 1, g_scale, g_shift, nullptr, st);
+    if (rc >= 0) return rc;
+  }
   // stride-1 spatial + temporal: correlation of dy with the flipped filter, padding k-1-p
   if (bwd_is_s1_corr(*s)) {
     const pb_dwconv_shape c = bwd_corr_shape(*s);

@@ -107,6 +107,7 @@ class MoViNetA2(nn.Module):
     @PF.scoped
     def forward(self, x):
         dt = compute_dtype(x)
+        PF.prepare_model_weights(self, x, dt)
         conv, bn, act_m = self.block1
         act, slope = act_of(act_m)
         y5 = PF.stem_bn_act(x, conv, bn, act=act, slope=slope, training=bn.training, dtype=dt,

@@ -147,6 +147,10 @@ DW_CASES = [  # N, C, (T,H,W), kernel, stride, pad
     (1, 6, (3, 4, 4), (3, 3, 3), (1, 1, 1), (1, 1, 1)),           # scalar channel path
     (2, 40, (3, 7, 7), (1, 3, 3), (1, 1, 1), (1, 1, 1)),          # 7x7 whole-frame-in-registers kernels, k=3
     (3, 66, (4, 7, 7), (1, 5, 5), (2, 1, 1), (2, 2, 2)),          # ... with temporal stride/padding (zero frames)
+    (2, 48, (12, 11, 11), (3, 3, 3), (1, 1, 1), (2, 1, 1)),       # (kt,3,3) time-walking kernels: MoViNet block padding
+    (1, 32, (23, 6, 6), (5, 3, 3), (1, 1, 1), (4, 1, 1)),         # (kt-1 both sides => T grows), several time chunks
+    (1, 24, (13, 10, 10), (5, 3, 3), (1, 2, 2), (4, 1, 1)),
+    (2, 16, (7, 9, 9), (3, 3, 3), (1, 2, 2), (2, 1, 1)),
 ]
 
 

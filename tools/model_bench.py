@@ -1,0 +1,107 @@
+"""Per-kernel-family timing of the other BASELINE.json workloads (not the bench line; that is bench.py).
+
+  python tools/model_bench.py mobilevit_s_train --batch 4 --steps 5 [--detail gpurun_out/x.txt]
+
+Workloads: mobilevit_s_train / mobilevit_xxs_train (16x256x256), mobilevit_xxs_fwd (32x224x224, eval),
+movinet_a2_fwd (50x172x172, eval), mobilenet_small_train (16x224x224).
+Prints wall ms/step (eager launches, synchronised) and the HIP-event family table.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+CFG = {  # reference config/*.json
+    "s": dict(dims=[144, 192, 240], channels=[16, 32, 64, 64, 96, 96, 128, 128, 160, 160, 640]),
+    "xs": dict(dims=[96, 120, 144], channels=[16, 32, 48, 48, 64, 64, 80, 80, 96, 96, 384]),
+    "xxs": dict(dims=[64, 80, 96], channels=[16, 16, 24, 24, 48, 48, 64, 64, 80, 80, 320]),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("workload")
+    ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--detail", default=None)
+    ap.add_argument("--fp32", action="store_true")
+    args = ap.parse_args()
+
+    import picklebot_amd as pb
+    from picklebot_amd import kernels as K
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    w = args.workload
+    train = w.endswith("_train")
+    if w.startswith("mobilevit_"):
+        size = w.split("_")[1]
+        model = pb.MobileViT(num_classes=13, **CFG[size])
+        shape = (args.batch, 3, 16, 256, 256) if train else (args.batch, 3, 32, 224, 224)
+    elif w.startswith("movinet_a2"):
+        model = pb.MoViNetA2(num_classes=13)
+        shape = (args.batch, 3, 50, 172, 172)
+    elif w.startswith("mobilenet_small"):
+        model = pb.MobileNetSmall3D(num_classes=13)
+        shape = (args.batch, 3, 16, 224, 224)
+    elif w.startswith("mobilenet_large"):
+        model = pb.MobileNetLarge3D(num_classes=13)
+        shape = (args.batch, 3, 16, 224, 224)
+    else:
+        raise SystemExit("unknown workload " + w)
+    model = model.to(dev)
+    model.train(train)
+    x = torch.randn(shape, device=dev)
+    if not args.fp32:
+        x = x.to(torch.bfloat16)
+    x = x.to(memory_format=torch.channels_last_3d)
+    y = torch.randint(0, 13, (args.batch,), device=dev)
+    opt = torch.optim.AdamW(model.parameters(), lr=3e-4, fused=True) if train else None
+
+    def step():
+        if train:
+            opt.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=not args.fp32):
+                loss = torch.nn.functional.cross_entropy(model(x).float(), y)
+            loss.backward()
+            opt.step()
+            return loss
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=not args.fp32):
+            return model(x)
+
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / args.steps * 1e3
+
+    K.start_profile()
+    for _ in range(args.steps):
+        step()
+    prof = K.stop_profile()
+    detail = {k: v for k, v in prof.items() if " | " in k}
+    prof = {k: v for k, v in prof.items() if " | " not in k}
+    tot = sum(d["ms"] for d in prof.values())
+    print(f"{w} batch {args.batch} {shape}: {ms:.2f} ms/step eager ({args.batch / ms * 1e3:.1f} clips/s), "
+          f"sum of kernel events {tot / args.steps:.2f} ms/step, peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+    for name, d in sorted(prof.items(), key=lambda kv: -kv[1]["ms"]):
+        print("  %-34s n=%4d  %8.3f ms/step  %7.1f GB/s  %5.1f%%" % (
+            name, d["launches"] // args.steps, d["ms"] / args.steps, d["bytes"] / 1e6 / max(d["ms"], 1e-9), 100 * d["ms"] / tot))
+    if args.detail:
+        with open(args.detail, "w") as f:
+            for k, d in sorted(detail.items(), key=lambda kv: -kv[1]["ms"]):
+                f.write("%-100s n=%3d  %8.1f us/launch  %7.1f GB/s\n" % (
+                    k, d["launches"] // args.steps, d["ms"] / d["launches"] * 1e3, d["bytes"] / 1e6 / max(d["ms"], 1e-9)))
+    print(json.dumps({"workload": w, "batch": args.batch, "ms_per_step": round(ms, 3)}))
+
+
+if __name__ == "__main__":
+    main()
