@@ -34,7 +34,7 @@ typedef enum {
   PB_ACT_HSIGMOID = 4, PB_ACT_SILU = 5
 } pb_act;
 
-#define PB_ABI_VERSION 6
+#define PB_ABI_VERSION 7
 
 /* Per-channel statistics buffers (`stats`, `sums` below) are PB_STAT_REPLICAS replicas of [2][C]
  * fp32, layout [replica][2][C], zero-filled by the caller.  A workgroup adds its partial sums into
@@ -116,6 +116,12 @@ int pb_conv_weight_prep(const float* in, float* out, int Cout, int Cin, int taps
 int pb_conv3d_fwd(const void* x, const float* wp, void* y, const pb_conv_shape* s, pb_dtype dtype,
                   const float* out_scale, const float* out_shift, pb_act out_act, float out_slope, float* stats,
                   int device, void* stream);
+/* bf16, stride 1, Cin % 8 == 0, Cout % 8 == 0: both operands by LDS-DMA (the implicit-GEMM form of pb_pwconv_fwd_bf16w:
+ * the 16-byte chunks of an im2col row are fetched from the tap-shifted voxel, or from `zero16` - any 16 zero bytes in
+ * device memory - for padding).  wb: bf16 [Cout][taps][Cin] (pb_conv_weight_prep mode 0 or 1, then pb_pw_weight_prep). */
+int pb_conv3d_fwd_bf16w(const void* x, const void* wb, void* y, const pb_conv_shape* s, const void* zero16,
+                        const float* out_scale, const float* out_shift, pb_act out_act, float out_slope, float* stats,
+                        int device, void* stream);
 int pb_conv3d_bwd_weight(const void* dy, const void* x, float* dwp, const pb_conv_shape* s, pb_dtype dtype, int device,
                          void* stream);
 

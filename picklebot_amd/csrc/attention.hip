@@ -33,6 +33,7 @@ struct AttnArgs {
   void* dqkv;          // bwd: [R][384]
   int n, npad;         // tokens per group, rounded up to 32
   float scale;
+  int split;           // workgroups per (group, head): each takes every split-th round of query (key) tiles
 };
 
 template <typename T> struct Frag;
@@ -74,7 +75,7 @@ template <typename T>
 __device__ __forceinline__ void stage_head(const T* src, int64_t ld, int n, int npad, T* rm, T* tr, int ldt) {
   constexpr int VEC = ElemTraits<T>::VEC;
   constexpr int CPR = HD / VEC;       // 16-byte chunks per row: 2 (bf16) / 4 (fp32)
-  for (int i = threadIdx.x; i < npad * CPR; i += 256) {
+  for (int i = threadIdx.x; i < npad * CPR; i += blockDim.x) {
     const int r = i / CPR, c = i - r * CPR;
     Vec16<T> v = vec_zero<T>();
     if (r < n) v = vec_load<T>(src + (int64_t)r * ld + c * VEC);
@@ -88,13 +89,14 @@ __device__ __forceinline__ void stage_head(const T* src, int64_t ld, int n, int 
 
 // ------------------------------------------------------------------------------------------ forward
 template <typename T>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(512) void attn_fwd_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr bool BF = sizeof(T) == 2;
   const int n = a.n, npad = a.npad, ldt = npad + 8;
   T* Ks = (T*)smem;                                   // [npad][16]
   T* Vs = Ks + npad * HD;                             // bf16: V^T [16][ldt]; fp32: V [npad][16]
-  const int grp = blockIdx.x / NH, h = blockIdx.x - grp * NH;
+  const int gh = blockIdx.x / a.split, sp = blockIdx.x - gh * a.split, nwv = blockDim.x >> 6;
+  const int grp = gh / NH, h = gh - grp * NH;
   const T* base = (const T*)a.qkv + (int64_t)grp * n * QKV_LD + h * HD;
   stage_head<T>(base + NH * HD, QKV_LD, n, npad, Ks, nullptr, 0);
   if constexpr (BF) stage_head<T>(base + 2 * NH * HD, QKV_LD, n, npad, nullptr, Vs, ldt);
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, g = lane >> 4;
   const float NEG = -3.0e38f;
-  for (int qt = wave; qt * 16 < n; qt += 4) {
+  for (int qt = sp * nwv + wave; qt * 16 < n; qt += nwv * a.split) {
     const int q = qt * 16 + li;
     const bool qok = q < n;
     const Frag<T> qf = load_rowfrag<T>(qok ? base + (int64_t)q * QKV_LD : nullptr, g);
@@ -192,21 +194,22 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const T* dout, const T*
 // ------------------------------------------------------------------------------------------ backward: dQ
 // waves own query tiles; S^T orientation (key on the accumulator row): dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q]
 template <typename T>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
+__global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr bool BF = sizeof(T) == 2;
   const int n = a.n, npad = a.npad, ldt = npad + 8;
   T* Ks = (T*)smem;                 // [npad][16]
   T* Vs = Ks + npad * HD;           // [npad][16]
   T* Kt = Vs + npad * HD;           // bf16 only: K^T [16][ldt]
-  const int grp = blockIdx.x / NH, h = blockIdx.x - grp * NH;
+  const int gh = blockIdx.x / a.split, sp = blockIdx.x - gh * a.split, nwv = blockDim.x >> 6;
+  const int grp = gh / NH, h = gh - grp * NH;
   const T* base = (const T*)a.qkv + (int64_t)grp * n * QKV_LD + h * HD;
   stage_head<T>(base + NH * HD, QKV_LD, n, npad, Ks, BF ? Kt : nullptr, ldt);
   stage_head<T>(base + 2 * NH * HD, QKV_LD, n, npad, Vs, nullptr, 0);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, g = lane >> 4;
-  for (int qt = wave; qt * 16 < n; qt += 4) {
+  for (int qt = sp * nwv + wave; qt * 16 < n; qt += nwv * a.split) {
     const int q = qt * 16 + li;
     const bool qok = q < n;
     const int64_t row = (int64_t)grp * n + q;
@@ -265,7 +268,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
 // waves own key tiles; S orientation (query on the accumulator row, key on the lane):
 //   dV^T[d][key] = sum_q dO^T[d][q] P[q][key],   dK^T[d][key] = sum_q Q^T[d][q] dS[q][key]
 template <typename T>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
+__global__ __launch_bounds__(1024) void attn_bwd_dkv_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr bool BF = sizeof(T) == 2;
   const int n = a.n, npad = a.npad, ldt = npad + 8;
@@ -275,19 +278,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
   T* Ot = Qt + (BF ? HD * ldt : 0);
   float* Ls = (float*)(Ot + (BF ? HD * ldt : 0));   // lse [npad], delta [npad]
   float* Ds = Ls + npad;
-  const int grp = blockIdx.x / NH, h = blockIdx.x - grp * NH;
+  const int gh = blockIdx.x / a.split, sp = blockIdx.x - gh * a.split, nwv = blockDim.x >> 6;
+  const int grp = gh / NH, h = gh - grp * NH;
   const T* base = (const T*)a.qkv + (int64_t)grp * n * QKV_LD + h * HD;
   const T* dob = (const T*)a.dout + (int64_t)grp * n * OUT_LD + h * HD;
   stage_head<T>(base, QKV_LD, n, npad, Qs, BF ? Qt : nullptr, ldt);
   stage_head<T>(dob, OUT_LD, n, npad, Os, BF ? Ot : nullptr, ldt);
-  for (int i = threadIdx.x; i < npad; i += 256) {
+  for (int i = threadIdx.x; i < npad; i += blockDim.x) {
     Ls[i] = i < n ? a.lse[((int64_t)grp * n + i) * NH + h] : 0.f;
     Ds[i] = i < n ? a.delta[((int64_t)grp * n + i) * NH + h] : 0.f;
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, g = lane >> 4;
-  for (int kt = wave; kt * 16 < n; kt += 4) {
+  for (int kt = sp * nwv + wave; kt * 16 < n; kt += nwv * a.split) {
     const int key = kt * 16 + li;
     const bool kok = key < n;
     const Frag<T> kf = load_rowfrag<T>(kok ? base + NH * HD + (int64_t)key * QKV_LD : nullptr, g);
@@ -360,8 +364,18 @@ int set_lds(KernelT k, size_t bytes) {
   return 0;
 }
 
+// 8 waves per workgroup (the staged K/V/Q/dO slices, up to 105 KB at n = 768, allow only 1-3 workgroups per CU) and
+// enough workgroups per (group, head) to put ~1024 on the chip
+constexpr int ATT_THREADS = 512, ATT_THREADS_DKV = 1024;
+int attn_split(int64_t G, int n, int threads = ATT_THREADS) {
+  const int64_t tiles = pb_cdiv(n, 16), rounds = pb_cdiv(tiles, threads / 64);
+  int64_t sp = pb_cdiv(1024, G * NH);
+  if (sp > rounds) sp = rounds;
+  return sp < 1 ? 1 : (int)sp;
+}
+
 int check_attn(int64_t G, int n, pb_dtype dtype, const char* who) {
-  PB_CHECK_ARG(G > 0 && n > 0 && G * NH < 0x7fffffffLL, "%s: bad sizes G=%lld n=%d", who, (long long)G, n);
+  PB_CHECK_ARG(G > 0 && n > 0 && G * NH * 64 < 0x7fffffffLL, "%s: bad sizes G=%lld n=%d", who, (long long)G, n);
   PB_CHECK_ARG(dtype == PB_F32 || dtype == PB_BF16, "%s: bad dtype", who);
   return 0;
 }
@@ -375,15 +389,16 @@ extern "C" int pb_attention_fwd(const void* qkv, void* out, float* lse, int64_t 
   PB_ENTER(device);
   AttnArgs a = {};
   a.qkv = qkv; a.out = out; a.lse = lse; a.n = n; a.npad = (n + 31) / 32 * 32; a.scale = scale;
+  a.split = attn_split(G, n);
   const size_t es = dtype == PB_BF16 ? 2 : 4;
   const size_t lds = (size_t)a.npad * HD * es + (dtype == PB_BF16 ? (size_t)HD * (a.npad + 8) * es : (size_t)a.npad * HD * es);
-  dim3 grid((unsigned)(G * NH));
+  dim3 grid((unsigned)(G * NH * a.split));
   if (dtype == PB_BF16) {
     if (int rc = set_lds(attn_fwd_kernel<bf16_t>, lds)) return rc;
-    hipLaunchKernelGGL(attn_fwd_kernel<bf16_t>, grid, dim3(256), lds, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(attn_fwd_kernel<bf16_t>, grid, dim3(ATT_THREADS), lds, (hipStream_t)stream, a);
   } else {
     if (int rc = set_lds(attn_fwd_kernel<float>, lds)) return rc;
-    hipLaunchKernelGGL(attn_fwd_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(attn_fwd_kernel<float>, grid, dim3(ATT_THREADS), lds, (hipStream_t)stream, a);
   }
   PB_LAUNCH_CHECK();
   return 0;
@@ -397,25 +412,29 @@ extern "C" int pb_attention_bwd(const void* qkv, const void* out, const void* do
   hipStream_t st = (hipStream_t)stream;
   AttnArgs a = {};
   a.qkv = qkv; a.dout = dout; a.lse = const_cast<float*>(lse); a.delta = delta; a.dqkv = dqkv; a.n = n; a.npad = (n + 31) / 32 * 32; a.scale = scale;
+  a.split = attn_split(G, n);
   const int64_t R = G * n;
   const bool bf = dtype == PB_BF16;
   const size_t es = bf ? 2 : 4;
   const size_t rm = (size_t)a.npad * HD * es, tr = bf ? (size_t)HD * (a.npad + 8) * es : 0;
   const size_t lds_dq = 2 * rm + tr;
   const size_t lds_dkv = 2 * rm + 2 * tr + 2 * (size_t)a.npad * 4;
-  dim3 grid((unsigned)(G * NH));
+  dim3 grid((unsigned)(G * NH * a.split));
+  AttnArgs akv = a;
+  akv.split = attn_split(G, n, ATT_THREADS_DKV);
+  dim3 grid_kv((unsigned)(G * NH * akv.split));
   if (bf) {
     hipLaunchKernelGGL(attn_delta_kernel<bf16_t>, dim3((unsigned)pb_cdiv(R * NH, 256)), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)out, delta, R);
     if (int rc = set_lds(attn_bwd_dkv_kernel<bf16_t>, lds_dkv)) return rc;
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<bf16_t>, grid, dim3(256), lds_dkv, st, a);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<bf16_t>, grid_kv, dim3(ATT_THREADS_DKV), lds_dkv, st, akv);
     if (int rc = set_lds(attn_bwd_dq_kernel<bf16_t>, lds_dq)) return rc;
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<bf16_t>, grid, dim3(256), lds_dq, st, a);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<bf16_t>, grid, dim3(ATT_THREADS), lds_dq, st, a);
   } else {
     hipLaunchKernelGGL(attn_delta_kernel<float>, dim3((unsigned)pb_cdiv(R * NH, 256)), dim3(256), 0, st, (const float*)dout, (const float*)out, delta, R);
     if (int rc = set_lds(attn_bwd_dkv_kernel<float>, lds_dkv)) return rc;
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<float>, grid, dim3(256), lds_dkv, st, a);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<float>, grid_kv, dim3(ATT_THREADS_DKV), lds_dkv, st, akv);
     if (int rc = set_lds(attn_bwd_dq_kernel<float>, lds_dq)) return rc;
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<float>, grid, dim3(256), lds_dq, st, a);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<float>, grid, dim3(ATT_THREADS), lds_dq, st, a);
   }
   PB_LAUNCH_CHECK();
   return 0;

@@ -40,6 +40,11 @@ struct DmaArgs {
   float* stats;
   int n_tiles;
   int m_tiles;
+  // implicit-GEMM convolution (CONV instantiations): X is [N,Ti,Hi,Wi,Cin], row m = output voxel, K = taps*Cin with
+  // k = tap*Cin + c; a 16-byte chunk (8 channels) of a row comes from the voxel shifted by the tap, or from `zero`
+  int Ti, Hi, Wi, To, Ho, Wo, pt, ph, pw, kh, kw, taps, Cin;
+  unsigned cin_magic;        // ceil(2^32 / Cin): k / Cin == umulhi(k, cin_magic) for k < 65536
+  const bf16_t* zero;        // >= 16 bytes of zeros in device memory
 };
 
 __device__ __forceinline__ void glds16(const void* gsrc, unsigned char* lds_dst) {
@@ -56,7 +61,7 @@ PB_VMCNT(0) PB_VMCNT(5) PB_VMCNT(6) PB_VMCNT(7) PB_VMCNT(8) PB_VMCNT(10) PB_VMCN
 PB_VMCNT(15) PB_VMCNT(18) PB_VMCNT(21) PB_VMCNT(24) PB_VMCNT(30)
 #undef PB_VMCNT
 
-template <int NT, int NS>
+template <int NT, int NS, bool CONV>
 __global__ __launch_bounds__(256) void pw_gemm_dma_kernel(DmaArgs a) {
   typedef bf16_t T;
   constexpr int VEC = 8, KS = 64, MK = 32;
@@ -100,6 +105,11 @@ __global__ __launch_bounds__(256) void pw_gemm_dma_kernel(DmaArgs a) {
 
   // ring starts out as zeros: from then on every byte in it is real (finite) data
   for (int i = tid; i < NS * STAGE / 16; i += 256) *reinterpret_cast<u32x4*>(ring + i * 16) = u32x4{0u, 0u, 0u, 0u};
+  __shared__ int taptab[CONV ? 64 : 1];                  // tap -> dt | dh << 8 | dw << 16
+  if (CONV && tid < a.taps) {
+    const int dw_ = tid % a.kw, r_ = tid / a.kw;
+    taptab[tid] = (r_ / a.kh) | ((r_ % a.kh) << 8) | (dw_ << 16);
+  }
 
   // this thread's chunks of a stage: A chunk f = i*256 + tid -> row f>>3, LDS chunk f&7 holds source chunk
   // (f&7) ^ swz(row); same for the weight slice
@@ -117,6 +127,22 @@ __global__ __launch_bounds__(256) void pw_gemm_dma_kernel(DmaArgs a) {
     w_cs[i] = ((f & 7) ^ ((w_row[i] >> 1) & 7)) * VEC;
   }
   const int wave_off = __builtin_amdgcn_readfirstlane(wave * 1024);
+  // CONV: the four rows this thread fetches for the tile being requested: coordinates of their tap-(0,0,0) source voxel
+  int rq_t[CONV ? 4 : 1], rq_h[CONV ? 4 : 1], rq_w[CONV ? 4 : 1], rq_pix[CONV ? 4 : 1];
+  auto set_rows = [&](int t) {
+    if constexpr (CONV) {
+      const int64_t m0 = (int64_t)tile_mt(t) * BM;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = (int)min(m0 + a_row[i], a.M - 1);
+        const int wo = m % a.Wo, r1 = m / a.Wo;
+        const int ho = r1 % a.Ho, r2 = r1 / a.Ho;
+        const int to = r2 % a.To, n = r2 / a.To;
+        rq_t[i] = to - a.pt; rq_h[i] = ho - a.ph; rq_w[i] = wo - a.pw;
+        rq_pix[i] = ((n * a.Ti + rq_t[i]) * a.Hi + rq_h[i]) * a.Wi + rq_w[i];
+      }
+    }
+  };
 
   auto issue = [&](int t, int ks, int buf) {
     int64_t m0, mend;
@@ -129,8 +155,22 @@ __global__ __launch_bounds__(256) void pw_gemm_dma_kernel(DmaArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int k = k0 + a_cs[i];
-      const int64_t m = min(m0 + a_row[i], a.M - 1);         // rows past the panel: any valid row (never stored)
-      if (k < a.K) glds16(a.X + m * a.K + k, A + i * 4096);
+      if constexpr (CONV) {
+        const T* src = a.zero;                               // padding voxels and the K tail
+        if (k < a.K) {
+          const int tap = (int)__umulhi((unsigned)k, a.cin_magic);
+          const int c = k - tap * a.Cin;
+          const int tp = taptab[tap];
+          const int dt = tp & 255, dh = (tp >> 8) & 255, dw = tp >> 16;
+          if ((unsigned)(rq_t[i] + dt) < (unsigned)a.Ti && (unsigned)(rq_h[i] + dh) < (unsigned)a.Hi &&
+              (unsigned)(rq_w[i] + dw) < (unsigned)a.Wi)
+            src = a.X + (int64_t)(rq_pix[i] + (dt * a.Hi + dh) * a.Wi + dw) * a.Cin + c;
+        }
+        glds16(src, A + i * 4096);
+      } else {
+        const int64_t m = min(m0 + a_row[i], a.M - 1);       // rows past the panel: any valid row (never stored)
+        if (k < a.K) glds16(a.X + m * a.K + k, A + i * 4096);
+      }
     }
 #pragma unroll
     for (int i = 0; i < WCH; ++i) {
@@ -199,8 +239,10 @@ __global__ __launch_bounds__(256) void pw_gemm_dma_kernel(DmaArgs a) {
     if (++ksi == nk) {
       ksi = 0;
       ti = next_valid(ti + gridDim.x);
+      if (ti < total) set_rows(ti);
     }
   };
+  set_rows(ti);
 #pragma unroll
   for (int s0 = 0; s0 < NS - 1; ++s0) {
     if (ti < total) {
@@ -393,23 +435,23 @@ int pick_nt_dma(int N, int K) {
   return best;
 }
 
-template <int NT, int NS>
+template <int NT, int NS, bool CONV = false>
 int launch_dma(const DmaArgs& a, int64_t total, int device, hipStream_t st) {
   constexpr int BN = NT * 16;
   constexpr int ER = (NT >= 8 && NS == 2) ? 8 : 16;
   constexpr size_t lds = (size_t)NS * (BM * 128 + BN * 128) + 4 * ER * (BN + 8) * 2 + 4 * BN * 2 * 4;
   static int resident = 0;
   if (resident == 0) {
-    (void)hipFuncSetAttribute((const void*)pw_gemm_dma_kernel<NT, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)pw_gemm_dma_kernel<NT, NS, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     int per_cu = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pw_gemm_dma_kernel<NT, NS>, 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pw_gemm_dma_kernel<NT, NS, CONV>, 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) cus = 256;
     resident = per_cu * cus;
   }
   int64_t blocks = resident;
   if (blocks > total) blocks = total;
   blocks = pb_cdiv(blocks, 8) * 8;
-  hipLaunchKernelGGL((pw_gemm_dma_kernel<NT, NS>), dim3((unsigned)blocks), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((pw_gemm_dma_kernel<NT, NS, CONV>), dim3((unsigned)blocks), dim3(256), lds, st, a);
   return 0;
 }
 
@@ -495,6 +537,52 @@ extern "C" int pb_pwconv_fwd_bf16w(const void* x, const void* wb, void* y, int64
     case 6: launch_dma<6, 3>(a, total, device, st); break;
     case 8: launch_dma<8, 3>(a, total, device, st); break;
     default: launch_dma<12, 3>(a, total, device, st); break;
+  }
+  PB_LAUNCH_CHECK();
+  return 0;
+}
+
+// Dense Conv3d (groups = 1, stride 1) as implicit GEMM on the same kernel: M = output voxels, K = taps*Cin.
+extern "C" int pb_conv3d_fwd_bf16w(const void* x, const void* wb, void* y, const pb_conv_shape* s, const void* zero16,
+                                   const float* out_scale, const float* out_shift, pb_act out_act, float out_slope,
+                                   float* stats, int device, void* stream) {
+  PB_CHECK_ARG(x && wb && y && s && zero16, "pb_conv3d_fwd_bf16w: null pointer");
+  PB_CHECK_ARG(s->st == 1 && s->sh == 1 && s->sw == 1, "pb_conv3d_fwd_bf16w: stride 1 only");
+  const int taps = s->kt * s->kh * s->kw;
+  PB_CHECK_ARG(s->N > 0 && s->Cin > 0 && s->Cout > 0 && s->Cin % 8 == 0 && s->Cout % 8 == 0,
+               "pb_conv3d_fwd_bf16w: channel counts must be multiples of 8 (Cin=%d Cout=%d)", s->Cin, s->Cout);
+  PB_CHECK_ARG(taps >= 1 && taps <= 64 && s->kt < 256 && s->kh < 256 && s->kw < 256 && (int64_t)taps * s->Cin < 65536,
+               "pb_conv3d_fwd_bf16w: kernel too large (taps=%d Cin=%d)", taps, s->Cin);
+  PB_CHECK_ARG(s->To > 0 && s->Ho > 0 && s->Wo > 0 && s->Ti > 0 && s->Hi > 0 && s->Wi > 0, "pb_conv3d_fwd_bf16w: empty tensor");
+  const int64_t M = (int64_t)s->N * s->To * s->Ho * s->Wo;
+  PB_CHECK_ARG(M < (1LL << 31) && (int64_t)s->N * s->Ti * s->Hi * s->Wi < (1LL << 30), "pb_conv3d_fwd_bf16w: tensor too large");
+  PB_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)wb % 16) == 0 && ((uintptr_t)zero16 % 16) == 0,
+               "pb_conv3d_fwd_bf16w: unaligned pointer");
+  PB_ENTER(device);
+  DmaArgs a = {};
+  a.X = (const bf16_t*)x; a.WB = (const bf16_t*)wb; a.Y = (bf16_t*)y; a.M = M; a.K = taps * s->Cin; a.N = s->Cout;
+  a.out_scale = out_scale; a.out_shift = out_shift; a.out_act = (int)out_act; a.out_slope = out_slope; a.stats = stats;
+  a.m_tiles = (int)pb_cdiv(M, BM);
+  a.Ti = s->Ti; a.Hi = s->Hi; a.Wi = s->Wi; a.To = s->To; a.Ho = s->Ho; a.Wo = s->Wo;
+  a.pt = s->pt; a.ph = s->ph; a.pw = s->pw; a.kh = s->kh; a.kw = s->kw; a.taps = taps; a.Cin = s->Cin;
+  a.cin_magic = (unsigned)(((1ULL << 32) + (unsigned)s->Cin - 1) / (unsigned)s->Cin);
+  a.zero = (const bf16_t*)zero16;
+  // few row panels (small frames): narrower column tiles give the chip more workgroups
+  int nt = pick_nt_dma(a.N, a.K);
+  static const int min_tiles = getenv("PB_CONV_MIN_TILES") ? atoi(getenv("PB_CONV_MIN_TILES")) : 1200;
+  while (nt > 2 && (int64_t)a.m_tiles * pb_cdiv(a.N, nt * 16) < min_tiles) nt -= 2;
+  a.n_tiles = (int)pb_cdiv(a.N, nt * 16);
+  const int64_t total = a.n_tiles == 1 ? a.m_tiles : pb_cdiv(a.m_tiles, 8) * 8 * a.n_tiles;
+  hipStream_t st = (hipStream_t)stream;
+  static const int ns = getenv("PB_CONV_DMA_NS") ? atoi(getenv("PB_CONV_DMA_NS")) : 2;
+  if (ns == 2) {
+    if (nt == 2) launch_dma<2, 2, true>(a, total, device, st);
+    else if (nt == 4) launch_dma<4, 2, true>(a, total, device, st);
+    else launch_dma<6, 2, true>(a, total, device, st);
+  } else {
+    if (nt == 2) launch_dma<2, 4, true>(a, total, device, st);
+    else if (nt == 4) launch_dma<4, 4, true>(a, total, device, st);
+    else launch_dma<6, 3, true>(a, total, device, st);
   }
   PB_LAUNCH_CHECK();
   return 0;

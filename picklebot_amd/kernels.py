@@ -622,6 +622,9 @@ def se_fc_bwd(dscale, pool, inv_count, scale, hidden, w1, w2, want_bias=True):
 
 
 # ------------------------------------------------------------------------------ dense conv (implicit GEMM)
+_CONV_DMA = os.environ.get("PB_CONV_DMA", "1") != "0"
+
+
 def _conv_shape(N, cin, cout, in_thw, out_thw, kernel, stride, pad):
     s = _C.ConvShape()
     s.N, s.Cin, s.Cout = N, cin, cout
@@ -657,6 +660,15 @@ def conv3d_fwd(x, wp, cout, kernel, stride, pad_front, out_thw, *, out_scale=Non
     y = torch.empty((N,) + tuple(out_thw) + (cout,), dtype=x.dtype, device=x.device)
     s = _conv_shape(N, cin, cout, (T, H, W), out_thw, kernel, stride, pad_front)
     dev, st = _dev_stream(x)
+    if (_CONV_DMA and x.dtype == torch.bfloat16 and tuple(stride) == (1, 1, 1) and cin % 8 == 0 and cout % 8 == 0 and taps <= 64
+            and taps * cin < 65536 and y.numel() // cout < 2 ** 31 and x.numel() // cin < 2 ** 30):
+        # implicit GEMM on the LDS-DMA kernel (bf16 filter copy: one tiny launch)
+        wb = torch.empty(cout * taps * cin, dtype=torch.bfloat16, device=x.device)
+        _launch("pw_weight_prep_kernel", _nb(wp, wb), "pb_pw_weight_prep", _p(wp), cout, taps * cin, 0, None, 1, _p(wb), dev, st)
+        _launch("conv3d_dma_kernel", _nb(x, y, wb), "pb_conv3d_fwd_bf16w", _p(x), _p(wb), _p(y), ctypes.byref(s), _p(zeros(8, x.device)),
+                _p(out_scale), _p(out_shift), ACT[out_act], float(out_slope), _p(stats), dev, st,
+                detail=f"Cin{cin} Cout{cout} {T}x{H}x{W} k{kernel}")
+        return y
     _launch("pw_gemm_kernel<conv>", _nb(x, y, wp), "pb_conv3d_fwd", _p(x), _p(wp), _p(y), ctypes.byref(s), _dt(x), _p(out_scale),
             _p(out_shift), ACT[out_act], float(out_slope), _p(stats), dev, st,
             detail=f"Cin{cin} Cout{cout} {T}x{H}x{W} k{kernel} s{stride}")

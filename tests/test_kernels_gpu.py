@@ -350,6 +350,8 @@ CONV_CASES = [  # N, Cin, Cout, (T,H,W), kernel, stride, pad
     (1, 48, 80, (5, 7, 7), (3, 3, 3), (1, 1, 1), (1, 1, 1)),        # partial channel stage
     (1, 8, 24, (7, 5, 5), (3, 3, 3), (1, 1, 1), (2, 1, 1)),         # causal-style front padding only on T (back pad 0)
     (2, 16, 8, (4, 9, 9), (1, 3, 3), (1, 2, 2), (0, 1, 1)),
+    (2, 64, 136, (4, 12, 12), (3, 3, 3), (1, 1, 1), (1, 1, 1)),     # several row panels x column tiles (last one partial)
+    (3, 160, 160, (3, 8, 8), (3, 3, 3), (1, 1, 1), (1, 1, 1)),      # MobileViT-S last stage
 ]
 
 
