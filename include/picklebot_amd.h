@@ -34,7 +34,7 @@ typedef enum {
   PB_ACT_HSIGMOID = 4, PB_ACT_SILU = 5
 } pb_act;
 
-#define PB_ABI_VERSION 7
+#define PB_ABI_VERSION 8
 
 /* Per-channel statistics buffers (`stats`, `sums` below) are PB_STAT_REPLICAS replicas of [2][C]
  * fp32, layout [replica][2][C], zero-filled by the caller.  A workgroup adds its partial sums into
@@ -92,6 +92,16 @@ int pb_pwconv_fwd_bf16w(const void* x, const void* wb, void* y, int64_t M, int K
 int pb_pwconv_bwd_weight(const void* dy, const void* x, float* dw, int64_t M, int K, int N, pb_dtype dtype,
                          const float* in_scale, const float* in_shift, pb_act in_act, float in_slope,
                          const float* row_scale, int64_t rows_per_group, int device, void* stream);
+/* The same with a caller-provided workspace: the row ranges store partial dW tiles in `ws` and a second kernel adds
+ * them into dw, instead of fp32 atomics (a CU retires ~1 float atomic per clock: 25-30 us per launch whatever the
+ * layer).  pb_pwconv_bwd_weight_ws_bytes returns the size this shape wants (0: the shape takes a kernel that does not
+ * use one); ws may be NULL or smaller, then the atomic epilogue runs.  ws and dw 16-byte aligned. */
+int64_t pb_pwconv_bwd_weight_ws_bytes(int64_t M, int K, int N, pb_dtype dtype, int has_affine, int has_row_scale,
+                                      int64_t rows_per_group, int device);
+int pb_pwconv_bwd_weight_ws(const void* dy, const void* x, float* dw, int64_t M, int K, int N, pb_dtype dtype,
+                            const float* in_scale, const float* in_shift, pb_act in_act, float in_slope,
+                            const float* row_scale, int64_t rows_per_group, void* ws, int64_t ws_bytes, int device,
+                            void* stream);
 
 /* ---------------------------------------------------------------- dense 3-D convolution (implicit GEMM)
  * Replaces nn.Conv3d(Cin,Cout,k,stride,padding,bias=False) with groups=1: mobilevit.py:19-24 (the

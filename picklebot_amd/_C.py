@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libpicklebot_amd.so")
 
 PB_F32, PB_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY_RELU, ACT_HSWISH, ACT_HSIGMOID, ACT_SILU = range(6)
-ABI_VERSION = 7
+ABI_VERSION = 8
 STAT_REPLICAS = 16
 
 
@@ -38,6 +38,7 @@ P, F, I, L, D = c_void_p, c_float, c_int, c_int64, c_double
 SIGNATURES = {
     "pb_pwconv_fwd": [P, P, P, L, I, I, I, I, I, P, P, I, F, P, L, P, P, I, F, P, I, P],
     "pb_pwconv_bwd_weight": [P, P, P, L, I, I, I, P, P, I, F, P, L, I, P],
+    "pb_pwconv_bwd_weight_ws": [P, P, P, L, I, I, I, P, P, I, F, P, L, P, L, I, P],
     "pb_dwconv3d_fwd": [P, P, P, POINTER(DwShape), I, P, I, P],
     "pb_dwconv3d_bwd_data": [P, P, P, POINTER(DwShape), I, P, P, I, P],
     "pb_dwconv3d_bwd_weight": [P, P, P, POINTER(DwShape), I, P, P, I, P],
@@ -75,6 +76,11 @@ STRING_SIGNATURES = {
     "pb_dwconv3d_kernel_name": [POINTER(DwShape), I, I],
 }
 
+# entry points returning a size (int64) instead of a status
+SIZE_SIGNATURES = {
+    "pb_pwconv_bwd_weight_ws_bytes": [L, I, I, I, I, I, L, I],
+}
+
 
 def load():
     """Load (once) and type the library.  Raises RuntimeError when it is not built."""
@@ -97,6 +103,10 @@ def load():
     for name, args in STRING_SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = c_char_p
+        fn.argtypes = args
+    for name, args in SIZE_SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = ctypes.c_int64
         fn.argtypes = args
     if lib.pb_abi_version() != ABI_VERSION:
         raise RuntimeError(f"picklebot_amd: ABI version mismatch ({lib.pb_abi_version()} != {ABI_VERSION}); rebuild")

@@ -564,6 +564,7 @@ struct WgArgs {
   int split;           // pw_wgrad128: number of row ranges (grid.x is padded to 8 * tiles * ceil(split/8))
   // CONV: blockIdx.z = filter tap, X rows are the tap-shifted input voxels, dW is [N][taps][K]
   int cTi, cHi, cWi, cTo, cHo, cWo, ckt, ckh, ckw, cst, csh, csw, cpt, cph, cpw;
+  float* P;            // pw_wgrad128_dma: per-range partial tiles [split][N][K] (plain stores) instead of atomics into dW
 };
 
 // Each wave streams 32-row blocks of dY[:, n-tile] and X[:, k-tile] through its private LDS
@@ -1116,8 +1117,32 @@ __global__ __launch_bounds__(256) void pw_wgrad128_dma_kernel(WgArgs a) {
       for (int r = 0; r < 4; ++r) {
         const int n = n0 + wn * 64 + i * 16 + (lane >> 4) * 4 + r;
         const int k = k0 + wk * 64 + j * 16 + (lane & 15);
-        if (n < a.N && k < a.K) atomicAdd(a.dW + (int64_t)n * a.K + k, acc[i][j][r] * sk[j]);
+        if (n < a.N && k < a.K) {
+          // a CU retires float atomics at ~1 per clock: 16 K of them per workgroup cost 25-30 us whatever the layer
+          // (measured: 39 -> 11 us without them at M = 8192).  With a workspace every range stores its partial
+          // tile (64-byte runs, plain stores) and pw_wgrad_reduce_kernel adds the ranges up.
+          if (a.P) a.P[((int64_t)srange * a.N + n) * a.K + k] = acc[i][j][r] * sk[j];
+          else atomicAdd(a.dW + (int64_t)n * a.K + k, acc[i][j][r] * sk[j]);
+        }
       }
+}
+
+// dW[e] += sum over the row ranges of P[s][e]
+__global__ __launch_bounds__(256) void pw_wgrad_reduce_kernel(const float* P, float* dW, int64_t nk4, int split) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= nk4) return;
+  const f32x4* p = reinterpret_cast<const f32x4*>(P) + e;
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+  int i = 0;
+  for (; i + 4 <= split; i += 4) {
+    s0 += p[(int64_t)i * nk4];
+    s1 += p[(int64_t)(i + 1) * nk4];
+    s2 += p[(int64_t)(i + 2) * nk4];
+    s3 += p[(int64_t)(i + 3) * nk4];
+  }
+  for (; i < split; ++i) s0 += p[(int64_t)i * nk4];
+  f32x4* o = reinterpret_cast<f32x4*>(dW) + e;
+  *o = *o + ((s0 + s1) + (s2 + s3));
 }
 
 int pick_nt(int N, bool f32) {
@@ -1233,63 +1258,112 @@ extern "C" int pb_pwconv_fwd(const void* x, const float* w, void* y, int64_t M, 
   return 0;
 }
 
-extern "C" int pb_pwconv_bwd_weight(const void* dy, const void* x, float* dw, int64_t M, int K, int N,
-                                    pb_dtype dtype, const float* in_scale, const float* in_shift, pb_act in_act,
-                                    float in_slope, const float* row_scale, int64_t rows_per_group, int device,
-                                    void* stream) {
+namespace {
+
+// launch plan of the 128x128-tile weight-gradient kernels (shared by the launcher and the workspace-size query)
+struct WgPlan {
+  bool dma;
+  int ns, n_tiles, k_tiles, ranges_per_group;
+  int64_t split, rows_per_wg;
+};
+
+WgPlan wgrad128_plan(int64_t M, int K, int N, bool has_row_scale, bool affine, int64_t rows_per_group, bool with_ws, int device) {
+  WgPlan p;
+  p.n_tiles = (int)pb_cdiv(N, 128);
+  p.k_tiles = (int)pb_cdiv(K, 128);
+  const int64_t tiles128 = (int64_t)p.n_tiles * p.k_tiles;
+  // One round of co-resident workgroups (a second, nearly empty round would double the time).
+  // Atomic epilogue: every workgroup is one atomic writer per element of its dW tile and same-address float atomics
+  // serialise (~25 ns each), so layers with few tiles get fewer, deeper workgroups: 1 per CU with a 6-stage ring
+  // (80 KB in flight) instead of 3 per CU with 3 stages.  Workspace epilogue: every workgroup writes and the
+  // reduction re-reads a 64 KB partial tile, so the grid is sized by PB_WGRAD_WS_WGS workgroups per CU.
+  static int cus = 0;
+  if (cus == 0 && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) cus = 256;
+  static const int force_ns = getenv("PB_WGRAD_NS") ? atoi(getenv("PB_WGRAD_NS")) : 0;
+  static const int small_tiles = getenv("PB_WGRAD_SMALL_TILES") ? atoi(getenv("PB_WGRAD_SMALL_TILES")) : 4;
+  static const int small_ns = getenv("PB_WGRAD_SMALL_NS") ? atoi(getenv("PB_WGRAD_SMALL_NS")) : 6;
+  static const int ws_ns = getenv("PB_WGRAD_WS_NS") ? atoi(getenv("PB_WGRAD_WS_NS")) : 0;
+  int ns = force_ns ? force_ns : (tiles128 <= small_tiles ? small_ns : 3);
+  if (with_ws && ws_ns) ns = ws_ns;
+  if (ns != 3 && ns != 4 && ns != 6) ns = 3;
+  p.ns = ns;
+  const int per_cu = ns == 3 ? 3 : (ns == 4 ? 2 : 1);        // 48 / 64 / 96 KB of LDS per workgroup
+  const int64_t target_wgs = (int64_t)per_cu * cus;
+  int64_t split = target_wgs / tiles128;
+  static const int ws_min_rows = getenv("PB_WGRAD_WS_MINROWS") ? atoi(getenv("PB_WGRAD_WS_MINROWS")) : 256;
+  const int64_t max_split128 = pb_cdiv(M, with_ws ? ws_min_rows : 256);
+  if (split > max_split128) split = max_split128;
+  if (split < 1) split = 1;
+  p.rows_per_wg = pb_cdiv(pb_cdiv(M, split), 32) * 32;
+  split = pb_cdiv(M, p.rows_per_wg);
+  p.ranges_per_group = 0;
+  const bool se_only = has_row_scale && !affine;
+  if (se_only && rows_per_group >= 64 && M % rows_per_group == 0) {
+    // clip-aligned ranges (the squeeze-excite scale then applies to the accumulators): at most the
+    // same number of workgroups, none straddling two clips
+    const int64_t clips = M / rows_per_group;
+    int64_t rpc = split / clips;
+    if (rpc < 1) rpc = 1;
+    p.rows_per_wg = pb_cdiv(pb_cdiv(rows_per_group, rpc), 32) * 32;
+    rpc = pb_cdiv(rows_per_group, p.rows_per_wg);
+    p.ranges_per_group = (int)rpc;
+    split = clips * rpc;
+  }
+  p.split = split;
+  const bool in_loop_prologue = p.ranges_per_group == 0 && (has_row_scale || affine);
+  static const bool dma_on = !(getenv("PB_WGRAD_DMA") && atoi(getenv("PB_WGRAD_DMA")) == 0);
+  p.dma = !in_loop_prologue && dma_on;
+  return p;
+}
+
+bool wgrad_is_big(int K, int N, pb_dtype dtype) {
+  return dtype == PB_BF16 && (N > 64 || K > 64) && (N % 8) == 0 && (K % 8) == 0;
+}
+
+}  // namespace
+
+extern "C" int64_t pb_pwconv_bwd_weight_ws_bytes(int64_t M, int K, int N, pb_dtype dtype, int has_affine, int has_row_scale,
+                                                 int64_t rows_per_group, int device) {
+  static const bool ws_on = !(getenv("PB_WGRAD_WS") && atoi(getenv("PB_WGRAD_WS")) == 0);
+  if (!ws_on || M <= 0 || K <= 0 || N <= 0 || !wgrad_is_big(K, N, dtype)) return 0;
+  const WgPlan p = wgrad128_plan(M, K, N, has_row_scale != 0, has_affine != 0, rows_per_group > 0 ? rows_per_group : 1, true, device);
+  return p.dma ? p.split * (int64_t)N * K * 4 : 0;
+}
+
+extern "C" int pb_pwconv_bwd_weight_ws(const void* dy, const void* x, float* dw, int64_t M, int K, int N,
+                                       pb_dtype dtype, const float* in_scale, const float* in_shift, pb_act in_act,
+                                       float in_slope, const float* row_scale, int64_t rows_per_group, void* ws,
+                                       int64_t ws_bytes, int device, void* stream) {
   PB_CHECK_ARG(dy && x && dw, "pb_pwconv_bwd_weight: null pointer");
   PB_CHECK_ARG(M >= 0 && K > 0 && N > 0, "pb_pwconv_bwd_weight: bad sizes");
   PB_CHECK_ARG(dtype == PB_F32 || dtype == PB_BF16, "pb_pwconv_bwd_weight: bad dtype %d", (int)dtype);
   PB_CHECK_ARG(!row_scale || rows_per_group > 0, "pb_pwconv_bwd_weight: row_scale needs rows_per_group > 0");
   PB_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0, "pb_pwconv_bwd_weight: unaligned pointer");
+  PB_CHECK_ARG(!ws || ((uintptr_t)ws % 16) == 0, "pb_pwconv_bwd_weight: unaligned workspace");
   if (M == 0) return 0;
   PB_ENTER(device);
   WgArgs a;
+  a.P = nullptr;
   a.dY = dy; a.X = x; a.dW = dw; a.M = M; a.K = K; a.N = N;
   a.in_scale = in_scale; a.in_shift = in_shift; a.in_act = (int)in_act; a.in_slope = in_slope;
   a.row_scale = row_scale; a.rows_per_group = rows_per_group > 0 ? rows_per_group : 1;
-  const bool big = dtype == PB_BF16 && (N > 64 || K > 64) && (N % 8) == 0 && (K % 8) == 0;
+  const bool big = wgrad_is_big(K, N, dtype);
   if (big) {
-    a.n_tiles = (int)pb_cdiv(N, 128);
-    a.k_tiles = (int)pb_cdiv(K, 128);
-    const int64_t tiles128 = (int64_t)a.n_tiles * a.k_tiles;
-    // One round of co-resident workgroups (a second, nearly empty round would double the time).  Every
-    // workgroup is also one atomic writer per element of its dW tile and same-address float atomics
-    // serialise (~25 ns each), so layers with few tiles get fewer, deeper workgroups: 1 per CU with a
-    // 6-stage ring (80 KB in flight) instead of 3 per CU with 3 stages.
-    static int cus = 0;
-    if (cus == 0 && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) cus = 256;
-    static const int force_ns = getenv("PB_WGRAD_NS") ? atoi(getenv("PB_WGRAD_NS")) : 0;
-    static const int small_tiles = getenv("PB_WGRAD_SMALL_TILES") ? atoi(getenv("PB_WGRAD_SMALL_TILES")) : 4;
-    static const int small_ns = getenv("PB_WGRAD_SMALL_NS") ? atoi(getenv("PB_WGRAD_SMALL_NS")) : 6;
-    int ns = force_ns ? force_ns : (tiles128 <= small_tiles ? small_ns : 3);
-    if (ns != 3 && ns != 4 && ns != 6) ns = 3;
-    const int per_cu = ns == 3 ? 3 : (ns == 4 ? 2 : 1);        // 48 / 64 / 96 KB of LDS per workgroup
-    const int64_t target_wgs = (int64_t)per_cu * cus;
-    int64_t split = target_wgs / tiles128;
-    const int64_t max_split128 = pb_cdiv(M, 256);
-    if (split > max_split128) split = max_split128;
-    if (split < 1) split = 1;
-    a.rows_per_wg = pb_cdiv(pb_cdiv(M, split), 32) * 32;
-    split = pb_cdiv(M, a.rows_per_wg);
-    a.ranges_per_group = 0;
-    const bool se_only = row_scale && !in_scale && !in_shift && in_act == PB_ACT_NONE;
-    if (se_only && rows_per_group >= 64 && M % rows_per_group == 0) {
-      // clip-aligned ranges (the squeeze-excite scale then applies to the accumulators): at most the
-      // same number of workgroups, none straddling two clips
-      const int64_t clips = M / rows_per_group;
-      int64_t rpc = split / clips;
-      if (rpc < 1) rpc = 1;
-      a.rows_per_wg = pb_cdiv(pb_cdiv(rows_per_group, rpc), 32) * 32;
-      rpc = pb_cdiv(rows_per_group, a.rows_per_wg);
-      a.ranges_per_group = (int)rpc;
-      split = clips * rpc;
+    const bool affine = in_scale || in_shift || in_act != PB_ACT_NONE;
+    WgPlan p = wgrad128_plan(M, K, N, row_scale != nullptr, affine, a.rows_per_group, ws != nullptr, device);
+    if (ws && !(p.dma && ws_bytes >= p.split * (int64_t)N * K * 4 && ((uintptr_t)dw % 16) == 0)) {
+      ws = nullptr;                                   // no use for it (or too small): atomic epilogue
+      p = wgrad128_plan(M, K, N, row_scale != nullptr, affine, a.rows_per_group, false, device);
     }
-    a.split = (int)split;
-    const bool in_loop_prologue = a.ranges_per_group == 0 && (row_scale || in_scale || in_shift || in_act != PB_ACT_NONE);
-    const dim3 grid((unsigned)(tiles128 * 8 * pb_cdiv(split, 8)));
-    static const bool dma_on = !(getenv("PB_WGRAD_DMA") && atoi(getenv("PB_WGRAD_DMA")) == 0);
-    if (!in_loop_prologue && dma_on) {
+    a.n_tiles = p.n_tiles; a.k_tiles = p.k_tiles;
+    const int64_t tiles128 = (int64_t)a.n_tiles * a.k_tiles;
+    a.rows_per_wg = p.rows_per_wg;
+    a.ranges_per_group = p.ranges_per_group;
+    a.split = (int)p.split;
+    const int ns = p.ns;
+    const dim3 grid((unsigned)(tiles128 * 8 * pb_cdiv(p.split, 8)));
+    if (p.dma) {
+      a.P = (float*)ws;
       static bool attr_done = false;
       if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)pw_wgrad128_dma_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 16384);
@@ -1298,6 +1372,11 @@ extern "C" int pb_pwconv_bwd_weight(const void* dy, const void* x, float* dw, in
       if (ns == 6) hipLaunchKernelGGL((pw_wgrad128_dma_kernel<6>), grid, dim3(256), 6 * 16384, (hipStream_t)stream, a);
       else if (ns == 4) hipLaunchKernelGGL((pw_wgrad128_dma_kernel<4>), grid, dim3(256), 4 * 16384, (hipStream_t)stream, a);
       else hipLaunchKernelGGL((pw_wgrad128_dma_kernel<3>), grid, dim3(256), 3 * 16384, (hipStream_t)stream, a);
+      if (a.P) {
+        const int64_t nk4 = (int64_t)N * K / 4;
+        hipLaunchKernelGGL(pw_wgrad_reduce_kernel, dim3((unsigned)pb_cdiv(nk4, 256)), dim3(256), 0, (hipStream_t)stream, a.P, dw,
+                           nk4, a.split);
+      }
     } else {
       hipLaunchKernelGGL((pw_wgrad128_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, a);
     }
@@ -1479,4 +1558,12 @@ extern "C" int pb_conv3d_bwd_weight(const void* dy, const void* x, float* dwp, c
   }
   PB_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int pb_pwconv_bwd_weight(const void* dy, const void* x, float* dw, int64_t M, int K, int N,
+                                    pb_dtype dtype, const float* in_scale, const float* in_shift, pb_act in_act,
+                                    float in_slope, const float* row_scale, int64_t rows_per_group, int device,
+                                    void* stream) {
+  return pb_pwconv_bwd_weight_ws(dy, x, dw, M, K, N, dtype, in_scale, in_shift, in_act, in_slope, row_scale, rows_per_group,
+                                 nullptr, 0, device, stream);
 }

@@ -316,6 +316,9 @@ def pw_fwd(x, w, *, w_transposed=False, in_scale=None, in_shift=None, in_act="no
     return y
 
 
+_ws_bytes = {}
+
+
 def pw_bwd_weight(dy, x, dw, *, in_scale=None, in_shift=None, in_act="none", in_slope=0.0, row_scale=None,
                   rows_per_group=0):
     """dw[N,K] += dy[M,N]^T @ P(x)[M,K]."""
@@ -335,8 +338,16 @@ def pw_bwd_weight(dy, x, dw, *, in_scale=None, in_shift=None, in_act="none", in_
     affine = in_scale is not None or in_shift is not None or in_act != "none"
     se_inloop = row_scale is not None and (rows_per_group < 64 or M % max(rows_per_group, 1))
     family = "pw_wgrad_kernel" if not big else ("pw_wgrad128_kernel" if (affine or se_inloop) else "pw_wgrad128_dma_kernel")
-    _launch(family, _nb(dy, x, dw), "pb_pwconv_bwd_weight", _p(dy), _p(x), _p(dw), M, K, N, _dt(x), _p(in_scale), _p(in_shift),
-            ACT[in_act], float(in_slope), _p(row_scale), int(rows_per_group), dev, st, detail=f"M{M} K{K} N{N}")
+    # workspace for the row ranges' partial tiles (plain stores + a reduction instead of 16 K float atomics per workgroup)
+    key = (M, K, N, x.dtype, affine, row_scale is not None, int(rows_per_group), dev)
+    nws = _ws_bytes.get(key)
+    if nws is None:
+        nws = _ws_bytes[key] = int(_C.load().pb_pwconv_bwd_weight_ws_bytes(M, K, N, _dt(x), int(affine), int(row_scale is not None),
+                                                                           int(rows_per_group), dev))
+    ws = torch.empty(nws // 4, dtype=torch.float32, device=x.device) if nws and dw.data_ptr() % 16 == 0 else None
+    _launch(family, _nb(dy, x, dw), "pb_pwconv_bwd_weight_ws", _p(dy), _p(x), _p(dw), M, K, N, _dt(x), _p(in_scale), _p(in_shift),
+            ACT[in_act], float(in_slope), _p(row_scale), int(rows_per_group), _p(ws), nws if ws is not None else 0, dev, st,
+            detail=f"M{M} K{K} N{N}")
     return dw
 
 

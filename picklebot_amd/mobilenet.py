@@ -32,7 +32,7 @@ def act_of(module):
 
 def compute_dtype(x):
     if torch.is_autocast_enabled():
-        dt = torch.get_autocast_gpu_dtype()
+        dt = torch.get_autocast_dtype("cuda")
         if dt != torch.bfloat16:
             raise NotImplementedError(f"picklebot_amd: autocast dtype {dt} not supported (bf16 only, train.py:264)")
         return dt

@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--detail", default=None)
     ap.add_argument("--fp32", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="also time the step replayed from one HIP graph (as bench.py does)")
     args = ap.parse_args()
 
     import picklebot_amd as pb
@@ -61,7 +62,7 @@ def main():
         x = x.to(torch.bfloat16)
     x = x.to(memory_format=torch.channels_last_3d)
     y = torch.randint(0, 13, (args.batch,), device=dev)
-    opt = torch.optim.AdamW(model.parameters(), lr=3e-4, fused=True) if train else None
+    opt = torch.optim.AdamW(model.parameters(), lr=3e-4, fused=True, capturable=args.graph) if train else None
 
     def step():
         if train:
@@ -83,6 +84,31 @@ def main():
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / args.steps * 1e3
 
+    graph_ms = None
+    if args.graph:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        if train:
+            opt.zero_grad(set_to_none=True)
+        g = torch.cuda.CUDAGraph()
+        K.reset_zero_arena()
+        with torch.cuda.graph(g):
+            step()
+        K.reset_zero_arena()
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(4 * args.steps):
+            g.replay()
+        torch.cuda.synchronize()
+        graph_ms = (time.perf_counter() - t0) / (4 * args.steps) * 1e3
+        print(f"{w} batch {args.batch}: {graph_ms:.3f} ms/step replayed from a HIP graph ({args.batch / graph_ms * 1e3:.1f} clips/s)")
+
     K.start_profile()
     for _ in range(args.steps):
         step()
@@ -100,7 +126,8 @@ def main():
             for k, d in sorted(detail.items(), key=lambda kv: -kv[1]["ms"]):
                 f.write("%-100s n=%3d  %8.1f us/launch  %7.1f GB/s\n" % (
                     k, d["launches"] // args.steps, d["ms"] / d["launches"] * 1e3, d["bytes"] / 1e6 / max(d["ms"], 1e-9)))
-    print(json.dumps({"workload": w, "batch": args.batch, "ms_per_step": round(ms, 3)}))
+    print(json.dumps({"workload": w, "batch": args.batch, "ms_per_step_eager": round(ms, 3),
+                      "ms_per_step_hipgraph": None if graph_ms is None else round(graph_ms, 3)}))
 
 
 if __name__ == "__main__":
