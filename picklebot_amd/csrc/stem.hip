@@ -492,10 +492,13 @@ __device__ __forceinline__ S3Item s3_item(const pb_stem_shape& s, int64_t it, in
   return q;
 }
 
-__global__ __launch_bounds__(256) void stem3_wgrad_kernel(StemArgs a) {
+// 16 waves per workgroup: every workgroup ends with 1312 float atomics onto the same addresses, and those serialise
+// chip-wide (measured +147 us per 1024 extra workgroups) - same wave count per CU from a quarter of the workgroups
+constexpr int S3W_NW = 16;
+__global__ __launch_bounds__(64 * S3W_NW) void stem3_wgrad_kernel(StemArgs a) {
   typedef bf16_t T;
-  __shared__ __attribute__((aligned(16))) T win_s[4][S3_MAXROWS * S3_SP * 8];
-  __shared__ __attribute__((aligned(16))) T dy_s[4][SW_PIX * OCB];
+  __shared__ __attribute__((aligned(16))) T win_s[S3W_NW][S3_MAXROWS * S3_SP * 8];
+  __shared__ __attribute__((aligned(16))) T dy_s[S3W_NW][SW_PIX * OCB];
   __shared__ float red[OCB * S3_MAXROWS * 16];
   const pb_stem_shape& s = a.s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -518,7 +521,7 @@ __global__ __launch_bounds__(256) void stem3_wgrad_kernel(StemArgs a) {
   // before this item's MFMAs, so one HBM round trip per item is no longer on the critical path
   S3Regs rg;
   Vec16<T> dyv;
-  const int64_t step = (int64_t)gridDim.x * 4;
+  const int64_t step = (int64_t)gridDim.x * S3W_NW;
   auto fetch = [&](int64_t it) {
     const S3Item q = s3_item(s, it, wblocks);
     s3_load(rg, x, s, q.n, q.to, q.ho, q.wo0, lane);
@@ -526,7 +529,7 @@ __global__ __launch_bounds__(256) void stem3_wgrad_kernel(StemArgs a) {
     const int p = lane * 8 / OCB;                          // 64 lanes x 16 B = the whole [32][16] tile
     dyv = p < q.npx ? vec_load<T>(dy + pix0 * OCB + (int64_t)lane * 8) : vec_zero<T>();
   };
-  int64_t it = (int64_t)blockIdx.x * 4 + wave;
+  int64_t it = (int64_t)blockIdx.x * S3W_NW + wave;
   if (it < nitems) fetch(it);
   for (; it < nitems; it += step) {
     s3_store(rg, win, nrows, lane);
@@ -551,7 +554,7 @@ __global__ __launch_bounds__(256) void stem3_wgrad_kernel(StemArgs a) {
     __builtin_amdgcn_wave_barrier();
   }
   // D[oc][n] per window row: n < 6 -> tap (aw = n/3, ci = n%3); 8 <= n < 11 -> (aw = 2, ci = n-8); row 0, n = 6 -> bias
-  for (int i = tid; i < OCB * S3_MAXROWS * 16; i += 256) red[i] = 0.f;
+  for (int i = tid; i < OCB * S3_MAXROWS * 16; i += 64 * S3W_NW) red[i] = 0.f;
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < S3_MAXROWS; ++r)
@@ -559,7 +562,7 @@ __global__ __launch_bounds__(256) void stem3_wgrad_kernel(StemArgs a) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) atomicAdd(&red[((lane >> 4) * 4 + i) * (S3_MAXROWS * 16) + r * 16 + (lane & 15)], acc[r][i]);
   __syncthreads();
-  for (int i = tid; i < OCB * (CT + 1); i += 256) {
+  for (int i = tid; i < OCB * (CT + 1); i += 64 * S3W_NW) {
     const int oc = i / (CT + 1), c = i - oc * (CT + 1);
     if (oc0 + oc >= s.Cout) continue;
     if (c < CT) {
@@ -755,7 +758,12 @@ extern "C" int pb_stem_conv3d_bwd_weight(const void* dy, const void* x, int x_dt
   int64_t gx = pb_cdiv(items, 4);
   if (gx > 1024) gx = 1024;
   dim3 grid((unsigned)gx, (unsigned)pb_cdiv(s->Cout, OCB));
-  if (stem3_ok(s, x_dtype, dtype) && x_scale == 1.f) hipLaunchKernelGGL(stem3_wgrad_kernel, grid, dim3(256), 0, st, a);
+  if (stem3_ok(s, x_dtype, dtype) && x_scale == 1.f) {
+    static const int wg_cap = getenv("PB_STEM_WGRAD_WGS") ? atoi(getenv("PB_STEM_WGRAD_WGS")) : 256;
+    int64_t g3 = pb_cdiv(items, S3W_NW);
+    if (g3 > wg_cap) g3 = wg_cap;
+    hipLaunchKernelGGL(stem3_wgrad_kernel, dim3((unsigned)g3, grid.y), dim3(64 * S3W_NW), 0, st, a);
+  }
   else PB_STEM_DISPATCH(stem_wgrad_kernel, grid);
   PB_LAUNCH_CHECK();
   return 0;
