@@ -1127,22 +1127,33 @@ __global__ __launch_bounds__(256) void pw_wgrad128_dma_kernel(WgArgs a) {
       }
 }
 
-// dW[e] += sum over the row ranges of P[s][e]
+// dW[e] += sum over the row ranges of P[s][e].  A workgroup = 32 float4 columns x 8 range groups (N*K/4 columns alone
+// are ~100 workgroups of serial loops: measured 13 us per launch), combined through LDS.
 __global__ __launch_bounds__(256) void pw_wgrad_reduce_kernel(const float* P, float* dW, int64_t nk4, int split) {
-  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (e >= nk4) return;
-  const f32x4* p = reinterpret_cast<const f32x4*>(P) + e;
+  __shared__ f32x4 red[8][32];
+  const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int64_t e = (int64_t)blockIdx.x * 32 + col;
   f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
-  int i = 0;
-  for (; i + 4 <= split; i += 4) {
-    s0 += p[(int64_t)i * nk4];
-    s1 += p[(int64_t)(i + 1) * nk4];
-    s2 += p[(int64_t)(i + 2) * nk4];
-    s3 += p[(int64_t)(i + 3) * nk4];
+  if (e < nk4) {
+    const f32x4* p = reinterpret_cast<const f32x4*>(P) + e;
+    int i = grp;
+    for (; i + 24 < split; i += 32) {
+      s0 += p[(int64_t)i * nk4];
+      s1 += p[(int64_t)(i + 8) * nk4];
+      s2 += p[(int64_t)(i + 16) * nk4];
+      s3 += p[(int64_t)(i + 24) * nk4];
+    }
+    for (; i < split; i += 8) s0 += p[(int64_t)i * nk4];
   }
-  for (; i < split; ++i) s0 += p[(int64_t)i * nk4];
-  f32x4* o = reinterpret_cast<f32x4*>(dW) + e;
-  *o = *o + ((s0 + s1) + (s2 + s3));
+  red[grp][col] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (grp == 0 && e < nk4) {
+    f32x4 t = red[0][col];
+#pragma unroll
+    for (int g = 1; g < 8; ++g) t += red[g][col];
+    f32x4* o = reinterpret_cast<f32x4*>(dW) + e;
+    *o = *o + t;
+  }
 }
 
 int pick_nt(int N, bool f32) {
@@ -1290,7 +1301,7 @@ WgPlan wgrad128_plan(int64_t M, int K, int N, bool has_row_scale, bool affine, i
   const int per_cu = ns == 3 ? 3 : (ns == 4 ? 2 : 1);        // 48 / 64 / 96 KB of LDS per workgroup
   const int64_t target_wgs = (int64_t)per_cu * cus;
   int64_t split = target_wgs / tiles128;
-  static const int ws_min_rows = getenv("PB_WGRAD_WS_MINROWS") ? atoi(getenv("PB_WGRAD_WS_MINROWS")) : 256;
+  static const int ws_min_rows = getenv("PB_WGRAD_WS_MINROWS") ? atoi(getenv("PB_WGRAD_WS_MINROWS")) : 512;
   const int64_t max_split128 = pb_cdiv(M, with_ws ? ws_min_rows : 256);
   if (split > max_split128) split = max_split128;
   if (split < 1) split = 1;
@@ -1374,7 +1385,7 @@ extern "C" int pb_pwconv_bwd_weight_ws(const void* dy, const void* x, float* dw,
       else hipLaunchKernelGGL((pw_wgrad128_dma_kernel<3>), grid, dim3(256), 3 * 16384, (hipStream_t)stream, a);
       if (a.P) {
         const int64_t nk4 = (int64_t)N * K / 4;
-        hipLaunchKernelGGL(pw_wgrad_reduce_kernel, dim3((unsigned)pb_cdiv(nk4, 256)), dim3(256), 0, (hipStream_t)stream, a.P, dw,
+        hipLaunchKernelGGL(pw_wgrad_reduce_kernel, dim3((unsigned)pb_cdiv(nk4, 32)), dim3(256), 0, (hipStream_t)stream, a.P, dw,
                            nk4, a.split);
       }
     } else {

@@ -1,0 +1,20 @@
+#!/bin/bash
+# Refresh the judged profiles of the bench command (run on the GPU box through gpurun):
+#   kernel trace + stats (CSV), then FETCH_SIZE and WRITE_SIZE in separate PMC passes, then the default bench line.
+# Outputs under gpurun_out/prof_round/; copy the summaries into profiles/ afterwards (tools/pmc_summary.py).
+set -o pipefail
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/prof_round
+rm -rf $O && mkdir -p $O
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o trace -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-graph > $O/trace.log 2>&1 || { echo trace failed; tail -5 $O/trace.log; exit 1; }
+echo "trace done"
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -o fetch -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph > $O/fetch.log 2>&1 || { echo fetch failed; tail -5 $O/fetch.log; exit 1; }
+echo "fetch done"
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -o write -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph > $O/write.log 2>&1 || { echo write failed; tail -5 $O/write.log; exit 1; }
+echo "write done"
+cd $R
+timeout -k 10 600 python bench.py > $O/bench.jsonl 2> $O/bench.err || { echo bench failed; tail -5 $O/bench.err; exit 1; }
+tail -c 600 $O/bench.jsonl
+find $O -name "*.csv" | head -20
+du -sh $O
