@@ -1400,7 +1400,8 @@ extern "C" int pb_pwconv_bwd_weight_ws(const void* dy, const void* x, float* dw,
   const int64_t tiles = (int64_t)a.n_tiles * a.k_tiles;
   // ~1024 workgroups (4 per CU is what the 36 KB of LDS admits); every workgroup is one atomic writer
   // per address of its tile, so the M split is also capped for the atomics' sake
-  int64_t msplit = pb_cdiv(1024, tiles);
+  static const int small_wgs = getenv("PB_WGRAD_SMALL_WGS") ? atoi(getenv("PB_WGRAD_SMALL_WGS")) : 512;
+  int64_t msplit = pb_cdiv(small_wgs, tiles);
   const int64_t max_split = pb_cdiv(M, 128);
   if (msplit > max_split) msplit = max_split;
   if (msplit > 65535) msplit = 65535;
