@@ -953,6 +953,71 @@ __global__ __launch_bounds__(256) void pw_skinny_kernel(PwArgs a) {
   }
 }
 
+// The same for bf16 on the matrix cores: a workgroup owns 16 output columns, its four waves split K in 32-wide chunks
+// (two 16x16x32 MFMAs per chunk for the 32 rows), partial tiles meet in LDS.  The scalar kernel above spends its time
+// in 32 two-byte loads per k and 768 cross-lane shuffles per wave (50-75 us for the 32 x 960 x 1280 head layers).
+__global__ __launch_bounds__(256) void pw_skinny_mfma_kernel(PwArgs a) {
+  __shared__ float part[4][32][17];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r16 = lane & 15, kg = lane >> 4;
+  const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 32;
+  const int rows = min(32, (int)a.M - m0);
+  const bf16_t* X = (const bf16_t*)a.X + (int64_t)m0 * a.K;
+  const int n = n0 + r16;
+  const bool nok = n < a.N;
+  const bool xvec = (a.K & 7) == 0;
+  const bool wvec = !a.w_transposed && (a.ldw & 3) == 0;
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+  for (int k0 = wave * 32; k0 < a.K; k0 += 128) {
+    const int k = k0 + kg * 8;
+    bf16x8 a0 = {0, 0, 0, 0, 0, 0, 0, 0}, a1 = a0, b = a0;
+    if (xvec) {
+      if (k < a.K) {
+        if (r16 < rows) a0 = *reinterpret_cast<const bf16x8*>(X + (int64_t)r16 * a.K + k);
+        if (r16 + 16 < rows) a1 = *reinterpret_cast<const bf16x8*>(X + (int64_t)(r16 + 16) * a.K + k);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (k + j < a.K) {
+          if (r16 < rows) a0[j] = X[(int64_t)r16 * a.K + k + j];
+          if (r16 + 16 < rows) a1[j] = X[(int64_t)(r16 + 16) * a.K + k + j];
+        }
+    }
+    if (nok) {
+      if (wvec && k + 8 <= a.K) {
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(a.W + (int64_t)n * a.ldw + k);
+        const f32x4 w1 = *reinterpret_cast<const f32x4*>(a.W + (int64_t)n * a.ldw + k + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { b[j] = (bf16_t)w0[j]; b[4 + j] = (bf16_t)w1[j]; }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (k + j < a.K) b[j] = (bf16_t)(a.w_transposed ? a.W[(int64_t)(k + j) * a.ldw + n] : a.W[(int64_t)n * a.ldw + k + j]);
+      }
+    }
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b, acc1, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    part[wave][kg * 4 + r][r16] = acc0[r];
+    part[wave][16 + kg * 4 + r][r16] = acc1[r];
+  }
+  __syncthreads();
+  bf16_t* Y = (bf16_t*)a.Y;
+  for (int i = threadIdx.x; i < 32 * 16; i += 256) {
+    const int m = i >> 4, c = i & 15;
+    if (m < rows && n0 + c < a.N) {
+      float v = (part[0][m][c] + part[1][m][c]) + (part[2][m][c] + part[3][m][c]);
+      const float sc = a.out_scale ? a.out_scale[n0 + c] : 1.f;
+      const float sh = a.out_shift ? a.out_shift[n0 + c] : 0.f;
+      v = act_fwd(v * sc + sh, a.out_act, a.out_slope);
+      Y[(int64_t)(m0 + m) * a.N + n0 + c] = from_f32<bf16_t>(v);
+    }
+  }
+}
+
 // LDS-DMA variant of the 128 x 128 weight-gradient tile (plain streams: no affine prologue, no conv):
 // the 32-row blocks of dY[:, 128] and X[:, 128] go HBM -> LDS by global_load_lds_dwordx4 into a ring of
 // NS stage buffers, NS-1 blocks ahead of the MFMAs, with no registers and no commit pass in between.
@@ -1258,7 +1323,10 @@ extern "C" int pb_pwconv_fwd(const void* x, const float* w, void* y, int64_t M, 
   static const bool skinny_on = !(getenv("PB_SKINNY") && atoi(getenv("PB_SKINNY")) == 0);
   if (skinny_on && M <= 64 && !in_scale && !in_shift && in_act == PB_ACT_NONE && !row_scale && !stats) {
     const dim3 grid((unsigned)pb_cdiv(N, 4), (unsigned)pb_cdiv(M, 32));
-    if (dtype == PB_BF16) hipLaunchKernelGGL(pw_skinny_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    static const bool skinny_mfma = !(getenv("PB_SKINNY_MFMA") && atoi(getenv("PB_SKINNY_MFMA")) == 0);
+    if (dtype == PB_BF16 && skinny_mfma)
+      hipLaunchKernelGGL(pw_skinny_mfma_kernel, dim3((unsigned)pb_cdiv(N, 16), grid.y), dim3(256), 0, (hipStream_t)stream, a);
+    else if (dtype == PB_BF16) hipLaunchKernelGGL(pw_skinny_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(pw_skinny_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, a);
     PB_LAUNCH_CHECK();
     return 0;
