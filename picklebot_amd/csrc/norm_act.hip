@@ -4,6 +4,7 @@
 // is one contiguous span; per-channel sums are reduced thread -> LDS -> one atomic per workgroup
 // and channel.
 #include "pb_common.h"
+#include <stdlib.h>
 #include <type_traits>
 
 namespace {
@@ -284,7 +285,8 @@ int launch_ew(EwArgs a, hipStream_t st) {
   PB_CHECK_ARG(a.M < 0x7fffffffLL, "elementwise kernels: M must fit 31 bits");
   // as many workgroups as there are row groups, up to the cap: small tensors (the 7x7 / 14x14 stages) were
   // running 1 workgroup per CU with 8 dependent rows per thread - latency-bound at ~1 TB/s
-  int64_t gx = pb_cdiv(a.M, (int64_t)a.map.P * 8);           // 8 rows per thread on large tensors (measured best)
+  static const int sum_rows = getenv("PB_EW_SUM_ROWS") ? atoi(getenv("PB_EW_SUM_ROWS")) : 16;
+  int64_t gx = pb_cdiv(a.M, (int64_t)a.map.P * (a.sums ? sum_rows : 8));   // 8 rows per thread on large tensors (measured best)
   if (gx * a.map.chunks < 1024) {
     gx = pb_cdiv(a.M, (int64_t)a.map.P);                      // small tensor: spread it over ~1024 workgroups
     if (gx * a.map.chunks > 1024) gx = pb_cdiv(1024, a.map.chunks);
