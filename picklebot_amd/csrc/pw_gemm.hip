@@ -1625,7 +1625,8 @@ extern "C" int pb_conv3d_bwd_weight(const void* dy, const void* x, float* dwp, c
     a.n_tiles = (int)pb_cdiv(a.N, 128);
     a.k_tiles = (int)pb_cdiv(a.K, 128);
     const int64_t t128 = (int64_t)a.n_tiles * a.k_tiles;
-    int64_t split = pb_cdiv(2048, t128 * taps);
+    static const int conv_wgs = getenv("PB_CONV_WGRAD_WGS") ? atoi(getenv("PB_CONV_WGRAD_WGS")) : 2048;
+    int64_t split = pb_cdiv(conv_wgs, t128 * taps);
     if (split > pb_cdiv(a.M, 256)) split = pb_cdiv(a.M, 256);
     if (split < 1) split = 1;
     a.rows_per_wg = pb_cdiv(pb_cdiv(a.M, split), 32) * 32;
