@@ -16,6 +16,7 @@
 // contractions use all 32: slot (g,j) <-> index 4g+j (j<4) / 16+4g+(j-4) of a 32-wide pair of tiles).
 // fp32 (parity path): exact-f32 v_mfma_f32_16x16x4_f32, slot g of step r <-> index 4g+r of a tile.
 #include "pb_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -105,39 +106,45 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, g = lane >> 4;
   const float NEG = -3.0e38f;
+  // scores are kept in the log2 domain (scale * log2(e) folded into one multiplier, v_exp_f32 is exp2), and only the
+  // last key tile, the one that can hold keys >= n, pays for the mask
+  const float sl = a.scale * 1.44269504088896340736f;
+  const int nfull = n >> 4;                                  // key tiles without padding keys
   for (int qt = sp * nwv + wave; qt * 16 < n; qt += nwv * a.split) {
     const int q = qt * 16 + li;
     const bool qok = q < n;
     const Frag<T> qf = load_rowfrag<T>(qok ? base + (int64_t)q * QKV_LD : nullptr, g);
     // pass 1: running max / sum over this lane's key rows (4g..4g+3 of every tile), merged over g afterwards
     float m = NEG, l = 0.f;
-    for (int kt = 0; kt * 16 < npad; ++kt) {
+    auto pass1_tile = [&](int kt, auto masked) {
       const Frag<T> kf = load_rowfrag<T>(Ks + (kt * 16 + li) * HD, g);
       const f32x4 s = mma_d16<T>(kf, qf);
       float sv[4], mx = m;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        sv[r] = (kt * 16 + 4 * g + r < n) ? s[r] * a.scale : NEG;
+        sv[r] = (!decltype(masked)::value || kt * 16 + 4 * g + r < n) ? s[r] * sl : NEG;
         mx = fmaxf(mx, sv[r]);
       }
-      float acc = l * __expf(m - mx);
+      float acc = l * __builtin_amdgcn_exp2f(m - mx);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc += __expf(sv[r] - mx);
+      for (int r = 0; r < 4; ++r) acc += __builtin_amdgcn_exp2f(sv[r] - mx);
       l = acc;
       m = mx;
-    }
+    };
+    for (int kt = 0; kt < nfull; ++kt) pass1_tile(kt, std::false_type{});
+    for (int kt = nfull; kt * 16 < npad; ++kt) pass1_tile(kt, std::true_type{});
 #pragma unroll
     for (int off = 16; off <= 32; off <<= 1) {
       const float m2 = __shfl_xor(m, off, 64), l2 = __shfl_xor(l, off, 64);
       const float mn = fmaxf(m, m2);
-      l = l * __expf(m - mn) + l2 * __expf(m2 - mn);
+      l = l * __builtin_amdgcn_exp2f(m - mn) + l2 * __builtin_amdgcn_exp2f(m2 - mn);
       m = mn;
     }
     const float inv_l = 1.f / l;
     // pass 2: O^T[d][q] = sum_key V^T[d][key] * P^T[key][q]
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
     if constexpr (BF) {
-      for (int kp = 0; kp * 32 < npad; ++kp) {
+      auto pass2_pair = [&](int kp, auto masked) {
         bf16x8 pb;
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
@@ -146,7 +153,8 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnArgs a) {
           const f32x4 s = mma_d16<T>(kf, qf);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float p = (kt * 16 + 4 * g + r < n) ? __expf(s[r] * a.scale - m) * inv_l : 0.f;
+            float p = __builtin_amdgcn_exp2f(s[r] * sl - m) * inv_l;
+            if (decltype(masked)::value && !(kt * 16 + 4 * g + r < n)) p = 0.f;
             pb[4 * half + r] = (bf16_t)p;
           }
         }
@@ -155,7 +163,10 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnArgs a) {
         const bf16x4 v1 = *reinterpret_cast<const bf16x4*>(Vs + li * ldt + kp * 32 + 16 + 4 * g);
         const bf16x8 va = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
         o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, pb, o, 0, 0, 0);
-      }
+      };
+      const int pfull = n >> 5;                              // key-tile pairs without padding keys
+      for (int kp = 0; kp < pfull; ++kp) pass2_pair(kp, std::false_type{});
+      for (int kp = pfull; kp * 32 < npad; ++kp) pass2_pair(kp, std::true_type{});
     } else {
       for (int kt = 0; kt * 16 < npad; ++kt) {
         const Frag<T> kf = load_rowfrag<T>(Ks + (kt * 16 + li) * HD, g);
@@ -163,7 +174,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int key = kt * 16 + 4 * g + r;
-          const float p = (key < n) ? __expf(s[r] * a.scale - m) * inv_l : 0.f;
+          const float p = (key < n) ? __builtin_amdgcn_exp2f(s[r] * sl - m) * inv_l : 0.f;
           o = __builtin_amdgcn_mfma_f32_16x16x4f32(Vs[key * HD + li], p, o, 0, 0, 0);   // A[d = li][slot g] = V[key][d]
         }
       }
@@ -173,7 +184,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnArgs a) {
       T* op = (T*)a.out + ((int64_t)grp * n + q) * OUT_LD + h * HD + 4 * g;
 #pragma unroll
       for (int r = 0; r < 4; ++r) op[r] = from_f32<T>(o[r]);
-      if (g == 0) a.lse[((int64_t)grp * n + q) * NH + h] = m + __logf(l);
+      if (g == 0) a.lse[((int64_t)grp * n + q) * NH + h] = m * 0.69314718055994530942f + __logf(l);
     }
   }
 }
@@ -217,6 +228,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnArgs a) {
     const Frag<T> dof = load_rowfrag<T>(qok ? (const T*)a.dout + row * OUT_LD + h * HD : nullptr, g);
     const float L = qok ? a.lse[row * NH + h] : 0.f;
     const float dl = qok ? a.delta[row * NH + h] : 0.f;
+    const float sl = a.scale * 1.44269504088896340736f, L2 = L * 1.44269504088896340736f;
     f32x4 dq = {0.f, 0.f, 0.f, 0.f};
     if constexpr (BF) {
       for (int kp = 0; kp * 32 < npad; ++kp) {
@@ -228,10 +240,11 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnArgs a) {
           const Frag<T> vf = load_rowfrag<T>(Vs + (kt * 16 + li) * HD, g);
           const f32x4 s = mma_d16<T>(kf, qf);        // S^T[key][q]
           const f32x4 dp = mma_d16<T>(vf, dof);      // dP^T[key][q] = sum_d V[key][d] dO[q][d]
+          // no masks: a padded key has K = V = 0, so its (finite) dS meets a zero K^T column; a padded query has
+          // Q = dO = 0 and is never stored.  Scores in the log2 domain (v_exp_f32 is exp2).
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const bool ok = qok && (kt * 16 + 4 * g + r < n);
-            const float p = ok ? __expf(s[r] * a.scale - L) : 0.f;
+            const float p = __builtin_amdgcn_exp2f(fminf(s[r] * sl - L2, 0.f));   // (<= 0 for real keys; bounds the padded ones)
             dsb[4 * half + r] = (bf16_t)(p * (dp[r] - dl) * a.scale);
           }
         }
@@ -297,6 +310,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_dkv_kernel(AttnArgs a) {
     const Frag<T> kf = load_rowfrag<T>(kok ? base + NH * HD + (int64_t)key * QKV_LD : nullptr, g);
     const Frag<T> vf = load_rowfrag<T>(kok ? base + 2 * NH * HD + (int64_t)key * QKV_LD : nullptr, g);
     f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
+    const float sl = a.scale * 1.44269504088896340736f;
     if constexpr (BF) {
       for (int qp = 0; qp * 32 < npad; ++qp) {
         bf16x8 pb, dsb;
@@ -307,13 +321,14 @@ __global__ __launch_bounds__(1024) void attn_bwd_dkv_kernel(AttnArgs a) {
           const Frag<T> dof = load_rowfrag<T>(Os + (qt * 16 + li) * HD, g);
           const f32x4 s = mma_d16<T>(qf, kf);        // S[q][key]: rows q = 4g + r, column = key
           const f32x4 dp = mma_d16<T>(dof, vf);      // dP[q][key]
+          // no masks (see the dQ kernel): padded queries have Q = dO = 0 and lse = delta = 0, padded keys are not stored
+          const f32x4 l4 = *reinterpret_cast<const f32x4*>(Ls + qt * 16 + 4 * g);
+          const f32x4 d4 = *reinterpret_cast<const f32x4*>(Ds + qt * 16 + 4 * g);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int q = qt * 16 + 4 * g + r;
-            const bool ok = kok && q < n;
-            const float p = ok ? __expf(s[r] * a.scale - Ls[q]) : 0.f;
+            const float p = __builtin_amdgcn_exp2f(fminf(s[r] * sl - l4[r] * 1.44269504088896340736f, 0.f));
             pb[4 * half + r] = (bf16_t)p;
-            dsb[4 * half + r] = (bf16_t)(p * (dp[r] - Ds[q]) * a.scale);
+            dsb[4 * half + r] = (bf16_t)(p * (dp[r] - d4[r]) * a.scale);
           }
         }
         const bf16x4 o0 = *reinterpret_cast<const bf16x4*>(Ot + li * ldt + qp * 32 + 4 * g);
