@@ -34,16 +34,17 @@ __global__ __launch_bounds__(256) void se_gemv_kernel(const float* vec, float vs
 //   out[g][o] = oscale * omask(g,o) * sum_r W[r][o] * v[g][r]
 //   dh      (O = Cm, R = C ): W = W2 [C][Cm], v = dpre2,  omask = hidden[g][o] > 0
 //   g_shift (O = C,  R = Cm): W = W1 [Cm][C], v = dh,     oscale = inv_count
-__global__ __launch_bounds__(256) void se_gemvT_kernel(const float* W, const float* v, int64_t vstride, float* out,
-                                                       int64_t ostride, const float* omask_src, float oscale, int O,
-                                                       int R) {
-  __shared__ float part[4][64];
+constexpr int SE_RS = 16;     // reduction slices (waves) per workgroup: 60-240 dependent steps per thread with 4 were 12 us
+__global__ __launch_bounds__(64 * SE_RS) void se_gemvT_kernel(const float* W, const float* v, int64_t vstride, float* out,
+                                                              int64_t ostride, const float* omask_src, float oscale, int O,
+                                                              int R) {
+  __shared__ float part[SE_RS][64];
   const int ol = threadIdx.x & 63, rs = threadIdx.x >> 6;
   const int oblocks = (O + 63) / 64;
   const int g = blockIdx.x / oblocks, ob = blockIdx.x - g * oblocks;
   const int o = ob * 64 + ol;
   const float* vg = v + (int64_t)g * vstride;
-  const int rq = (R + 3) / 4, r0 = rs * rq, r1 = min(R, r0 + rq);
+  const int rq = (R + SE_RS - 1) / SE_RS, r0 = rs * rq, r1 = min(R, r0 + rq);
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (o < O) {
     int r = r0;
@@ -58,7 +59,9 @@ __global__ __launch_bounds__(256) void se_gemvT_kernel(const float* W, const flo
   part[rs][ol] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (rs == 0 && o < O) {
-    float s = (part[0][ol] + part[1][ol]) + (part[2][ol] + part[3][ol]);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < SE_RS; ++i) s += part[i][ol];
     if (omask_src && !(omask_src[(int64_t)g * O + o] > 0.f)) s = 0.f;
     out[(int64_t)g * ostride + o] = s * oscale;
   }
@@ -84,22 +87,26 @@ __global__ __launch_bounds__(256) void se_fc_bwd_w_kernel(const float* work, con
   if (idx < nW) {                       // dW2[c][j] = sum_g dpre2[g][c] * h[g][j]
     const int c = (int)(idx / Cm), j = (int)(idx - (int64_t)c * Cm);
     float s = 0.f;
+#pragma unroll 8
     for (int g = 0; g < G; ++g) s += work[(int64_t)g * stride + c] * hidden[(int64_t)g * Cm + j];
     dw2[idx] += s;
   } else if (idx < 2 * nW) {            // dW1[j][c] = sum_g dh[g][j] * mean[g][c]
     const int64_t i = idx - nW;
     const int j = (int)(i / C), c = (int)(i - (int64_t)j * C);
     float s = 0.f;
+#pragma unroll 8
     for (int g = 0; g < G; ++g) s += work[(int64_t)g * stride + C + j] * pool[(int64_t)g * C + c] * inv_count;
     dw1[i] += s;
   } else if (idx < 2 * nW + C) {        // db2
     const int c = (int)(idx - 2 * nW);
     float s = 0.f;
+#pragma unroll 8
     for (int g = 0; g < G; ++g) s += work[(int64_t)g * stride + c];
     if (db2) db2[c] += s;
   } else if (idx < 2 * nW + C + Cm) {   // db1
     const int j = (int)(idx - 2 * nW - C);
     float s = 0.f;
+#pragma unroll 8
     for (int g = 0; g < G; ++g) s += work[(int64_t)g * stride + C + j];
     if (db1) db1[j] += s;
   }
@@ -132,9 +139,9 @@ extern "C" int pb_se_fc_bwd(const float* dscale, const float* pool, float inv_co
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(se_dpre2_kernel, dim3((unsigned)pb_cdiv((int64_t)G * C, 256)), dim3(256), 0, st, dscale, scale, work,
                      G, C, Cm);
-  hipLaunchKernelGGL(se_gemvT_kernel, dim3((unsigned)(G * pb_cdiv(Cm, 64))), dim3(256), 0, st, w2, (const float*)work,
+  hipLaunchKernelGGL(se_gemvT_kernel, dim3((unsigned)(G * pb_cdiv(Cm, 64))), dim3(64 * SE_RS), 0, st, w2, (const float*)work,
                      (int64_t)(C + Cm), work + C, (int64_t)(C + Cm), hidden, 1.f, Cm, C);
-  hipLaunchKernelGGL(se_gemvT_kernel, dim3((unsigned)(G * pb_cdiv(C, 64))), dim3(256), 0, st, w1,
+  hipLaunchKernelGGL(se_gemvT_kernel, dim3((unsigned)(G * pb_cdiv(C, 64))), dim3(64 * SE_RS), 0, st, w1,
                      (const float*)(work + C), (int64_t)(C + Cm), g_shift, (int64_t)C, (const float*)nullptr, inv_count,
                      C, Cm);
   const int64_t total = 2LL * C * Cm + C + Cm;
