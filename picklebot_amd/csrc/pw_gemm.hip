@@ -954,7 +954,8 @@ __global__ __launch_bounds__(256) void pw_skinny_kernel(PwArgs a) {
 }
 
 // The same for bf16 on the matrix cores: a workgroup owns 16 output columns, its four waves split K in 32-wide chunks
-// (two 16x16x32 MFMAs per chunk for the 32 rows), partial tiles meet in LDS.  The scalar kernel above spends its time
+// (two 16x16x32 MFMAs per chunk for the 32 rows, twice: the fp32 weights enter as a bf16 hi + lo pair so that the head
+// keeps the accuracy of fp32 weights), partial tiles meet in LDS.  The scalar kernel above spends its time
 // in 32 two-byte loads per k and 768 cross-lane shuffles per wave (50-75 us for the 32 x 960 x 1280 head layers).
 __global__ __launch_bounds__(256) void pw_skinny_mfma_kernel(PwArgs a) {
   __shared__ float part[4][32][17];
@@ -970,7 +971,7 @@ __global__ __launch_bounds__(256) void pw_skinny_mfma_kernel(PwArgs a) {
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
   for (int k0 = wave * 32; k0 < a.K; k0 += 128) {
     const int k = k0 + kg * 8;
-    bf16x8 a0 = {0, 0, 0, 0, 0, 0, 0, 0}, a1 = a0, b = a0;
+    bf16x8 a0 = {0, 0, 0, 0, 0, 0, 0, 0}, a1 = a0, b = a0, bl = a0;   // W = b + bl: the fp32 weights keep ~16 mantissa bits
     if (xvec) {
       if (k < a.K) {
         if (r16 < rows) a0 = *reinterpret_cast<const bf16x8*>(X + (int64_t)r16 * a.K + k);
@@ -989,15 +990,24 @@ __global__ __launch_bounds__(256) void pw_skinny_mfma_kernel(PwArgs a) {
         const f32x4 w0 = *reinterpret_cast<const f32x4*>(a.W + (int64_t)n * a.ldw + k);
         const f32x4 w1 = *reinterpret_cast<const f32x4*>(a.W + (int64_t)n * a.ldw + k + 4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { b[j] = (bf16_t)w0[j]; b[4 + j] = (bf16_t)w1[j]; }
+        for (int j = 0; j < 4; ++j) {
+          b[j] = (bf16_t)w0[j]; b[4 + j] = (bf16_t)w1[j];
+          bl[j] = (bf16_t)(w0[j] - (float)b[j]); bl[4 + j] = (bf16_t)(w1[j] - (float)b[4 + j]);
+        }
       } else {
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-          if (k + j < a.K) b[j] = (bf16_t)(a.w_transposed ? a.W[(int64_t)(k + j) * a.ldw + n] : a.W[(int64_t)n * a.ldw + k + j]);
+          if (k + j < a.K) {
+            const float wv = a.w_transposed ? a.W[(int64_t)(k + j) * a.ldw + n] : a.W[(int64_t)n * a.ldw + k + j];
+            b[j] = (bf16_t)wv;
+            bl[j] = (bf16_t)(wv - (float)b[j]);
+          }
       }
     }
     acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b, acc0, 0, 0, 0);
     acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bl, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bl, acc1, 0, 0, 0);
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
