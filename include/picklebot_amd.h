@@ -34,7 +34,7 @@ typedef enum {
   PB_ACT_HSIGMOID = 4, PB_ACT_SILU = 5
 } pb_act;
 
-#define PB_ABI_VERSION 8
+#define PB_ABI_VERSION 9
 
 /* Per-channel statistics buffers (`stats`, `sums` below) are PB_STAT_REPLICAS replicas of [2][C]
  * fp32, layout [replica][2][C], zero-filled by the caller.  A workgroup adds its partial sums into
@@ -134,6 +134,12 @@ int pb_conv3d_fwd_bf16w(const void* x, const void* wb, void* y, const pb_conv_sh
                         int device, void* stream);
 int pb_conv3d_bwd_weight(const void* dy, const void* x, float* dwp, const pb_conv_shape* s, pb_dtype dtype, int device,
                          void* stream);
+/* The same on the LDS-DMA weight-gradient kernel (bf16): partial tiles per row range in `ws` (size from
+ * pb_conv3d_bwd_weight_ws_bytes; 0 = shape not eligible) + one reduction into dwp; zero16 = 16 zero bytes of device
+ * memory for the padding voxels.  Falls back to pb_conv3d_bwd_weight when ws is NULL / too small. */
+int64_t pb_conv3d_bwd_weight_ws_bytes(const pb_conv_shape* s, pb_dtype dtype, int device);
+int pb_conv3d_bwd_weight_ws(const void* dy, const void* x, float* dwp, const pb_conv_shape* s, pb_dtype dtype, void* ws,
+                            int64_t ws_bytes, const void* zero16, int device, void* stream);
 
 /* ---------------------------------------------------------------- depthwise 3-D convolution
  * Replaces nn.Conv3d(C,C,(kt,kh,kw),groups=C,bias=False) forward/backward:

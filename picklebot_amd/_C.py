@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libpicklebot_amd.so")
 
 PB_F32, PB_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY_RELU, ACT_HSWISH, ACT_HSIGMOID, ACT_SILU = range(6)
-ABI_VERSION = 8
+ABI_VERSION = 9
 STAT_REPLICAS = 16
 
 
@@ -66,6 +66,7 @@ SIGNATURES = {
     "pb_conv3d_fwd": [P, P, P, POINTER(ConvShape), I, P, P, I, F, P, I, P],
     "pb_conv3d_fwd_bf16w": [P, P, P, POINTER(ConvShape), P, P, P, I, F, P, I, P],
     "pb_conv3d_bwd_weight": [P, P, P, POINTER(ConvShape), I, I, P],
+    "pb_conv3d_bwd_weight_ws": [P, P, P, POINTER(ConvShape), I, P, L, P, I, P],
 }
 
 _lib = None
@@ -79,6 +80,7 @@ STRING_SIGNATURES = {
 # entry points returning a size (int64) instead of a status
 SIZE_SIGNATURES = {
     "pb_pwconv_bwd_weight_ws_bytes": [L, I, I, I, I, I, L, I],
+    "pb_conv3d_bwd_weight_ws_bytes": [POINTER(ConvShape), I, I],
 }
 
 

@@ -565,6 +565,7 @@ struct WgArgs {
   // CONV: blockIdx.z = filter tap, X rows are the tap-shifted input voxels, dW is [N][taps][K]
   int cTi, cHi, cWi, cTo, cHo, cWo, ckt, ckh, ckw, cst, csh, csw, cpt, cph, cpw;
   float* P;            // pw_wgrad128_dma: per-range partial tiles [split][N][K] (plain stores) instead of atomics into dW
+  const void* zero;    // CONV on the DMA kernel: 16 zero bytes in device memory (padding voxels)
 };
 
 // Each wave streams 32-row blocks of dY[:, n-tile] and X[:, k-tile] through its private LDS
@@ -1051,7 +1052,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned char* lds_dst)
 }
 __device__ __forceinline__ int wg_swz(int r) { return ((r & 3) | (((r >> 3) & 1) << 2)) << 1; }
 
-template <int NS>
+template <int NS, bool CONV = false>
 __global__ __launch_bounds__(256) void pw_wgrad128_dma_kernel(WgArgs a) {
   typedef bf16_t T;
   constexpr int TT = 128;
@@ -1097,13 +1098,30 @@ __global__ __launch_bounds__(256) void pw_wgrad128_dma_kernel(WgArgs a) {
     kok[i] = kcol[i] < a.K;
   }
   const int wave_off = __builtin_amdgcn_readfirstlane(wave * 1024);
+  // CONV (blockIdx.z = filter tap): the X row of output voxel m is the tap-shifted input voxel, or the zero page
+  const int tap = CONV ? (int)blockIdx.z : 0;
+  const int tap_w = CONV ? tap % a.ckw : 0, tap_h = CONV ? (tap / a.ckw) % a.ckh : 0, tap_t = CONV ? tap / (a.ckw * a.ckh) : 0;
   auto issue = [&](int64_t mb, int buf) {
     unsigned char* base = dsmem + buf * (2 * SLAB) + wave_off;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int64_t m = min(mb + rr[i], mend - 1);           // rows past the range re-read the last row; zeroed below
       if (nok[i]) glds16(dY + m * a.N + ncol[i], base + i * 4096);
-      if (kok[i]) glds16(X + m * a.K + kcol[i], base + SLAB + i * 4096);
+      if constexpr (CONV) {
+        if (kok[i]) {
+          const unsigned mu = (unsigned)m;
+          const unsigned wo = mu % (unsigned)a.cWo, r1 = mu / (unsigned)a.cWo;
+          const unsigned ho = r1 % (unsigned)a.cHo, r2 = r1 / (unsigned)a.cHo;
+          const unsigned to = r2 % (unsigned)a.cTo, n = r2 / (unsigned)a.cTo;
+          const int ti = (int)to * a.cst - a.cpt + tap_t, hi = (int)ho * a.csh - a.cph + tap_h, wi = (int)wo * a.csw - a.cpw + tap_w;
+          const T* src = (const T*)a.zero;
+          if ((unsigned)ti < (unsigned)a.cTi && (unsigned)hi < (unsigned)a.cHi && (unsigned)wi < (unsigned)a.cWi)
+            src = X + ((((int64_t)n * a.cTi + ti) * a.cHi + hi) * a.cWi + wi) * a.K + kcol[i];
+          glds16(src, base + SLAB + i * 4096);
+        }
+      } else {
+        if (kok[i]) glds16(X + m * a.K + kcol[i], base + SLAB + i * 4096);
+      }
     }
   };
 
@@ -1196,8 +1214,10 @@ __global__ __launch_bounds__(256) void pw_wgrad128_dma_kernel(WgArgs a) {
           // a CU retires float atomics at ~1 per clock: 16 K of them per workgroup cost 25-30 us whatever the layer
           // (measured: 39 -> 11 us without them at M = 8192).  With a workspace every range stores its partial
           // tile (64-byte runs, plain stores) and pw_wgrad_reduce_kernel adds the ranges up.
-          if (a.P) a.P[((int64_t)srange * a.N + n) * a.K + k] = acc[i][j][r] * sk[j];
-          else atomicAdd(a.dW + (int64_t)n * a.K + k, acc[i][j][r] * sk[j]);
+          const int64_t ldw = CONV ? (int64_t)a.ckt * a.ckh * a.ckw * a.K : a.K;      // dW is [N][taps][K] for CONV
+          const int64_t col = (CONV ? (int64_t)tap * a.K : 0) + k;
+          if (a.P) a.P[((int64_t)srange * a.N + n) * ldw + col] = acc[i][j][r] * sk[j];
+          else atomicAdd(a.dW + (int64_t)n * ldw + col, acc[i][j][r] * sk[j]);
         }
       }
 }
@@ -1657,4 +1677,65 @@ extern "C" int pb_pwconv_bwd_weight(const void* dy, const void* x, float* dw, in
                                     void* stream) {
   return pb_pwconv_bwd_weight_ws(dy, x, dw, M, K, N, dtype, in_scale, in_shift, in_act, in_slope, row_scale, rows_per_group,
                                  nullptr, 0, device, stream);
+}
+
+// Dense-conv weight gradient on the LDS-DMA kernel (bf16, any stride): grid z = filter taps, partial tiles into the
+// workspace, one reduction.  zero16: any 16 zero bytes of device memory.
+namespace {
+// row ranges of the DMA conv weight gradient: ~1536 workgroups over (128x128 tiles) x taps x ranges; 0 = not eligible
+int64_t conv_wgrad_dma_plan(const pb_conv_shape* s, pb_dtype dtype, int64_t* rows_per_wg) {
+  static const bool on = !(getenv("PB_CONV_WGRAD_DMA") && atoi(getenv("PB_CONV_WGRAD_DMA")) == 0);
+  if (!on || !s || dtype != PB_BF16 || s->Cin % 8 || s->Cout % 8) return 0;
+  const int taps = s->kt * s->kh * s->kw;
+  const int64_t M = (int64_t)s->N * s->To * s->Ho * s->Wo;
+  if (M <= 0 || M >= (1LL << 31) || taps > 65535) return 0;
+  const int64_t t128 = pb_cdiv(s->Cout, 128) * pb_cdiv(s->Cin, 128);
+  static const int conv_wgs = getenv("PB_CONV_WGRAD_DMA_WGS") ? atoi(getenv("PB_CONV_WGRAD_DMA_WGS")) : 1536;
+  int64_t split = conv_wgs / (t128 * taps);
+  if (split > pb_cdiv(M, 256)) split = pb_cdiv(M, 256);
+  if (split < 1) split = 1;
+  *rows_per_wg = pb_cdiv(pb_cdiv(M, split), 32) * 32;
+  return pb_cdiv(M, *rows_per_wg);
+}
+}  // namespace
+
+extern "C" int64_t pb_conv3d_bwd_weight_ws_bytes(const pb_conv_shape* s, pb_dtype dtype, int device) {
+  (void)device;
+  int64_t rows = 0;
+  const int64_t split = conv_wgrad_dma_plan(s, dtype, &rows);
+  return split ? split * (int64_t)s->Cout * (s->kt * s->kh * s->kw) * s->Cin * 4 : 0;
+}
+
+extern "C" int pb_conv3d_bwd_weight_ws(const void* dy, const void* x, float* dwp, const pb_conv_shape* s, pb_dtype dtype,
+                                       void* ws, int64_t ws_bytes, const void* zero16, int device, void* stream) {
+  const int64_t need = pb_conv3d_bwd_weight_ws_bytes(s, dtype, device);
+  if (!ws || !zero16 || need == 0 || ws_bytes < need || ((uintptr_t)ws % 16) || ((uintptr_t)dwp % 16))
+    return pb_conv3d_bwd_weight(dy, x, dwp, s, dtype, device, stream);
+  PB_CHECK_ARG(dy && x && dwp, "pb_conv3d_bwd_weight_ws: null pointer");
+  if (int rc = check_conv(s, dtype, "pb_conv3d_bwd_weight_ws")) return rc;
+  PB_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0 && ((uintptr_t)zero16 % 16) == 0, "pb_conv3d_bwd_weight_ws: unaligned pointer");
+  PB_ENTER(device);
+  WgArgs a = {};
+  a.dY = dy; a.X = x; a.dW = dwp; a.P = (float*)ws; a.zero = zero16;
+  a.M = (int64_t)s->N * s->To * s->Ho * s->Wo;
+  a.K = s->Cin; a.N = s->Cout; a.rows_per_group = 1;
+  a.cTi = s->Ti; a.cHi = s->Hi; a.cWi = s->Wi; a.cTo = s->To; a.cHo = s->Ho; a.cWo = s->Wo;
+  a.ckt = s->kt; a.ckh = s->kh; a.ckw = s->kw; a.cst = s->st; a.csh = s->sh; a.csw = s->sw;
+  a.cpt = s->pt; a.cph = s->ph; a.cpw = s->pw;
+  const int taps = s->kt * s->kh * s->kw;
+  a.n_tiles = (int)pb_cdiv(a.N, 128);
+  a.k_tiles = (int)pb_cdiv(a.K, 128);
+  const int64_t t128 = (int64_t)a.n_tiles * a.k_tiles;
+  int64_t rows = 0;
+  const int64_t split = conv_wgrad_dma_plan(s, dtype, &rows);
+  a.rows_per_wg = rows;
+  a.split = (int)split;
+  a.ranges_per_group = 0;
+  hipLaunchKernelGGL((pw_wgrad128_dma_kernel<3, true>), dim3((unsigned)(t128 * 8 * pb_cdiv(split, 8)), 1, (unsigned)taps), dim3(256),
+                     3 * 16384, (hipStream_t)stream, a);
+  const int64_t nk4 = (int64_t)s->Cout * taps * s->Cin / 4;
+  hipLaunchKernelGGL(pw_wgrad_reduce_kernel, dim3((unsigned)pb_cdiv(nk4, 32)), dim3(256), 0, (hipStream_t)stream, a.P, dwp, nk4,
+                     a.split);
+  PB_LAUNCH_CHECK();
+  return 0;
 }

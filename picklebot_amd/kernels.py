@@ -697,6 +697,12 @@ def conv3d_bwd_weight(dy, x, kernel, stride, pad_front):
     dwp = zeros(cout * taps * cin, x.device)
     s = _conv_shape(N, cin, cout, tuple(x.shape[1:4]), (To, Ho, Wo), kernel, stride, pad_front)
     dev, st = _dev_stream(x)
+    nws = int(_C.load().pb_conv3d_bwd_weight_ws_bytes(ctypes.byref(s), _dt(x), dev))
+    if nws:
+        ws = torch.empty(nws // 4, dtype=torch.float32, device=x.device)
+        _launch("conv3d_wgrad_dma_kernel", _nb(dy, x, dwp), "pb_conv3d_bwd_weight_ws", _p(dy), _p(x), _p(dwp), ctypes.byref(s), _dt(x),
+                _p(ws), nws, _p(zeros(8, x.device)), dev, st, detail=f"Cin{cin} Cout{cout} {tuple(x.shape[1:4])} k{kernel}")
+        return dwp
     _launch("pw_wgrad_kernel<conv>", _nb(dy, x, dwp), "pb_conv3d_bwd_weight", _p(dy), _p(x), _p(dwp), ctypes.byref(s), _dt(x), dev, st,
             detail=f"Cin{cin} Cout{cout} {tuple(x.shape[1:4])} k{kernel}")
     return dwp
