@@ -542,6 +542,10 @@ extern "C" int pb_pwconv_fwd_bf16w(const void* x, const void* wb, void* y, int64
   return 0;
 }
 
+__attribute__((visibility("hidden"))) int pb_conv3d_halo_fwd(const void* x, const void* wb, void* y, const pb_conv_shape* s,
+                                                             const void* zero16, const float* out_scale, const float* out_shift,
+                                                             pb_act out_act, float out_slope, float* stats, int device, hipStream_t st);
+
 // Dense Conv3d (groups = 1, stride 1) as implicit GEMM on the same kernel: M = output voxels, K = taps*Cin.
 extern "C" int pb_conv3d_fwd_bf16w(const void* x, const void* wb, void* y, const pb_conv_shape* s, const void* zero16,
                                    const float* out_scale, const float* out_shift, pb_act out_act, float out_slope,
@@ -559,6 +563,11 @@ extern "C" int pb_conv3d_fwd_bf16w(const void* x, const void* wb, void* y, const
   PB_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)wb % 16) == 0 && ((uintptr_t)zero16 % 16) == 0,
                "pb_conv3d_fwd_bf16w: unaligned pointer");
   PB_ENTER(device);
+  {
+    // 3x3x3: the halo-resident kernel (conv_halo.hip) reads the input once per 32-channel chunk instead of once per tap
+    const int rc = pb_conv3d_halo_fwd(x, wb, y, s, zero16, out_scale, out_shift, out_act, out_slope, stats, device, (hipStream_t)stream);
+    if (rc >= 0) return rc;
+  }
   DmaArgs a = {};
   a.X = (const bf16_t*)x; a.WB = (const bf16_t*)wb; a.Y = (bf16_t*)y; a.M = M; a.K = taps * s->Cin; a.N = s->Cout;
   a.out_scale = out_scale; a.out_shift = out_shift; a.out_act = (int)out_act; a.out_slope = out_slope; a.stats = stats;
