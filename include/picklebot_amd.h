@@ -34,7 +34,7 @@ typedef enum {
   PB_ACT_HSIGMOID = 4, PB_ACT_SILU = 5
 } pb_act;
 
-#define PB_ABI_VERSION 9
+#define PB_ABI_VERSION 10
 
 /* Per-channel statistics buffers (`stats`, `sums` below) are PB_STAT_REPLICAS replicas of [2][C]
  * fp32, layout [replica][2][C], zero-filled by the caller.  A workgroup adds its partial sums into
@@ -81,10 +81,12 @@ int pb_pw_weight_prep_batch(const int64_t* desc, int count, int device, void* st
 
 /* Y[M,N] = X[M,K] * Wb[g(m)][N,K]^T, bf16, both operands streamed by LDS-DMA rings (pw_gemm_dma.hip); same
  * epilogue as pb_pwconv_fwd (out_scale/out_shift/act, BN statistics).  Wb from pb_pw_weight_prep:
- * [groups][N][K]; groups > 1: rows [g*rows_per_group, (g+1)*rows_per_group) use Wb[g].  K, N multiples of 8. */
+ * [groups][N][K]; groups > 1: rows [g*rows_per_group, (g+1)*rows_per_group) use Wb[g].  K, N multiples of 8.
+ * residual (optional, bf16 [M][N], not together with stats) is added in the store pass: y = epilogue(x Wb^T) + residual
+ * (the `x + attn(x)` / `x + ff(x)` of mobilevit.py:102-103 and their backward `dx = dy W + dy_skip`). */
 int pb_pwconv_fwd_bf16w(const void* x, const void* wb, void* y, int64_t M, int K, int N, int groups,
                         int64_t rows_per_group, const float* out_scale, const float* out_shift, pb_act out_act,
-                        float out_slope, float* stats, int device, void* stream);
+                        float out_slope, float* stats, const void* residual, int device, void* stream);
 
 /* Weight gradient  dW[N,K] += sum_m dY[m,n] * P(X)[m,k]   (same prologue P as above; fp32
  * atomics into dw, which the caller zero-fills or holds a running gradient).

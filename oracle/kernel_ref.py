@@ -66,7 +66,7 @@ def _prologue(x, in_scale, in_shift, in_act, in_slope, row_scale, rows_per_group
 
 
 def pw_fwd(x, w, *, w_transposed=False, in_scale=None, in_shift=None, in_act="none", in_slope=0.0, row_scale=None,
-           rows_per_group=0, out_scale=None, out_shift=None, out_act="none", out_slope=0.0, stats=None):
+           rows_per_group=0, out_scale=None, out_shift=None, out_act="none", out_slope=0.0, stats=None, residual=None):
     xf = _prologue(x, in_scale, in_shift, in_act, in_slope, row_scale, rows_per_group)
     wl = (w.t() if w_transposed else w).to(x.dtype).float()
     acc = xf @ wl.t()
@@ -78,6 +78,8 @@ def pw_fwd(x, w, *, w_transposed=False, in_scale=None, in_shift=None, in_act="no
     if stats is not None:
         stats[0, 0] += y.float().sum(0)
         stats[0, 1] += (y.float() ** 2).sum(0)
+    if residual is not None:
+        y = (y.float() + residual.float()).to(x.dtype)
     return y
 
 

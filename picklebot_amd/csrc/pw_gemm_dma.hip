@@ -45,6 +45,7 @@ struct DmaArgs {
   int Ti, Hi, Wi, To, Ho, Wo, pt, ph, pw, kh, kw, taps, Cin;
   unsigned cin_magic;        // ceil(2^32 / Cin): k / Cin == umulhi(k, cin_magic) for k < 65536
   const bf16_t* zero;        // >= 16 bytes of zeros in device memory
+  const bf16_t* R;           // residual [M][N] added to the output in the store pass (y = P(x) W^T + r), or null
 };
 
 __device__ __forceinline__ void glds16(const void* gsrc, unsigned char* lds_dst) {
@@ -346,7 +347,15 @@ __global__ __launch_bounds__(256) void pw_gemm_dma_kernel(DmaArgs a) {
             const int r = f / CPR, c = f - r * CPR;
             const int64_t m = m0 + wave * 32 + i * 16 + h * ER + r;
             const int n = n0 + c * VEC;
-            if (m < mend && n < a.N) vec_store<T>(a.Y + m * a.N + n, vec_load<T>(epi + r * EPI_LD + c * VEC));
+            if (m < mend && n < a.N) {
+              Vec16<T> v = vec_load<T>(epi + r * EPI_LD + c * VEC);
+              if (a.R) {                                   // residual connection (MobileViT: x + attn(x), x + ff(x))
+                const Vec16<T> rv = vec_load<T>(a.R + m * a.N + n);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) v.set(e, v.get(e) + rv.get(e));
+              }
+              vec_store<T>(a.Y + m * a.N + n, v);
+            }
           }
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_wave_barrier();
@@ -485,7 +494,8 @@ extern "C" int pb_pw_weight_prep_batch(const int64_t* desc, int count, int devic
 
 extern "C" int pb_pwconv_fwd_bf16w(const void* x, const void* wb, void* y, int64_t M, int K, int N, int groups,
                                    int64_t rows_per_group, const float* out_scale, const float* out_shift,
-                                   pb_act out_act, float out_slope, float* stats, int device, void* stream) {
+                                   pb_act out_act, float out_slope, float* stats, const void* residual, int device,
+                                   void* stream) {
   PB_CHECK_ARG(x && wb && y, "pb_pwconv_fwd_bf16w: null pointer");
   PB_CHECK_ARG(M > 0 && K > 0 && N > 0 && K % 8 == 0 && N % 8 == 0, "pb_pwconv_fwd_bf16w: K and N must be multiples of 8 (M=%lld K=%d N=%d)",
                (long long)M, K, N);
@@ -493,8 +503,10 @@ extern "C" int pb_pwconv_fwd_bf16w(const void* x, const void* wb, void* y, int64
                "pb_pwconv_fwd_bf16w: groups * rows_per_group must equal M");
   PB_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)wb % 16) == 0, "pb_pwconv_fwd_bf16w: unaligned pointer");
   PB_ENTER(device);
-  DmaArgs a;
+  PB_CHECK_ARG(!residual || (((uintptr_t)residual % 16) == 0 && !stats), "pb_pwconv_fwd_bf16w: residual must be 16-byte aligned and excludes stats");
+  DmaArgs a = {};
   a.X = (const bf16_t*)x; a.WB = (const bf16_t*)wb; a.Y = (bf16_t*)y; a.M = M; a.K = K; a.N = N;
+  a.R = (const bf16_t*)residual;
   a.out_scale = out_scale; a.out_shift = out_shift; a.out_act = (int)out_act; a.out_slope = out_slope; a.stats = stats;
   if (groups > 1) {
     a.w_group_stride = (int64_t)N * K;

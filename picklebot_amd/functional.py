@@ -626,8 +626,7 @@ class _AttnBlock(torch.autograd.Function):
         xn, stat = K.layernorm_fwd(x, eps)
         qkv = K.pw_fwd(xn, w_qkv)
         o, lse = K.attention_fwd(qkv, G, n, scale)
-        y = K.pw_fwd(o, w_out)
-        K.copy_cols(x, 0, y, 0, D, accumulate=True)
+        y = K.pw_fwd(o, w_out, residual=x)
         ctx.save_for_backward(x, stat, xn, qkv, o, lse, w_qkv, w_out)
         ctx.meta = (G, n, scale, eps)
         return y
@@ -659,8 +658,7 @@ class _FFBlock(torch.autograd.Function):
         # silu in its own pass (12 MB) so that both GEMMs on it are the LDS-DMA kernels: the activation-prologue
         # GEMM measured 146 us against 21 + 5 on the [4096,768]x[768,192] layer
         h = K.affine_act_fwd(hpre, act="silu")
-        y = K.pw_fwd(h, w2)
-        K.copy_cols(x, 0, y, 0, D, accumulate=True)
+        y = K.pw_fwd(h, w2, residual=x)
         ctx.save_for_backward(x, hpre, h, w1, w2)
         return y
 
@@ -674,8 +672,7 @@ class _FFBlock(torch.autograd.Function):
         dh = K.pw_fwd(dy, w2, w_transposed=True)
         dhpre = K.act_bwd_reduce(dh, hpre, act="silu")
         K.pw_bwd_weight(dhpre, x, dw1)
-        dx = K.pw_fwd(dhpre, w1, w_transposed=True)
-        K.copy_cols(dy, 0, dx, 0, D, accumulate=True)
+        dx = K.pw_fwd(dhpre, w1, w_transposed=True, residual=dy)
         return dx, dw1, dw2
 
 

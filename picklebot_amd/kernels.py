@@ -253,7 +253,7 @@ class WeightSet:
 
 
 def pw_fwd(x, w, *, w_transposed=False, in_scale=None, in_shift=None, in_act="none", in_slope=0.0, row_scale=None,
-           rows_per_group=0, out_scale=None, out_shift=None, out_act="none", out_slope=0.0, stats=None):
+           rows_per_group=0, out_scale=None, out_shift=None, out_act="none", out_slope=0.0, stats=None, residual=None):
     """y[M,N] = P(x)[M,K] @ Wl[N,K]^T with fused prologue/epilogue (see pb_pwconv_fwd).
     w: fp32 [N,K], or [K,N] with w_transposed (backward-data)."""
     _rows(x, "x")
@@ -271,18 +271,22 @@ def pw_fwd(x, w, *, w_transposed=False, in_scale=None, in_shift=None, in_act="no
         if rows_per_group <= 0 or M % rows_per_group:
             raise ValueError("pw_fwd: rows_per_group must divide M")
         _f32(row_scale, (M // rows_per_group, K), "row_scale")
+    if residual is not None:
+        _rows(residual, "residual")
+        if tuple(residual.shape) != (M, N) or residual.dtype != x.dtype or stats is not None:
+            raise ValueError("pw_fwd: residual must be [M,N] of x's dtype (and excludes stats)")
     y = torch.empty((M, N), dtype=x.dtype, device=x.device)
     dev, st = _dev_stream(x)
     if (_GEMM_DMA and _K16_FOLD and x.dtype == torch.bfloat16 and K == 16 and N % 8 == 0 and 4 * N <= 96 and M % 4 == 0 and M >= 4096
             and in_scale is None and in_shift is None and in_act == "none" and row_scale is None and stats is None
-            and out_scale is None and out_shift is None and w.is_contiguous()):
+            and out_scale is None and out_shift is None and w.is_contiguous() and residual is None):
         # K = 16 (the first stage): a row is 32 bytes, a quarter of an LDS stage.  [M,16] is the same memory as
         # [M/4,64], and Y[M,N] the same as [M/4,4N] = X' * blockdiag(W,W,W,W)^T: a full-width K = 64 GEMM on a quarter
         # of the rows (4x the MFMA work, on zeros - the kernel is HBM-bound): 3.2 -> 4.6 TB/s on the 4M-row tensors when
         # the folded output stays one column tile (N = 16); wider outputs (N = 64 -> 256 columns) measured slower
         wb4 = _prepped_weight(w, w_transposed, fold4=True)
         _launch("pw_gemm_dma_kernel", _nb(x, y) + 4 * N * 64 * 2, "pb_pwconv_fwd_bf16w", _p(x), _p(wb4), _p(y), M // 4, 64, 4 * N, 1,
-                0, None, None, ACT[out_act], float(out_slope), None, dev, st, detail=f"M{M} K{K} N{N} (4-row fold)")
+                0, None, None, ACT[out_act], float(out_slope), None, None, dev, st, detail=f"M{M} K{K} N{N} (4-row fold)")
         return y
     if (_GEMM_DMA and x.dtype == torch.bfloat16 and _dma_gemm_pays(M, K, N) and K % 8 == 0 and N % 8 == 0
             and in_scale is None and in_shift is None and in_act == "none" and w.is_contiguous()
@@ -299,7 +303,7 @@ def pw_fwd(x, w, *, w_transposed=False, in_scale=None, in_shift=None, in_act="no
             wb = wbs
         _launch("pw_gemm_dma_kernel", _nb(x, y) + N * K * 2, "pb_pwconv_fwd_bf16w", _p(x), _p(wb), _p(y), M, K, N, groups,
                 int(rows_per_group) if groups > 1 else 0, _p(out_scale), _p(out_shift), ACT[out_act], float(out_slope),
-                _p(stats), dev, st, detail=f"M{M} K{K} N{N}")
+                _p(stats), _p(residual), dev, st, detail=f"M{M} K{K} N{N}")
         return y
     skinny = (M <= 64 and in_scale is None and in_shift is None and in_act == "none" and row_scale is None
               and stats is None)
@@ -313,6 +317,8 @@ def pw_fwd(x, w, *, w_transposed=False, in_scale=None, in_shift=None, in_act="no
     _launch(family, _nb(x, y, w), "pb_pwconv_fwd", _p(x), _p(w), _p(y), M, K, N, w.shape[1], int(w_transposed), _dt(x), _p(in_scale),
             _p(in_shift), ACT[in_act], float(in_slope), _p(row_scale), int(rows_per_group), _p(out_scale),
             _p(out_shift), ACT[out_act], float(out_slope), _p(stats), dev, st, detail=f"M{M} K{K} N{N}")
+    if residual is not None:                 # (only the LDS-DMA kernel adds it in its store pass)
+        copy_cols(residual, 0, y, 0, N, accumulate=True)
     return y
 
 

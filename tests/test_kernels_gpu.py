@@ -120,6 +120,17 @@ def test_pw_bwd_weight_training_paths(K, M, Kd, N, G, dtype):
         check("pw_bwd_weight_se", got, want, dtype)
 
 
+@pytest.mark.parametrize("M,Kd,N,trans", [(1024, 192, 144, False), (777, 144, 288, True), (96, 768, 192, False), (32, 128, 64, False)])
+def test_pw_fwd_residual(K, M, Kd, N, trans):
+    """y = x W^T + r in the GEMM's store pass (MobileViT residual connections); also the copy fallback for M <= 64."""
+    x = rnd((M, Kd), torch.bfloat16, 61)
+    w = rnd((Kd, N) if trans else (N, Kd), seed=62, scale=Kd ** -0.5)
+    r = rnd((M, N), torch.bfloat16, 63)
+    want = R.pw_fwd(x, w, w_transposed=trans, residual=r)
+    got = K.pw_fwd(dev(x), dev(w), w_transposed=trans, residual=dev(r))
+    check("pw_fwd_residual", got, want, torch.bfloat16)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,Kd,N,trans", [(32, 960, 1280, False), (32, 1280, 13, False), (32, 13, 1280, True), (2, 1280, 960, True),
                                           (64, 200, 36, False), (7, 2048, 40, True)])
