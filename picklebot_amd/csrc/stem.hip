@@ -597,8 +597,8 @@ __global__ __launch_bounds__(256) void stem3_fwd_kernel(StemArgs a) {
   __syncthreads();
   const int row = lane & 15, g = lane >> 4;
   constexpr int NKS = 5;                                   // 5 x 32 = 160 >= 18 groups x 8
-  bf16x8 wf[NKS];
-  int aoff[NKS];                                           // slot offset (elements) of this lane's group, pixel 0
+  bf16x8 wf[NKS], wl[NKS];                                 // filter as a bf16 hi + lo pair: the first layer's rounding
+  int aoff[NKS];                                           // error reaches every later one (logits: 2.6e-2 -> 1e-2 off)
 #pragma unroll
   for (int ks = 0; ks < NKS; ++ks) {
     const int grp = 4 * ks + g, r = grp >> 1, shift = grp & 1;
@@ -612,6 +612,7 @@ __global__ __launch_bounds__(256) void stem3_fwd_kernel(StemArgs a) {
         else if (shift == 1 && j < 3) v = a.w[(int64_t)row * CT + j * taps + r * 3 + 2];
       }
       wf[ks][j] = (bf16_t)v;
+      wl[ks][j] = (bf16_t)(v - (float)wf[ks][j]);
     }
     aoff[ks] = ((gv ? r : 0) * S3_SP + shift) * 8;
   }
@@ -629,16 +630,19 @@ __global__ __launch_bounds__(256) void stem3_fwd_kernel(StemArgs a) {
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    f32x4 acc[2];
-    acc[0] = acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[2], accl[2];                                 // (separate chains for the lo parts: 4 independent MFMA streams)
+    acc[0] = acc[1] = accl[0] = accl[1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
         const bf16x8 fa = *reinterpret_cast<const bf16x8*>(win + aoff[ks] + (mt * 16 + row) * 8);
         acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, wf[ks], acc[mt], 0, 0, 0);
+        accl[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, wl[ks], accl[mt], 0, 0, 0);
       }
     }
+    acc[0] += accl[0];
+    acc[1] += accl[1];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
