@@ -23,7 +23,7 @@ struct RowsArgs {
   int nseg, nbands, band_rows, CP;
 };
 
-template <typename T, int K, int S, int WSEG, bool FLIP>
+template <typename T, int K, int S, int WSEG, bool FLIP, bool PRO>
 __global__ __launch_bounds__(256) void dw_rows_fwd_kernel(RowsArgs a) {
   typedef typename Pair<T>::raw_t raw_t;
   constexpr int P = K / 2;
@@ -79,12 +79,21 @@ __global__ __launch_bounds__(256) void dw_rows_fwd_kernel(RowsArgs a) {
 #pragma unroll
     for (int j = 0; j < IW; ++j) r[j] = base[coloff[j]];
   };
+  // the kernels are VALU-bound (SQ_ACTIVE_INST_VALU is the highest of the whole step): interior rows of interior
+  // segments skip the padding selects, and the (g_scale, g_shift) prologue only exists in the PRO instantiation
+  constexpr unsigned FULL = IW >= 32 ? 0xffffffffu : ((1u << IW) - 1u);
   auto insert_row = [&](int hs, const raw_t (&r)[IW], f32x2 (&slot)[IW]) {
     const bool rowok = hs >= 0 && hs < a.Hs;
+    if (rowok && cmask == FULL) {
 #pragma unroll
-    for (int j = 0; j < IW; ++j) {
-      const bool ok = rowok && ((cmask >> j) & 1u);
-      slot[j] = ok ? Pair<T>::up(r[j]) * gs + gh : f32x2{0.f, 0.f};
+      for (int j = 0; j < IW; ++j) slot[j] = PRO ? Pair<T>::up(r[j]) * gs + gh : Pair<T>::up(r[j]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < IW; ++j) {
+        const bool ok = rowok && ((cmask >> j) & 1u);
+        const f32x2 v = PRO ? Pair<T>::up(r[j]) * gs + gh : Pair<T>::up(r[j]);
+        slot[j] = ok ? v : f32x2{0.f, 0.f};
+      }
     }
   };
   // first step: all K window rows
@@ -337,8 +346,14 @@ int launch_rows_fwd(RowsArgs a, int flip, hipStream_t st) {
   a.band_rows = (int)pb_cdiv(pb_cdiv(a.Hd, nbands), K) * K;
   a.nbands = (int)pb_cdiv(a.Hd, a.band_rows);
   const dim3 grid((unsigned)pb_cdiv(frames * a.nbands * per_frame, 256));
-  if (flip) hipLaunchKernelGGL((dw_rows_fwd_kernel<T, K, S, WSEG, true>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((dw_rows_fwd_kernel<T, K, S, WSEG, false>), grid, dim3(256), 0, st, a);
+  const bool pro = a.g_scale || a.g_shift;
+  if (flip) {
+    if (pro) hipLaunchKernelGGL((dw_rows_fwd_kernel<T, K, S, WSEG, true, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((dw_rows_fwd_kernel<T, K, S, WSEG, true, false>), grid, dim3(256), 0, st, a);
+  } else {
+    if (pro) hipLaunchKernelGGL((dw_rows_fwd_kernel<T, K, S, WSEG, false, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((dw_rows_fwd_kernel<T, K, S, WSEG, false, false>), grid, dim3(256), 0, st, a);
+  }
   if (hipGetLastError() != hipSuccess) { pb_set_error("dw_rows forward launch failed"); return 1; }
   return 0;
 }
