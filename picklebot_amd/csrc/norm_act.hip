@@ -333,14 +333,29 @@ __global__ __launch_bounds__(256) void rowgroup_kernel(RgArgs a) {
   const T* A = (const T*)a.a + g * a.R * a.C;
   const T* B = a.b ? (const T*)a.b + g * a.R * a.C : nullptr;
   if (lane_ok) {
-    for (int64_t r = (int64_t)blockIdx.x * mp.P + p; r < a.R; r += (int64_t)gridDim.x * mp.P) {
-      float va[CH], vb[CH];
-      ld<T, CH>(A + r * a.C + c0, va);
-      if (B) {
-        ld<T, CH>(B + r * a.C + c0, vb);
+    const int64_t stride = (int64_t)gridDim.x * mp.P;
+    int64_t r = (int64_t)blockIdx.x * mp.P + p;
+    if (B) {
+      // four rows (8 independent 16-byte loads) in flight per thread: the kernel is latency-bound otherwise
+      for (; r < a.R; r += 4 * stride) {
+        float va[4][CH], vb[4][CH];
 #pragma unroll
-        for (int i = 0; i < CH; ++i) acc[0][i] += va[i] * vb[i];
-      } else {
+        for (int u = 0; u < 4; ++u) {
+          const int64_t ru = min(r + u * stride, a.R - 1);          // (rows past the end re-read the last row, weight 0)
+          ld<T, CH>(A + ru * a.C + c0, va[u]);
+          ld<T, CH>(B + ru * a.C + c0, vb[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float wgt = r + u * stride < a.R ? 1.f : 0.f;
+#pragma unroll
+          for (int i = 0; i < CH; ++i) acc[0][i] += va[u][i] * vb[u][i] * wgt;
+        }
+      }
+    } else {
+      for (; r < a.R; r += stride) {
+        float va[CH];
+        ld<T, CH>(A + r * a.C + c0, va);
 #pragma unroll
         for (int i = 0; i < CH; ++i) acc[0][i] += va[i];
       }
