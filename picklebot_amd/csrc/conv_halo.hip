@@ -306,9 +306,13 @@ __attribute__((visibility("hidden"))) int pb_conv3d_halo_fwd(const void* x, cons
   // CU) on every MobileViT layer even where 64 pads Cout (96 -> 128)
   static const int force_nt = getenv("PB_CONV_HALO_NT") ? atoi(getenv("PB_CONV_HALO_NT")) : 0;
   int nt = 4;
-  if (force_nt == 4 || force_nt == 6 || force_nt == 8) nt = force_nt;
+  // few voxel blocks (small frames): 32-column tiles double the number of workgroups
+  static const int64_t narrow_below = getenv("PB_CONV_HALO_NARROW") ? atoi(getenv("PB_CONV_HALO_NARROW")) : 256;
+  if (a.m_tiles * pb_cdiv(s->Cout, 64) < narrow_below) nt = 2;
+  if (force_nt == 2 || force_nt == 4 || force_nt == 6 || force_nt == 8) nt = force_nt;
   a.n_tiles = (int)pb_cdiv(s->Cout, nt * 16);
-  if (nt == 4) launch_halo<4>(a, device, st);
+  if (nt == 2) launch_halo<2>(a, device, st);
+  else if (nt == 4) launch_halo<4>(a, device, st);
   else if (nt == 6) launch_halo<6>(a, device, st);
   else launch_halo<8>(a, device, st);
   if (hipGetLastError() != hipSuccess) { pb_set_error("conv3d halo launch failed"); return 1; }

@@ -363,6 +363,7 @@ CONV_CASES = [  # N, Cin, Cout, (T,H,W), kernel, stride, pad
     (2, 16, 8, (4, 9, 9), (1, 3, 3), (1, 2, 2), (0, 1, 1)),
     (2, 64, 136, (4, 12, 12), (3, 3, 3), (1, 1, 1), (1, 1, 1)),     # several row panels x column tiles (last one partial)
     (3, 160, 160, (3, 8, 8), (3, 3, 3), (1, 1, 1), (1, 1, 1)),      # MobileViT-S last stage
+    (4, 64, 72, (8, 32, 32), (3, 3, 3), (1, 1, 1), (1, 1, 1)),      # >= 256 voxel blocks: the 64-column halo kernel (second tile partial)
 ]
 
 
