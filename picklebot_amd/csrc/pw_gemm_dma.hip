@@ -363,9 +363,12 @@ __global__ __launch_bounds__(256) void pw_gemm_dma_kernel(DmaArgs a) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
-      if (a.stats && n_tiles > 1) flush_stats(n0);
       ks = 0;
-      t = next_valid(t + gridDim.x);
+      const int tn = next_valid(t + gridDim.x);
+      // several column tiles: the sums go out when the workgroup moves to another column tile (with 2 or 4 column
+      // tiles and a grid that is a multiple of 8 it never does: one flush per workgroup instead of one per tile)
+      if (a.stats && n_tiles > 1 && (tn >= total || tile_nt(tn) * BN != n0)) flush_stats(n0);
+      t = tn;
     } else {
       ++ks;
     }
