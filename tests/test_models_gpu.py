@@ -194,3 +194,35 @@ def test_weight_copies_follow_a_fused_optimizer_step():
         y2 = model(x).float()
         y2_fresh = fresh(x).float()
     assert torch.allclose(y2, y2_fresh, rtol=2e-2, atol=2e-2), (y2 - y2_fresh).abs().max()
+
+
+@pytest.mark.parametrize("name", ["large", "movinet", "vit"])
+def test_training_reduces_loss_on_a_fixed_batch(name):
+    """Beyond one step: 25 AdamW steps on ONE synthetic batch (bf16 autocast, the reference's training mode) must
+    bring the loss down - a wrong-signed or mis-scaled gradient somewhere would pass no per-step tolerance for long."""
+    torch.manual_seed(0)
+    if name == "large":
+        model, shape = picklebot_amd.MobileNetLarge3D(num_classes=13), (4, 16, 112, 112, 3)
+    elif name == "movinet":
+        model, shape = picklebot_amd.MoViNetA2(num_classes=13), (2, 16, 96, 96, 3)
+    else:
+        with contextlib.redirect_stdout(io.StringIO()):
+            model = picklebot_amd.MobileViT(num_classes=13, dims=[64, 80, 96], channels=[16, 16, 24, 24, 48, 48, 64, 64, 80, 80, 320])
+        shape = (2, 16, 128, 128, 3)
+    model = model.to(DEV).train()
+    for m in model.modules():
+        if isinstance(m, (torch.nn.Dropout, torch.nn.Dropout3d)):
+            m.p = 0.0
+    x = torch.rand(shape, device=DEV).permute(0, 4, 1, 2, 3).to(torch.bfloat16)
+    y = torch.randint(0, 13, (shape[0],), device=DEV)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, fused=True)
+    losses = []
+    for _ in range(25):
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16), contextlib.redirect_stdout(io.StringIO()):
+            loss = torch.nn.functional.cross_entropy(model(x).float(), y)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert all(v == v for v in losses), losses
+    assert min(losses[-5:]) < 0.6 * losses[0], losses
