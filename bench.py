@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="clips per GPU (BASELINE config: 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="submit every kernel from Python instead of replaying one HIP graph per step")
+    ap.add_argument("--torch-adamw", action="store_true", help="torch.optim.AdamW(fused=True) instead of picklebot_amd.FlatAdamW")
     args = ap.parse_args()
 
     import picklebot_amd
@@ -93,8 +94,20 @@ def main():
     model.train()
     reducer = GradReducer(model) if dp_path else None
     use_graph = not dp_path and not args.no_graph
-    opt = torch.optim.AdamW(model.parameters(), lr=3e-4, weight_decay=5e-4, fused=True, capturable=use_graph)
+    flat_opt = not args.torch_adamw
+    if flat_opt:
+        # AdamW (train.py:208-212, plain fp32 state) as one fused launch per flat bucket; in data parallel it adopts
+        # the reducer's gradient buckets
+        opt = picklebot_amd.FlatAdamW(reducer if reducer is not None else model.parameters(), lr=3e-4, weight_decay=5e-4)
+    else:
+        opt = torch.optim.AdamW(model.parameters(), lr=3e-4, weight_decay=5e-4, fused=True, capturable=use_graph)
     x, y = synthetic_batch(args.batch, device, 1234 + rank)
+
+    def opt_step_reduced():
+        if flat_opt:
+            opt.step(packed=True)         # the reducer's buckets already hold the (reduced) gradients
+        else:
+            opt.step()
 
     def step():
         if reducer is not None:
@@ -106,7 +119,9 @@ def main():
         loss.backward()
         if reducer is not None:
             reducer.finish()
-        opt.step()
+            opt_step_reduced()
+        else:
+            opt.step()
         return loss
 
     def sync():
@@ -170,7 +185,7 @@ def main():
             def step():  # noqa: F811
                 graph.replay()
                 reducer.reduce_now()
-                opt.step()
+                opt_step_reduced()
                 return graph_loss
             launch_mode = "hipgraph(fwd+bwd) + eager all-reduce/optimizer"
         except Exception as e:
@@ -205,7 +220,7 @@ def main():
                     with torch.autocast("cuda", dtype=torch.bfloat16):
                         loss = torch.nn.functional.cross_entropy(model(x).float(), y)
                     loss.backward()
-                opt.step()
+                opt_step_reduced()
                 return loss
         K.start_profile()
         for _ in range(args.steps):
@@ -252,7 +267,7 @@ def main():
             "config": {"workload": "MobileNetLarge3D (mobilenet_large.json) training step, synthetic 16x224x224 clips",
                        "clips_per_gpu": args.batch, "global_batch": args.batch * world, "num_classes": NCLS,
                        "precision": "fp32 params, bf16 activations (autocast)", "parallelism": f"dp{world}",
-                       "step": "fwd + CE loss + bwd + RCCL grad all-reduce (n>1) + fused AdamW",
+                       "step": "fwd + CE loss + bwd + RCCL grad all-reduce (n>1) + fused AdamW (%s)" % ("picklebot_amd.FlatAdamW" if flat_opt else "torch fused"),
                        "launch": launch_mode,
                        "weights": "random init (seed 1234)", "loss": round(float(loss.item()), 4)},
             "roofline": roofline,

@@ -34,7 +34,7 @@ typedef enum {
   PB_ACT_HSIGMOID = 4, PB_ACT_SILU = 5
 } pb_act;
 
-#define PB_ABI_VERSION 10
+#define PB_ABI_VERSION 11
 
 /* Per-channel statistics buffers (`stats`, `sums` below) are PB_STAT_REPLICAS replicas of [2][C]
  * fp32, layout [replica][2][C], zero-filled by the caller.  A workgroup adds its partial sums into
@@ -294,6 +294,18 @@ int pb_attention_bwd(const void* qkv, const void* out, const void* dout, const f
 /* ---------------------------------------------------------------- misc
  * fp32 [R][C] -> [C][R] (depthwise weight [C][taps] -> [taps][C] staging). */
 int pb_transpose_f32(const float* in, float* out, int R, int C, int device, void* stream);
+
+/* ---------------------------------------------------------------- optimizer step
+ * Fused AdamW (torch.optim.AdamW's update rule; the reference's bitsandbytes AdamW8bit, train.py:208-212, with fp32
+ * state) over one flat fp32 bucket: p, g, m, v [n], 16-byte aligned.  `step`: device float holding the step number of
+ * THIS update (the caller increments it first; device memory so that a captured HIP graph advances).  inv_scale /
+ * found_inf (both optional device floats): gradients are multiplied by *inv_scale, and the whole update is skipped
+ * when *found_inf != 0 - torch.amp.GradScaler's unscale + skip (train.py:283-289).  pb_grad_check sets *found_inf = 1
+ * when any gradient is inf/nan (the caller zeroes it). */
+int pb_adamw_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, const float* step, const float* inv_scale, const float* found_inf, int device,
+                  void* stream);
+int pb_grad_check(const float* g, int64_t n, float* found_inf, int device, void* stream);
 
 #ifdef __cplusplus
 }

@@ -415,3 +415,22 @@ def attention_bwd(qkv, out, dout, lse, G, n, scale):
     dk = torch.matmul(ds.transpose(-1, -2), q)
     dqkv = torch.stack([dq, dk, dv], 0).permute(1, 3, 0, 2, 4).reshape(G * n, 384)
     return dqkv.to(qkv.dtype)
+
+
+def adamw_flat(p, g, m, v, step, lr, beta1, beta2, eps, weight_decay, inv_scale=None, found_inf=None):
+    """torch.optim.AdamW's single-tensor update (torch/optim/adamw.py) on flat buffers, in place."""
+    if found_inf is not None and float(found_inf) != 0.0:
+        return
+    t = float(step)
+    gg = g * (float(inv_scale) if inv_scale is not None else 1.0)
+    p.mul_(1 - lr * weight_decay)
+    m.lerp_(gg, 1 - beta1)
+    v.mul_(beta2).addcmul_(gg, gg, value=1 - beta2)
+    bc1, bc2 = 1 - beta1 ** t, 1 - beta2 ** t
+    denom = (v.sqrt() / (bc2 ** 0.5)).add_(eps)
+    p.addcdiv_(m, denom, value=-lr / bc1)
+
+
+def grad_check(g, found_inf):
+    if not bool(torch.isfinite(g).all()):
+        found_inf.fill_(1.0)

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libpicklebot_amd.so")
 
 PB_F32, PB_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY_RELU, ACT_HSWISH, ACT_HSIGMOID, ACT_SILU = range(6)
-ABI_VERSION = 10
+ABI_VERSION = 11
 STAT_REPLICAS = 16
 
 
@@ -66,6 +66,8 @@ SIGNATURES = {
     "pb_conv3d_fwd": [P, P, P, POINTER(ConvShape), I, P, P, I, F, P, I, P],
     "pb_conv3d_fwd_bf16w": [P, P, P, POINTER(ConvShape), P, P, P, I, F, P, I, P],
     "pb_conv3d_bwd_weight": [P, P, P, POINTER(ConvShape), I, I, P],
+    "pb_adamw_flat": [P, P, P, P, L, F, F, F, F, F, P, P, P, I, P],
+    "pb_grad_check": [P, L, P, I, P],
     "pb_conv3d_bwd_weight_ws": [P, P, P, POINTER(ConvShape), I, P, L, P, I, P],
 }
 

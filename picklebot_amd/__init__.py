@@ -9,6 +9,7 @@ a module does (hand-written HIP kernels behind a C ABI, no eager fallback).
 from .mobilenet import Bottleneck3D, MobileNetLarge3D, MobileNetSmall3D, SEBlock3D  # noqa: F401
 from .movinet import CausalConv3d, MoviNetBottleneck, MoViNetA2  # noqa: F401
 from .mobilevit import Attention, FeedForward, MobileViT, MobileViTBlock, Transformer  # noqa: F401
+from .optim import FlatAdamW  # noqa: F401
 
 __all__ = ["SEBlock3D", "Bottleneck3D", "MobileNetLarge3D", "MobileNetSmall3D", "CausalConv3d", "MoviNetBottleneck",
            "MoViNetA2", "FeedForward", "Attention", "Transformer", "MobileViTBlock", "MobileViT"]

@@ -801,3 +801,22 @@ def attention_bwd(qkv, out, dout, lse, G, n, scale):
     _launch("attention_bwd", _nb(qkv, out, dout, dqkv), "pb_attention_bwd", _p(qkv), _p(out), _p(dout), _p(lse), _p(delta), _p(dqkv),
             G, n, float(scale), _dt(qkv), dev, st, detail=f"G{G} n{n}")
     return dqkv
+
+
+# ------------------------------------------------------------------------------ optimizer step
+def adamw_flat(p, g, m, v, step, lr, beta1, beta2, eps, weight_decay, inv_scale=None, found_inf=None):
+    """In-place fused AdamW over flat fp32 buffers; `step`: device float tensor holding this update's step number."""
+    n = p.numel()
+    for t, name in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
+        _f32(t, (n,), name)
+    _f32(step, (), "step"); _f32(inv_scale, (), "inv_scale"); _f32(found_inf, (), "found_inf")
+    dev, st = _dev_stream(p)
+    _launch("adamw_flat", 7 * n * 4, "pb_adamw_flat", _p(p), _p(g), _p(m), _p(v), n, float(lr), float(beta1), float(beta2), float(eps),
+            float(weight_decay), _p(step), _p(inv_scale), _p(found_inf), dev, st)
+
+
+def grad_check(g, found_inf):
+    """found_inf (device float scalar, zeroed by the caller) = 1 when any element of g is inf/nan."""
+    _f32(g, name="g"); _f32(found_inf, (), "found_inf")
+    dev, st = _dev_stream(g)
+    _launch("grad_check", g.numel() * 4, "pb_grad_check", _p(g), g.numel(), _p(found_inf), dev, st)

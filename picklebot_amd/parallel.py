@@ -24,6 +24,17 @@ import torch
 import torch.distributed as dist
 
 
+def bucket_layout(plist, align=16):
+    """Offsets (in elements) of the parameters of a bucket inside its flat buffer, each aligned to `align` elements
+    (64 bytes: the kernels take 16-byte-aligned weight pointers, and FlatAdamW keeps parameters in the same layout),
+    and the padded total."""
+    offs, off = [], 0
+    for p in plist:
+        offs.append(off)
+        off += -(-p.numel() // align) * align
+    return offs, off
+
+
 class GradReducer:
     def __init__(self, module, process_group=None, bucket_bytes=8 << 20, average=True, broadcast_from=0):
         if not dist.is_initialized():
@@ -48,19 +59,20 @@ class GradReducer:
                 cur, cur_bytes = [], 0
         if cur:
             self.buckets.append(cur)
-        self.flat, self._need, self._ready = [], [], []
+        self.flat, self.views, self._need, self._ready = [], [], [], []
         self._hooks = []
         for bi, plist in enumerate(self.buckets):
-            n = sum(p.numel() for p in plist)
+            offs, n = bucket_layout(plist)
             flat = torch.zeros(n, dtype=torch.float32, device=plist[0].device)
-            off = 0
-            for p in plist:
+            views = []
+            for p, off in zip(plist, offs):
                 if p.dtype != torch.float32:
                     raise TypeError("GradReducer: parameters must be float32 masters")
-                p.grad = flat[off:off + p.numel()].view_as(p)
-                off += p.numel()
+                views.append(flat[off:off + p.numel()].view_as(p))
+                p.grad = views[-1]
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
             self.flat.append(flat)
+            self.views.append(views)
             self._need.append(len(plist))
             self._ready.append(0)
 
@@ -111,19 +123,17 @@ class GradReducer:
         self._ready = [0] * len(self.buckets)
 
     def pack_grads(self):
-        """Gather the .grad tensors a hooks-off backward left behind into the flat buckets (one concatenation per
+        """Gather the .grad tensors a hooks-off backward left behind into the flat buckets (one multi-tensor copy per
         bucket); parameters without a gradient contribute zeros.  Follow with attach_grads() once (after a HIP-graph
         capture: the views stay valid for every replay) so that the optimiser reads the reduced buckets."""
-        for flat, plist in zip(self.flat, self.buckets):
-            parts = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in plist]
-            torch.cat(parts, out=flat)
+        for views, plist in zip(self.views, self.buckets):
+            srcs = [p.grad if p.grad is not None else torch.zeros_like(p) for p in plist]
+            torch._foreach_copy_(views, srcs)
 
     def attach_grads(self):
-        for flat, plist in zip(self.flat, self.buckets):
-            off = 0
-            for p in plist:
-                p.grad = flat[off:off + p.numel()].view_as(p)
-                off += p.numel()
+        for views, plist in zip(self.views, self.buckets):
+            for p, v in zip(plist, views):
+                p.grad = v
 
     def reduce_now(self):
         """All-reduce (and average) every bucket on the spot, stream-ordered behind whatever filled them - for steps

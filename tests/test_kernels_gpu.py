@@ -444,3 +444,38 @@ def test_attention(K, G, n, dtype):
     dq_ref = R.attention_bwd(qkv, out_ref, dout, lse_ref, G, n, 0.25)
     dq = K.attention_bwd(dev(qkv), dev(out_ref), dev(dout), dev(lse_ref), G, n, 0.25)
     check("attn_dqkv", dq, dq_ref, dtype, 1.5)
+
+
+@pytest.mark.parametrize("n", [4096, 1000003, 13])
+def test_adamw_flat_and_grad_check(K, n):
+    """Fused AdamW over a flat bucket vs torch.optim.AdamW's rule (CPU mirror), several steps incl. the ragged tail;
+    unscale + skip-on-inf (GradScaler semantics)."""
+    g = torch.Generator().manual_seed(90)
+    p0 = torch.randn(n, generator=g)
+    m0, v0 = torch.zeros(n), torch.zeros(n)
+    p1, m1, v1 = dev(p0.clone()), dev(m0.clone()), dev(v0.clone())
+    step_c, step_d = torch.zeros(()), torch.zeros((), device=DEV)
+    for it in range(4):
+        gr = torch.randn(n, generator=g) * (10.0 ** (it - 2))
+        step_c += 1; step_d += 1
+        R.adamw_flat(p0, gr, m0, v0, step_c, 3e-3, 0.9, 0.99, 1e-8, 5e-2)
+        K.adamw_flat(p1, dev(gr), m1, v1, step_d, 3e-3, 0.9, 0.99, 1e-8, 5e-2)
+        check("adamw_p", p1, p0, torch.float32)
+        check("adamw_v", v1, v0, torch.float32)
+    # unscale
+    gr = torch.randn(n, generator=g)
+    inv = torch.tensor(1.0 / 256.0)
+    step_c += 1; step_d += 1
+    R.adamw_flat(p0, gr * 256.0, m0, v0, step_c, 3e-3, 0.9, 0.99, 1e-8, 5e-2, inv_scale=inv)
+    K.adamw_flat(p1, dev(gr * 256.0), m1, v1, step_d, 3e-3, 0.9, 0.99, 1e-8, 5e-2, inv_scale=dev(inv))
+    check("adamw_unscale", p1, p0, torch.float32)
+    # inf check + skip
+    found = torch.zeros((), device=DEV)
+    K.grad_check(dev(gr), found)
+    assert float(found) == 0.0
+    bad = gr.clone(); bad[n // 2] = float("nan")
+    K.grad_check(dev(bad), found)
+    assert float(found) == 1.0
+    before = p1.clone()
+    K.adamw_flat(p1, dev(bad), m1, v1, step_d, 3e-3, 0.9, 0.99, 1e-8, 5e-2, found_inf=found)
+    assert torch.equal(before, p1)
