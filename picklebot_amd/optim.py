@@ -11,7 +11,8 @@ rule.  State (exp_avg, exp_avg_sq) is fp32.
     loss.backward()
     opt.step()                      # gathers the gradients into the flat bucket (one multi-tensor copy) and updates
 
-With a `GradReducer` the reducer's buckets are adopted (its flat gradient buffers are what the all-reduce fills).
+Construct it after the model is on its device (parameters are re-pointed into the flat buffer; `state_dict` keys and values are
+unchanged).  With a `GradReducer` the reducer's buckets are adopted (its flat gradient buffers are what the all-reduce fills).
 Everything is stream-ordered and allocation-free after construction, so a whole step can be captured into a HIP graph
 (the step count lives on the device).
 """
