@@ -76,17 +76,21 @@ __global__ __launch_bounds__(256) void dw3_fwd_kernel(Dw3Args a) {
   for (int d = 0; d < KT; ++d)
 #pragma unroll
     for (int j = 0; j < WSEG; ++j) acc[d][j] = f32x2{0.f, 0.f};
-  raw_t raw[3][IW];
-  auto load_frame = [&](int f) {
+  // two frames in flight: raw = the frame of this step, raw2 = the next one (KT = 3, stride 1 has the registers for it)
+  constexpr bool DEEP = KT == 3 && S == 1;
+  raw_t raw[3][IW], raw2[DEEP ? 3 : 1][DEEP ? IW : 1];
+  auto load_into = [&](int f, auto& dst) {
     const raw_t* base = src + (int64_t)min(max(f, 0), a.Ts - 1) * fstride_s;
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-      for (int j = 0; j < IW; ++j) raw[kh][j] = base[rowoff[kh] + coloff[j]];
+      for (int j = 0; j < IW; ++j) dst[kh][j] = base[rowoff[kh] + coloff[j]];
   };
+  auto load_frame = [&](int f) { load_into(f, raw); };
   const int f0 = t0 - a.pt;                                     // input frame of step 0
   const int nI = nT + KT - 1;
   load_frame(f0);
+  if constexpr (DEEP) load_into(f0 + 1, raw2);
   f32x2 psum = {0.f, 0.f};
   for (int ik = 0; ik < nI; ik += KT) {
 #pragma unroll
@@ -103,7 +107,15 @@ __global__ __launch_bounds__(256) void dw3_fwd_kernel(Dw3Args a) {
             const bool ok = fok && ((rmask >> kh) & 1u) && ((cmask >> j) & 1u);
             xin[kh][j] = ok ? Pair<T>::up(raw[kh][j]) * gs + gh : f32x2{0.f, 0.f};
           }
-        if (i + 1 < nI) load_frame(f + 1);
+        if constexpr (DEEP) {
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int j = 0; j < IW; ++j) raw[kh][j] = raw2[kh][j];
+          if (i + 2 < nI) load_into(f + 2, raw2);
+        } else {
+          if (i + 1 < nI) load_frame(f + 1);
+        }
         if (fok) {
 #pragma unroll
           for (int dt = 0; dt < KT; ++dt) {
