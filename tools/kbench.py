@@ -97,6 +97,8 @@ CASES = {
                         wg(351232, 40, 240), wg(250880, 120, 40)],
     "wg_small": lambda: [wg(8192, 192, 768), wg(8192, 128, 192), wg(2048, 960, 240), wg(25088, 960, 160, rs=True),
                          wg(25088, 160, 960), wg(100352, 112, 480)],
+    "wg_floor": lambda: [wg(256, 128, 192), wg(1024, 128, 192), wg(8192, 128, 192), wg(256, 192, 768), wg(8192, 192, 768),
+                         wg(65536, 192, 768)],
     "pw_small": lambda: [pw(4014080, 16, 64), pw(4014080, 16, 16, stats=True), pw(4014080, 64, 16, trans=True),
                          pw(602112, 64, 24, stats=True), pw(802816, 24, 72), pw(351232, 40, 240), wg(4014080, 16, 64),
                          wg(4014080, 16, 16), wg(802816, 24, 72)],
