@@ -34,17 +34,34 @@ typedef enum {
   PB_ACT_HSIGMOID = 4, PB_ACT_SILU = 5
 } pb_act;
 
-#define PB_ABI_VERSION 11
+#define PB_ABI_VERSION 12
 
-/* Per-channel statistics buffers (`stats`, `sums` below) are PB_STAT_REPLICAS replicas of [2][C]
- * fp32, layout [replica][2][C], zero-filled by the caller.  A workgroup adds its partial sums into
- * replica (workgroup id % PB_STAT_REPLICAS): same-address float atomics serialise at the memory side
- * (~25 ns each on MI355X), so no address may see more than a few dozen of them per launch.
- * pb_bn_finalize / pb_bn_bwd_finalize sum the replicas. */
-#define PB_STAT_REPLICAS 16
+/* Determinism.  Nothing in this library accumulates with floating-point atomics: two runs of the same binary on the
+ * same inputs give bit-identical outputs and gradients.  Every reduction that spans workgroups stores one partial
+ * result per workgroup (or work unit) in a "slot" of its own, and a consumer adds the slots in an order that depends
+ * only on the shapes.
+ *
+ * Per-channel statistics buffers (`stats`, `sums` below) are PB_STAT_SLOTS slots of [2][C] fp32, layout
+ * [slot][2][C], ZERO-FILLED by the caller.  Workgroup b of a producing launch adds its partial sums into slot b with
+ * plain read-modify-writes (the launchers keep their grids <= PB_STAT_SLOTS); pb_bn_finalize / pb_bn_bwd_finalize
+ * add the slots up in index order (in double). */
+#define PB_STAT_SLOTS 1024
 int pb_abi_version(void);
 /* Last error message of the calling thread ("" if none). */
 const char* pb_last_error(void);
+
+/* out[e] (+)= sum_{s < split} part[s*stride + e] for e < n, slots added in a fixed order (a function of `split`
+ * alone).  The weight-gradient entries below run this themselves unless the caller asks for the job back
+ * (`deferred` argument) in order to batch the reductions of several gradients into ONE launch. */
+typedef struct {
+  const float* part;
+  float* out;
+  int64_t n;
+  int64_t stride;
+  int split;
+  int accumulate;      /* 0: out = sum, != 0: out += sum */
+} pb_reduce_job;
+int pb_partials_reduce(const pb_reduce_job* jobs, int count, int device, void* stream);
 
 /* ---------------------------------------------------------------- pointwise 1x1x1 convolution
  * Replaces nn.Conv3d(Cin,Cout,1) forward / backward: mobilenet.py:64,79,141(head),179,187,189;
@@ -53,7 +70,7 @@ const char* pb_last_error(void);
  * GEMM  Y[M,N] = P(X)[M,K] * Wl[N,K]^T  with fused prologue/epilogue:
  *   P(x)[m,k] = act_in(x*in_scale[k] + in_shift[k]) * row_scale[m / rows_per_group, k]
  *   y[m,n]    = act_out(acc*out_scale[n] + out_shift[n])           (bias = out_shift)
- *   stats[0..N) += sum_m y, stats[N..2N) += sum_m y^2  (of the stored, rounded y; atomics)
+ *   stats[slot][0..N) += sum_m y, stats[slot][N..2N) += sum_m y^2  (of the stored, rounded y; slot = workgroup)
  * Wl is fp32: element (n,k) at w[n*ldw + k], or at w[k*ldw + n] when w_transposed != 0 (this is
  * how backward-data reuses the entry: dX = dY * W is the same GEMM with W read transposed).
  * Any of in_scale/in_shift/row_scale/out_scale/out_shift/stats may be NULL.
@@ -88,22 +105,18 @@ int pb_pwconv_fwd_bf16w(const void* x, const void* wb, void* y, int64_t M, int K
                         int64_t rows_per_group, const float* out_scale, const float* out_shift, pb_act out_act,
                         float out_slope, float* stats, const void* residual, int device, void* stream);
 
-/* Weight gradient  dW[N,K] += sum_m dY[m,n] * P(X)[m,k]   (same prologue P as above; fp32
- * atomics into dw, which the caller zero-fills or holds a running gradient).
- * Replaces the weight half of Conv3d/Linear backward for the sites listed above. */
-int pb_pwconv_bwd_weight(const void* dy, const void* x, float* dw, int64_t M, int K, int N, pb_dtype dtype,
-                         const float* in_scale, const float* in_shift, pb_act in_act, float in_slope,
-                         const float* row_scale, int64_t rows_per_group, int device, void* stream);
-/* The same with a caller-provided workspace: the row ranges store partial dW tiles in `ws` and a second kernel adds
- * them into dw, instead of fp32 atomics (a CU retires ~1 float atomic per clock: 25-30 us per launch whatever the
- * layer).  pb_pwconv_bwd_weight_ws_bytes returns the size this shape wants (0: the shape takes a kernel that does not
- * use one); ws may be NULL or smaller, then the atomic epilogue runs.  ws and dw 16-byte aligned. */
+/* Weight gradient  dW[N,K] += sum_m dY[m,n] * P(X)[m,k]   (same prologue P as above).
+ * Replaces the weight half of Conv3d/Linear backward for the sites listed above.
+ * The row ranges of the launch store partial dW tiles in the caller-provided workspace `ws` (size from
+ * pb_pwconv_bwd_weight_ws_bytes for the same arguments; 16-byte aligned) and a fixed-order reduction adds them into
+ * dw - no atomics.  deferred != NULL: the reduction is NOT launched; *deferred receives the job for
+ * pb_partials_reduce (ws must stay alive until that runs). */
 int64_t pb_pwconv_bwd_weight_ws_bytes(int64_t M, int K, int N, pb_dtype dtype, int has_affine, int has_row_scale,
                                       int64_t rows_per_group, int device);
 int pb_pwconv_bwd_weight_ws(const void* dy, const void* x, float* dw, int64_t M, int K, int N, pb_dtype dtype,
                             const float* in_scale, const float* in_shift, pb_act in_act, float in_slope,
-                            const float* row_scale, int64_t rows_per_group, void* ws, int64_t ws_bytes, int device,
-                            void* stream);
+                            const float* row_scale, int64_t rows_per_group, void* ws, int64_t ws_bytes,
+                            pb_reduce_job* deferred, int device, void* stream);
 
 /* ---------------------------------------------------------------- dense 3-D convolution (implicit GEMM)
  * Replaces nn.Conv3d(Cin,Cout,k,stride,padding,bias=False) with groups=1: mobilevit.py:19-24 (the
@@ -134,11 +147,10 @@ int pb_conv3d_fwd(const void* x, const float* wp, void* y, const pb_conv_shape* 
 int pb_conv3d_fwd_bf16w(const void* x, const void* wb, void* y, const pb_conv_shape* s, const void* zero16,
                         const float* out_scale, const float* out_shift, pb_act out_act, float out_slope, float* stats,
                         int device, void* stream);
-int pb_conv3d_bwd_weight(const void* dy, const void* x, float* dwp, const pb_conv_shape* s, pb_dtype dtype, int device,
-                         void* stream);
-/* The same on the LDS-DMA weight-gradient kernel (bf16): partial tiles per row range in `ws` (size from
- * pb_conv3d_bwd_weight_ws_bytes; 0 = shape not eligible) + one reduction into dwp; zero16 = 16 zero bytes of device
- * memory for the padding voxels.  Falls back to pb_conv3d_bwd_weight when ws is NULL / too small. */
+/* Weight gradient dwp[Cout][taps][Cin] += ...: partial tiles per row range in `ws` (size from
+ * pb_conv3d_bwd_weight_ws_bytes) + one fixed-order reduction into dwp; zero16 = 16 zero bytes of device memory for
+ * the padding voxels.  bf16 stride-1 shapes run on the LDS-DMA weight-gradient kernel, the rest on the
+ * register-staged one. */
 int64_t pb_conv3d_bwd_weight_ws_bytes(const pb_conv_shape* s, pb_dtype dtype, int device);
 int pb_conv3d_bwd_weight_ws(const void* dy, const void* x, float* dwp, const pb_conv_shape* s, pb_dtype dtype, void* ws,
                             int64_t ws_bytes, const void* zero16, int device, void* stream);
@@ -150,7 +162,9 @@ int pb_conv3d_bwd_weight_ws(const void* dy, const void* x, float* dwp, const pb_
  * pad_t_front = kt-1, pad_t_back = 0).
  * x [N,Ti,Hi,Wi,C] -> y [N,To,Ho,Wo,C]; w fp32 in the reference's layout [C][kt*kh*kw].
  * Temporal padding is asymmetric-capable: frame index t_in = t_out*st - pt_front + a.
- * pool (optional) [N][C] fp32 += sum over (To,Ho,Wo) of y  (squeeze for SEBlock3D, mobilenet.py:16).
+ * pool_part (optional): squeeze for SEBlock3D (mobilenet.py:16) as per-work-unit partial sums over (To,Ho,Wo) of y,
+ * fp32 [pool_slots][N][C] with pool_slots = pb_dwconv3d_pool_slots(s, dtype); every slot is written (plain stores,
+ * no zero-fill needed); pb_se_fc_fwd (or pb_partials_reduce) adds the slots up.
  */
 typedef struct {
   int N, C;
@@ -161,16 +175,21 @@ typedef struct {
   int pt, ph, pw;      /* front paddings (symmetric convs: also the back padding) */
 } pb_dwconv_shape;
 
+int pb_dwconv3d_pool_slots(const pb_dwconv_shape* s, pb_dtype dtype);
 int pb_dwconv3d_fwd(const void* x, const float* w, void* y, const pb_dwconv_shape* s, pb_dtype dtype,
-                    float* pool, int device, void* stream);
+                    float* pool_part, int pool_slots, int device, void* stream);
 
 /* Backward.  The incoming gradient may carry the fused squeeze-excite backward:
  *   g[n,t,h,w,c] = dy[n,t,h,w,c] * g_scale[n,c] + g_shift[n,c]   (either may be NULL)
- * dx = conv_transpose(g, w);  dw[C][kt*kh*kw] += sum g * x  (fp32 atomics). */
+ * dx = conv_transpose(g, w);  dw[C][kt*kh*kw] += sum g * x: per-workgroup partial gradients go to `ws`
+ * (pb_dwconv3d_bwd_weight_ws_bytes, 16-byte aligned) and are added in a fixed order; `deferred` as in
+ * pb_pwconv_bwd_weight_ws. */
 int pb_dwconv3d_bwd_data(const void* dy, const float* w, void* dx, const pb_dwconv_shape* s, pb_dtype dtype,
                          const float* g_scale, const float* g_shift, int device, void* stream);
+int64_t pb_dwconv3d_bwd_weight_ws_bytes(const pb_dwconv_shape* s, pb_dtype dtype);
 int pb_dwconv3d_bwd_weight(const void* dy, const void* x, float* dw, const pb_dwconv_shape* s, pb_dtype dtype,
-                           const float* g_scale, const float* g_shift, int device, void* stream);
+                           const float* g_scale, const float* g_shift, void* ws, int64_t ws_bytes,
+                           pb_reduce_job* deferred, int device, void* stream);
 
 /* Name of the HIP kernel the dispatcher picks for this shape (profiling labels: rocprofv3 kernel names
  * <-> bench.py families).  which: 0 = forward, 1 = backward-data, 2 = backward-weight.  Static string. */
@@ -195,9 +214,12 @@ typedef struct {
 
 int pb_stem_conv3d_fwd(const void* x, int x_dtype, float x_scale, const float* w, const float* bias, void* y,
                        const pb_stem_shape* s, pb_dtype dtype, float* stats, int device, void* stream);
-/* dw[Cout][Cin][kt][kh][kw] += ..., dbias[Cout] += sum dy (dbias may be NULL). */
+/* dw[Cout][Cin][kt][kh][kw] += ..., dbias[Cout] += sum dy (dbias may be NULL): per-workgroup partials in `ws`
+ * (pb_stem_conv3d_bwd_weight_ws_bytes) added in a fixed order. */
+int64_t pb_stem_conv3d_bwd_weight_ws_bytes(const pb_stem_shape* s, int x_dtype, float x_scale, pb_dtype dtype);
 int pb_stem_conv3d_bwd_weight(const void* dy, const void* x, int x_dtype, float x_scale, float* dw, float* dbias,
-                              const pb_stem_shape* s, pb_dtype dtype, int device, void* stream);
+                              const pb_stem_shape* s, pb_dtype dtype, void* ws, int64_t ws_bytes, int device,
+                              void* stream);
 
 /* ---------------------------------------------------------------- per-channel statistics / norm / activation
  * Replace nn.BatchNorm3d (+ the activation and Dropout3d after it): mobilenet.py:80-82,90-92,142-143;
@@ -209,10 +231,12 @@ int pb_chan_stats(const void* x, int64_t M, int C, pb_dtype dtype, float* stats,
 /* Training: mean/var from stats (count = M), running stats updated in place (unbiased var,
  * `momentum`), or evaluation (use_running != 0): from running_mean / running_var.
  * Outputs scale = gamma*rstd, shift = beta - mean*scale, plus mean and rstd for backward.
- * gamma/beta NULL = affine-free BatchNorm (mobilevit.py:15). */
+ * gamma/beta NULL = affine-free BatchNorm (mobilevit.py:15).  num_batches_tracked (optional, device int64) is
+ * incremented in training, like nn.BatchNorm does. */
 int pb_bn_finalize(const float* stats, double count, const float* gamma, const float* beta, float eps,
-                   float momentum, float* running_mean, float* running_var, int use_running,
-                   float* scale, float* shift, float* mean, float* rstd, int C, int device, void* stream);
+                   float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                   int use_running, float* scale, float* shift, float* mean, float* rstd, int C, int device,
+                   void* stream);
 
 /* y = act((x - mean[c])*scale[c] + shift[c]) * row_scale[g, c] + row_shift[g, c], g = m / rows_per_group;
  * optional stats of y.  For BatchNorm pass scale = gamma*rstd, shift = beta, mean = the batch mean: the
@@ -248,9 +272,11 @@ int pb_affine2(const void* g, const void* z, void* out, int64_t M, int C, pb_dty
 /* ---------------------------------------------------------------- squeeze-excite / pooling
  * SEBlock3D (mobilenet.py:11-26) and the classifier's AdaptiveAvgPool3d (mobilenet.py:186,252;
  * movinet.py:147; mobilevit.py:191). */
-/* out[g][c] += sum over the group's rows of a (b == NULL) or of a*b. */
+/* out[g][c] = sum over the group's rows of a (b == NULL) or of a*b.  ws: pb_rowgroup_reduce_ws_bytes bytes of
+ * scratch for the per-workgroup partial rows (may be 0 for small inputs), added up in a fixed order. */
+int64_t pb_rowgroup_reduce_ws_bytes(int64_t G, int64_t rows_per_group, int C, pb_dtype dtype);
 int pb_rowgroup_reduce(const void* a, const void* b, float* out, int64_t G, int64_t rows_per_group, int C,
-                       pb_dtype dtype, int device, void* stream);
+                       pb_dtype dtype, void* ws, int64_t ws_bytes, int device, void* stream);
 
 /* scale[g][c] = hardsigmoid(W2 relu(W1 (pool[g]/count) + b1) + b2); saves hidden (post-relu) [G][Cm].
  * W1 [Cm][C], W2 [C][Cm] fp32 (the reference's Conv3d 1x1x1 weights flattened). */

@@ -11,7 +11,18 @@ Each mirror is itself pinned by tests/test_kernel_ref_cpu.py against torch.nn.fu
 import torch
 import torch.nn.functional as F
 
-REPL = 16   # PB_STAT_REPLICAS: stats buffers are [REPL, 2, C]; the mirror adds into replica 0
+REPL = 4    # statistics buffers are [slots, 2, C] (PB_STAT_SLOTS in the product); the mirror adds into slot 0
+
+
+class deferred_reductions:
+    """Mirror of kernels.deferred_reductions (the product batches its fixed-order partial reductions; the mirror has
+    no partials)."""
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
 
 
 def zeros(shape, device):
@@ -107,7 +118,7 @@ def dw_fwd(x, w, kernel, stride, pad_front, pad_back=None, pool=None):
     y = F.conv3d(_pad_ncdhw(x, pad_front, pad_back), w.view(C, 1, *kernel), stride=stride, groups=C)
     y = y.permute(0, 2, 3, 4, 1).contiguous().to(x.dtype)
     if pool is not None:
-        pool += y.float().sum((1, 2, 3))
+        pool.copy_(y.float().sum((1, 2, 3)))
     return y
 
 
@@ -174,7 +185,10 @@ def chan_stats(x, stats):
     return stats
 
 
-def bn_finalize(stats, count, gamma, beta, eps, momentum, running_mean, running_var, use_running, C, device):
+def bn_finalize(stats, count, gamma, beta, eps, momentum, running_mean, running_var, use_running, C, device,
+                num_batches_tracked=None):
+    if not use_running and num_batches_tracked is not None:
+        num_batches_tracked += 1
     if use_running:
         mean, var = running_mean.double(), running_var.double()
     else:

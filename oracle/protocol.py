@@ -27,6 +27,18 @@ MODEL_CASES = {
     "mobilevit_xxs": ("MobileViT", dict(num_classes=13, **MOBILEVIT_CFG["xxs"]), (1, 32, 224, 224), (1, 10, 96, 96)),
 }
 
+# Well-conditioned gradient fixtures (round 2): the train-mode gradients of MODEL_CASES run BatchNorm over a 2-clip
+# batch, where the reference's own fp32 path is up to 1.5e-2 off fp64.  Two more protocols per model:
+#   evalgrad: model.eval() (running-statistics BatchNorm, SURVEY 8a-T "in eval-mode"), the train clip of MODEL_CASES
+#   train8  : model.train() on 8 clips at reduced resolution
+GRAD_CASES = {   # name -> train8 clip (N,T,H,W)
+    "small3d": (8, 8, 64, 64),
+    "large3d": (8, 8, 112, 112),
+    "movinet_a2": (8, 8, 64, 64),
+    "mobilevit_s": (8, 8, 64, 64),
+    "mobilevit_xxs": (8, 8, 64, 64),
+}
+
 N_SAMPLE = 8
 
 
@@ -110,6 +122,43 @@ def collect_model_case(ns, case, device="cpu", dtype=torch.float32, do_eval=True
         for k, v in bufs[:2] + bufs[-2:]:
             out["buf/" + k] = v.detach().double().cpu()
     return out
+
+
+def collect_grad_case(ns, case, mode, device="cpu", dtype=torch.float32, autocast=False):
+    """mode "evalgrad" | "train8" (see GRAD_CASES) -> RAW tensors {"logits", "loss", "grad/<param>"} (float64, CPU)."""
+    cls_name, kwargs, _, train_shape = MODEL_CASES[case]
+    ncls = kwargs["num_classes"]
+    model = build_model(ns, case, "cpu")
+    if dtype == torch.float64:
+        model = model.double()
+    model = model.to(device)
+    if mode == "evalgrad":
+        model.eval()
+        shape = train_shape
+    elif mode == "train8":
+        model.train()
+        shape = GRAD_CASES[case]
+    else:
+        raise ValueError(mode)
+    x = formula.clip_features(*shape, dtype=dtype).to(device)
+    y = formula.labels(shape[0], ncls).to(device)
+    model.zero_grad(set_to_none=True)
+    if autocast:
+        with torch.autocast(device_type=torch.device(device).type, dtype=torch.bfloat16):
+            logits = model(x)
+    else:
+        logits = model(x)
+    loss = F.cross_entropy(logits if logits.dtype == torch.float64 else logits.float(), y)
+    loss.backward()
+    out = {"logits": logits.detach().double().cpu(), "loss": loss.detach().double().cpu().reshape(1)}
+    for name, p in model.named_parameters():
+        if p.grad is not None:
+            out["grad/" + name] = p.grad.detach().double().cpu()
+    return out
+
+
+def run_grad_case(ns, case, mode, **kw):
+    return summarize(collect_grad_case(ns, case, mode, **kw))
 
 
 N_PROJ = 8

@@ -12,8 +12,8 @@ LIB_PATH = os.path.join(_HERE, "lib", "libpicklebot_amd.so")
 
 PB_F32, PB_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY_RELU, ACT_HSWISH, ACT_HSIGMOID, ACT_SILU = range(6)
-ABI_VERSION = 11
-STAT_REPLICAS = 16
+ABI_VERSION = 12
+STAT_SLOTS = 1024
 
 
 class DwShape(Structure):
@@ -24,6 +24,11 @@ class DwShape(Structure):
 class ConvShape(Structure):
     _fields_ = [(n, c_int) for n in ("N", "Cin", "Cout", "Ti", "Hi", "Wi", "To", "Ho", "Wo", "kt", "kh", "kw",
                                      "st", "sh", "sw", "pt", "ph", "pw")]
+
+
+class ReduceJob(Structure):
+    _fields_ = [("part", c_void_p), ("out", c_void_p), ("n", c_int64), ("stride", c_int64), ("split", c_int),
+                ("accumulate", c_int)]
 
 
 class StemShape(Structure):
@@ -37,20 +42,20 @@ P, F, I, L, D = c_void_p, c_float, c_int, c_int64, c_double
 # name -> argument types (every entry returns int status except the two noted)
 SIGNATURES = {
     "pb_pwconv_fwd": [P, P, P, L, I, I, I, I, I, P, P, I, F, P, L, P, P, I, F, P, I, P],
-    "pb_pwconv_bwd_weight": [P, P, P, L, I, I, I, P, P, I, F, P, L, I, P],
-    "pb_pwconv_bwd_weight_ws": [P, P, P, L, I, I, I, P, P, I, F, P, L, P, L, I, P],
-    "pb_dwconv3d_fwd": [P, P, P, POINTER(DwShape), I, P, I, P],
+    "pb_partials_reduce": [POINTER(ReduceJob), I, I, P],
+    "pb_pwconv_bwd_weight_ws": [P, P, P, L, I, I, I, P, P, I, F, P, L, P, L, POINTER(ReduceJob), I, P],
+    "pb_dwconv3d_fwd": [P, P, P, POINTER(DwShape), I, P, I, I, P],
     "pb_dwconv3d_bwd_data": [P, P, P, POINTER(DwShape), I, P, P, I, P],
-    "pb_dwconv3d_bwd_weight": [P, P, P, POINTER(DwShape), I, P, P, I, P],
+    "pb_dwconv3d_bwd_weight": [P, P, P, POINTER(DwShape), I, P, P, P, L, POINTER(ReduceJob), I, P],
     "pb_stem_conv3d_fwd": [P, I, F, P, P, P, POINTER(StemShape), I, P, I, P],
-    "pb_stem_conv3d_bwd_weight": [P, P, I, F, P, P, POINTER(StemShape), I, I, P],
+    "pb_stem_conv3d_bwd_weight": [P, P, I, F, P, P, POINTER(StemShape), I, P, L, I, P],
     "pb_chan_stats": [P, L, I, I, P, I, P],
-    "pb_bn_finalize": [P, D, P, P, F, F, P, P, I, P, P, P, P, I, I, P],
+    "pb_bn_finalize": [P, D, P, P, F, F, P, P, P, I, P, P, P, P, I, I, P],
     "pb_affine_act_fwd": [P, P, L, I, I, P, P, P, I, F, P, P, L, P, I, P],
     "pb_act_bwd_reduce": [P, P, P, L, I, I, P, P, I, F, P, L, L, F, P, P, P, I, P],
     "pb_bn_bwd_finalize": [P, D, P, P, P, I, P, P, P, P, P, I, I, P],
     "pb_affine2": [P, P, P, L, I, I, P, P, P, P, P, L, P, P, I, F, I, P],
-    "pb_rowgroup_reduce": [P, P, P, L, L, I, I, I, P],
+    "pb_rowgroup_reduce": [P, P, P, L, L, I, I, P, L, I, P],
     "pb_se_fc_fwd": [P, F, P, P, P, P, P, P, I, I, I, I, P],
     "pb_se_fc_bwd": [P, P, F, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P],
     "pb_transpose_f32": [P, P, I, I, I, P],
@@ -65,7 +70,6 @@ SIGNATURES = {
     "pb_conv_weight_prep": [P, P, I, I, I, I, I, P],
     "pb_conv3d_fwd": [P, P, P, POINTER(ConvShape), I, P, P, I, F, P, I, P],
     "pb_conv3d_fwd_bf16w": [P, P, P, POINTER(ConvShape), P, P, P, I, F, P, I, P],
-    "pb_conv3d_bwd_weight": [P, P, P, POINTER(ConvShape), I, I, P],
     "pb_adamw_flat": [P, P, P, P, L, F, F, F, F, F, P, P, P, I, P],
     "pb_grad_check": [P, L, P, I, P],
     "pb_conv3d_bwd_weight_ws": [P, P, P, POINTER(ConvShape), I, P, L, P, I, P],
@@ -83,6 +87,14 @@ STRING_SIGNATURES = {
 SIZE_SIGNATURES = {
     "pb_pwconv_bwd_weight_ws_bytes": [L, I, I, I, I, I, L, I],
     "pb_conv3d_bwd_weight_ws_bytes": [POINTER(ConvShape), I, I],
+    "pb_dwconv3d_bwd_weight_ws_bytes": [POINTER(DwShape), I],
+    "pb_stem_conv3d_bwd_weight_ws_bytes": [POINTER(StemShape), I, F, I],
+    "pb_rowgroup_reduce_ws_bytes": [L, L, I, I],
+}
+
+# entry points returning a plain int count
+COUNT_SIGNATURES = {
+    "pb_dwconv3d_pool_slots": [POINTER(DwShape), I],
 }
 
 
@@ -111,6 +123,10 @@ def load():
     for name, args in SIZE_SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = ctypes.c_int64
+        fn.argtypes = args
+    for name, args in COUNT_SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = c_int
         fn.argtypes = args
     if lib.pb_abi_version() != ABI_VERSION:
         raise RuntimeError(f"picklebot_amd: ABI version mismatch ({lib.pb_abi_version()} != {ABI_VERSION}); rebuild")

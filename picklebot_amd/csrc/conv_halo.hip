@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void conv3d_halo_kernel(HaloArgs a) {
         csum[j] = csq[j] = 0.f;
       }
       lds_barrier();
-      float* st = a.stats + (size_t)(blockIdx.x % PB_STAT_REPLICAS) * 2 * a.Cout;
+      float* st = a.stats + (size_t)blockIdx.x * 2 * a.Cout;     // this workgroup's own slot: plain read-modify-write
       for (int c = tid; c < BN; c += 256) {
         const int nn = n0 + c;
         if (nn < a.Cout) {
@@ -258,8 +258,8 @@ __global__ __launch_bounds__(256) void conv3d_halo_kernel(HaloArgs a) {
             s += sred[(w * BN + c) * 2 + 0];
             q += sred[(w * BN + c) * 2 + 1];
           }
-          atomicAdd(st + nn, s);
-          atomicAdd(st + a.Cout + nn, q);
+          st[nn] += s;
+          st[a.Cout + nn] += q;
         }
       }
     }
@@ -271,9 +271,13 @@ int launch_halo(const HaloArgs& a, int device, hipStream_t st) {
   constexpr int BN = NT * 16;
   constexpr int W_STAGE = ((BN * 4 + 255) / 256) * 4096;
   constexpr size_t lds = (size_t)HALO_BYTES + NSW * W_STAGE + 4 * BN * 2 * 4;
-  static int resident = 0;
+  static int resident_dev[16] = {0};                             // per device: the attribute is per (function, device)
+  int& resident = resident_dev[device & 15];
   if (resident == 0) {
-    (void)hipFuncSetAttribute((const void*)conv3d_halo_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (hipFuncSetAttribute((const void*)conv3d_halo_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      pb_set_error("conv3d halo: cannot reserve %d bytes of LDS", (int)lds);
+      return 1;
+    }
     int per_cu = 0, cus = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv3d_halo_kernel<NT>, 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) cus = 256;
@@ -281,6 +285,7 @@ int launch_halo(const HaloArgs& a, int device, hipStream_t st) {
   }
   int64_t blocks = a.m_tiles * a.n_tiles;
   if (blocks > resident) blocks = resident;
+  if (a.stats && blocks > PB_STAT_SLOTS) blocks = PB_STAT_SLOTS;    // one statistics slot per workgroup
   hipLaunchKernelGGL((conv3d_halo_kernel<NT>), dim3((unsigned)blocks), dim3(256), lds, st, a);
   return 0;
 }
@@ -311,10 +316,12 @@ __attribute__((visibility("hidden"))) int pb_conv3d_halo_fwd(const void* x, cons
   if (a.m_tiles * pb_cdiv(s->Cout, 64) < narrow_below) nt = 2;
   if (force_nt == 2 || force_nt == 4 || force_nt == 6 || force_nt == 8) nt = force_nt;
   a.n_tiles = (int)pb_cdiv(s->Cout, nt * 16);
-  if (nt == 2) launch_halo<2>(a, device, st);
-  else if (nt == 4) launch_halo<4>(a, device, st);
-  else if (nt == 6) launch_halo<6>(a, device, st);
-  else launch_halo<8>(a, device, st);
+  int lrc;
+  if (nt == 2) lrc = launch_halo<2>(a, device, st);
+  else if (nt == 4) lrc = launch_halo<4>(a, device, st);
+  else if (nt == 6) lrc = launch_halo<6>(a, device, st);
+  else lrc = launch_halo<8>(a, device, st);
+  if (lrc) return lrc;
   if (hipGetLastError() != hipSuccess) { pb_set_error("conv3d halo launch failed"); return 1; }
   return 0;
 }

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void dw3_fwd_kernel(Dw3Args a) {
   const int n = nc / a.nchunk, ck = nc - n * a.nchunk;
   const int t0 = ck * a.chunk;
   const int nT = min(a.Td, t0 + a.chunk) - t0;
-  if (nT <= 0) return;
+  if (nT <= 0) return;                                          // (never: nchunk = ceil(Td / chunk))
   const int w0 = sg * WSEG;
   const int ps = a.C / 2;                                       // pixel stride in raw_t units
   // column / row offsets of the 3 x IW input patch (clamped; validity in the masks)
@@ -149,10 +149,9 @@ __global__ __launch_bounds__(256) void dw3_fwd_kernel(Dw3Args a) {
       }
     }
   }
-  if (a.pool) {
-    atomicAdd(a.pool + (int64_t)n * a.C + c0, psum[0]);
-    atomicAdd(a.pool + (int64_t)n * a.C + c0 + 1, psum[1]);
-  }
+  // squeeze-excite partial sums [nchunk*Hd*nseg][N][C]: one slot per (frame chunk, output row, segment), plain stores
+  if (a.pool)
+    *reinterpret_cast<f32x2*>(a.pool + (((((int64_t)ck * a.Hd + ho) * a.nseg + sg) * a.N + n) * a.C + c0)) = psum;
 }
 
 bool dw3_ok(const pb_dwconv_shape* s) {
@@ -161,9 +160,8 @@ bool dw3_ok(const pb_dwconv_shape* s) {
          (s->sh == 1 || s->sh == 2) && s->C % 2 == 0 && s->C >= 16 && (int64_t)s->Hi * s->Wi * s->C < (1LL << 30);
 }
 
-template <typename T, int KT, int S>
-int launch_dw3(Dw3Args a, int flip, hipStream_t st) {
-  constexpr int WSEG = (S == 2 && KT == 5) ? 3 : 4;
+constexpr int dw3_wseg(int KT, int S) { return (S == 2 && KT == 5) ? 3 : 4; }
+void dw3_geom(Dw3Args& a, int KT, int WSEG) {
   a.CP = a.C / 2;
   a.nseg = (int)pb_cdiv(a.Wd, WSEG);
   const int64_t per_chunk = (int64_t)a.N * a.Hd * a.nseg * a.CP;
@@ -174,6 +172,13 @@ int launch_dw3(Dw3Args a, int flip, hipStream_t st) {
   if (nchunk < 1) nchunk = 1;
   a.chunk = (int)pb_cdiv(a.Td, nchunk);
   a.nchunk = (int)pb_cdiv(a.Td, a.chunk);
+}
+
+template <typename T, int KT, int S>
+int launch_dw3(Dw3Args a, int flip, hipStream_t st) {
+  constexpr int WSEG = dw3_wseg(KT, S);
+  dw3_geom(a, KT, WSEG);
+  const int64_t per_chunk = (int64_t)a.N * a.Hd * a.nseg * a.CP;
   const dim3 grid((unsigned)pb_cdiv(per_chunk * a.nchunk, 256));
   if (flip) hipLaunchKernelGGL((dw3_fwd_kernel<T, KT, S, WSEG, true>), grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL((dw3_fwd_kernel<T, KT, S, WSEG, false>), grid, dim3(256), 0, st, a);
@@ -184,6 +189,13 @@ int launch_dw3(Dw3Args a, int flip, hipStream_t st) {
 }  // namespace
 
 bool pb_dw3_eligible(const pb_dwconv_shape* s) { return dw3_ok(s); }
+
+int pb_dw3_pool_slots(const pb_dwconv_shape* s) {
+  Dw3Args a = {};
+  a.N = s->N; a.C = s->C; a.Td = s->To; a.Hd = s->Ho; a.Wd = s->Wo;
+  dw3_geom(a, s->kt, dw3_wseg(s->kt, s->sh));
+  return a.nchunk * a.Hd * a.nseg;
+}
 
 int pb_dw3_fwd(const void* src, const float* w, void* dst, const pb_dwconv_shape* s, pb_dtype dtype, int flip,
                const float* g_scale, const float* g_shift, float* pool, hipStream_t st) {

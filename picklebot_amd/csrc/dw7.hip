@@ -38,10 +38,13 @@ __global__ __launch_bounds__(256) void dw7_fwd_kernel(D7Args a) {
   const int ts = td * a.t_mul + a.t_off;
   raw_t* dst = (raw_t*)a.dst + ((int64_t)z * NPX * a.C + c0) / 2;
   const int64_t pstride = a.C / 2;                          // pixel stride in raw_t units
+  // squeeze-excite partial sums [Tdst][N][C]: one slot per output frame, plain stores (exactly one writer each)
+  float* pslot = a.pool ? a.pool + ((int64_t)td * a.N + n) * a.C + c0 : nullptr;
   if (ts < 0 || ts >= a.Tsrc) {                             // the reference's zero frames
     const raw_t zero = Pair<T>::down(f32x2{0.f, 0.f});
 #pragma unroll
     for (int p = 0; p < NPX; ++p) dst[p * pstride] = zero;
+    if (pslot) *reinterpret_cast<f32x2*>(pslot) = f32x2{0.f, 0.f};
     return;
   }
   const raw_t* src = (const raw_t*)a.src + (((int64_t)n * a.Tsrc + ts) * NPX * a.C + c0) / 2;
@@ -81,10 +84,7 @@ __global__ __launch_bounds__(256) void dw7_fwd_kernel(D7Args a) {
       if (a.pool) psum += Pair<T>::up(o);
     }
   }
-  if (a.pool) {
-    atomicAdd(a.pool + (int64_t)n * a.C + c0, psum[0]);
-    atomicAdd(a.pool + (int64_t)n * a.C + c0 + 1, psum[1]);
-  }
+  if (pslot) *reinterpret_cast<f32x2*>(pslot) = psum;
 }
 
 template <typename T, int K>
@@ -133,8 +133,9 @@ __global__ __launch_bounds__(256) void dw7_wgrad_kernel(D7Args a) {
       }
     }
   }
-  // the workgroup's 512 channels x K*K taps are one contiguous block of dw: go through LDS so that a wave's
-  // atomics hit consecutive floats (per-lane channel-strided atomics cost one memory transaction per lane)
+  // the workgroup's 512 channels x K*K taps are one contiguous block of its partial gradient (a.dw = workspace
+  // [gridDim.x][C][K*K]): through LDS so that the stores are consecutive floats; no atomics, the slots are added up
+  // in a fixed order afterwards
   __shared__ float red[512 * K * K];
 #pragma unroll
   for (int i = 0; i < K * K; ++i) {
@@ -145,7 +146,8 @@ __global__ __launch_bounds__(256) void dw7_wgrad_kernel(D7Args a) {
   __syncthreads();
   const int cbase = blockIdx.y * 512;
   const int nval = min(512, a.C - cbase) * (K * K);
-  for (int i = threadIdx.x; i < nval; i += 256) atomicAdd(a.dw + (int64_t)cbase * (K * K) + i, red[i]);
+  float* part = a.dw + (int64_t)blockIdx.x * a.C * (K * K) + (int64_t)cbase * (K * K);
+  for (int i = threadIdx.x; i < nval; i += 256) part[i] = red[i];
 }
 
 bool d7_ok(const pb_dwconv_shape* s) {
@@ -181,20 +183,31 @@ int pb_dw7_fwd(const void* src, const float* w, void* dst, const pb_dwconv_shape
   return 0;
 }
 
-int pb_dw7_wgrad(const void* dy, const void* x, float* dw, const pb_dwconv_shape* s, pb_dtype dtype,
-                 const float* g_scale, const float* g_shift, hipStream_t st) {
-  if (!d7_ok(s)) return -1;
-  D7Args a = {};
-  a.src = x; a.dstc = dy; a.dw = dw; a.g_scale = g_scale; a.g_shift = g_shift;
-  a.N = s->N; a.C = s->C; a.Tsrc = s->Ti; a.Tdst = s->To; a.t_mul = s->st; a.t_off = -s->pt;
-  // ~512 workgroups in all (98 loads in flight per lane make up for the low occupancy); every workgroup is one
-  // atomic writer per filter tap of its channels
+namespace {
+// ~384 workgroups in all (98 loads in flight per lane make up for the low occupancy); every workgroup writes one
+// partial gradient of its channels
+int d7_wgrad_wgs(const pb_dwconv_shape* s, int* frames_per_wg) {
   const int chunks = (int)pb_cdiv(s->C / 2, 256);
   const int nframes = s->N * s->To;
   int wgs = (int)pb_cdiv(384, chunks);
   if (wgs > nframes) wgs = nframes;
-  a.frames_per_wg = (int)pb_cdiv(nframes, wgs);
-  wgs = (int)pb_cdiv(nframes, a.frames_per_wg);
+  const int fpw = (int)pb_cdiv(nframes, wgs);
+  if (frames_per_wg) *frames_per_wg = fpw;
+  return (int)pb_cdiv(nframes, fpw);
+}
+}  // namespace
+
+int64_t pb_dw7_wgrad_slots(const pb_dwconv_shape* s) { return d7_ok(s) ? d7_wgrad_wgs(s, nullptr) : 0; }
+
+int pb_dw7_wgrad(const void* dy, const void* x, float* part, const pb_dwconv_shape* s, pb_dtype dtype,
+                 const float* g_scale, const float* g_shift, hipStream_t st, int64_t* slots) {
+  if (!d7_ok(s)) return -1;
+  D7Args a = {};
+  a.src = x; a.dstc = dy; a.dw = part; a.g_scale = g_scale; a.g_shift = g_shift;
+  a.N = s->N; a.C = s->C; a.Tsrc = s->Ti; a.Tdst = s->To; a.t_mul = s->st; a.t_off = -s->pt;
+  const int chunks = (int)pb_cdiv(s->C / 2, 256);
+  const int wgs = d7_wgrad_wgs(s, &a.frames_per_wg);
+  *slots = wgs;
   const dim3 grid((unsigned)wgs, (unsigned)chunks);
   if (dtype == PB_BF16) {
     if (s->kh == 3) hipLaunchKernelGGL((dw7_wgrad_kernel<bf16_t, 3>), grid, dim3(256), 0, st, a);

@@ -22,40 +22,41 @@ template <> struct Pair<float> {
 };
 
 
-// LDS-tiled kernels for small frames (dw_tile.hip).  Return 0 on launch, 1 on error, and -1 when the
-// shape is not eligible (caller falls through to the strip / generic kernels).
-__attribute__((visibility("hidden"))) int pb_dw_tile_wgrad(const void* dy, const void* x, float* dw,
-                                                           const pb_dwconv_shape* s, pb_dtype dtype,
-                                                           const float* g_scale, const float* g_shift,
-                                                           hipStream_t st);
-__attribute__((visibility("hidden"))) int pb_dw_tile_fwd(const void* src, const float* w, void* dst,
-                                                         const pb_dwconv_shape* s, pb_dtype dtype, int flip,
-                                                         const float* g_scale, const float* g_shift, float* pool,
-                                                         hipStream_t st);
+#define PB_HIDDEN __attribute__((visibility("hidden")))
 
+// Conventions: launchers return 0 on launch, 1 on error, and -1 when the shape is not eligible (the caller falls
+// through to the next kernel family).  `pool` = squeeze-excite partial sums [slots][N][C], every slot written with
+// plain stores.  Weight-gradient launchers write `*slots` partial gradients [C][taps] into `part` (a workspace of
+// ..._wgrad_slots(s) of them; 0 = shape not taken) - nothing accumulates with atomics.
+
+// LDS-tiled kernels for small frames (dw_tile.hip); the forward has no fused pooling.
+PB_HIDDEN int64_t pb_dw_tile_wgrad_slots(const pb_dwconv_shape* s, pb_dtype dtype);
+PB_HIDDEN int pb_dw_tile_wgrad(const void* dy, const void* x, float* part, const pb_dwconv_shape* s, pb_dtype dtype,
+                               const float* g_scale, const float* g_shift, hipStream_t st, int64_t* slots);
+PB_HIDDEN int pb_dw_tile_fwd(const void* src, const float* w, void* dst, const pb_dwconv_shape* s, pb_dtype dtype, int flip,
+                             const float* g_scale, const float* g_shift, hipStream_t st);
 // would the tile kernels take this correlation (same test the launchers apply)?
-__attribute__((visibility("hidden"))) bool pb_dw_tile_eligible(const pb_dwconv_shape* s, pb_dtype dtype, bool wgrad);
+PB_HIDDEN bool pb_dw_tile_eligible(const pb_dwconv_shape* s, pb_dtype dtype, bool wgrad);
 
-// whole-frame-in-registers kernels for 7x7 frames (dw7.hip); same return convention
-__attribute__((visibility("hidden"))) bool pb_dw7_eligible(const pb_dwconv_shape* s);
-__attribute__((visibility("hidden"))) int pb_dw7_fwd(const void* src, const float* w, void* dst, const pb_dwconv_shape* s,
-                                                     pb_dtype dtype, int flip, const float* g_scale, const float* g_shift,
-                                                     float* pool, hipStream_t st);
-__attribute__((visibility("hidden"))) int pb_dw7_wgrad(const void* dy, const void* x, float* dw, const pb_dwconv_shape* s,
-                                                       pb_dtype dtype, const float* g_scale, const float* g_shift,
-                                                       hipStream_t st);
+// whole-frame-in-registers kernels for 7x7 frames (dw7.hip); pool slots = s->To
+PB_HIDDEN bool pb_dw7_eligible(const pb_dwconv_shape* s);
+PB_HIDDEN int pb_dw7_fwd(const void* src, const float* w, void* dst, const pb_dwconv_shape* s, pb_dtype dtype, int flip,
+                         const float* g_scale, const float* g_shift, float* pool, hipStream_t st);
+PB_HIDDEN int64_t pb_dw7_wgrad_slots(const pb_dwconv_shape* s);
+PB_HIDDEN int pb_dw7_wgrad(const void* dy, const void* x, float* part, const pb_dwconv_shape* s, pb_dtype dtype,
+                           const float* g_scale, const float* g_shift, hipStream_t st, int64_t* slots);
 
-// rolling-window kernels with lanes along channel pairs (dw_rows.hip); same return convention
-__attribute__((visibility("hidden"))) bool pb_dw_rows_eligible(const pb_dwconv_shape* s, bool wgrad);
-__attribute__((visibility("hidden"))) int pb_dw_rows_fwd(const void* src, const float* w, void* dst, const pb_dwconv_shape* s,
-                                                         pb_dtype dtype, int flip, const float* g_scale, const float* g_shift,
-                                                         float* pool, hipStream_t st);
-__attribute__((visibility("hidden"))) int pb_dw_rows_wgrad(const void* dy, const void* x, float* dw, const pb_dwconv_shape* s,
-                                                           pb_dtype dtype, const float* g_scale, const float* g_shift,
-                                                           hipStream_t st);
+// rolling-window kernels with lanes along channel pairs (dw_rows.hip)
+PB_HIDDEN bool pb_dw_rows_eligible(const pb_dwconv_shape* s, bool wgrad);
+PB_HIDDEN int pb_dw_rows_pool_slots(const pb_dwconv_shape* s);
+PB_HIDDEN int pb_dw_rows_fwd(const void* src, const float* w, void* dst, const pb_dwconv_shape* s, pb_dtype dtype, int flip,
+                             const float* g_scale, const float* g_shift, float* pool, hipStream_t st);
+PB_HIDDEN int64_t pb_dw_rows_wgrad_slots(const pb_dwconv_shape* s);
+PB_HIDDEN int pb_dw_rows_wgrad(const void* dy, const void* x, float* part, const pb_dwconv_shape* s, pb_dtype dtype,
+                               const float* g_scale, const float* g_shift, hipStream_t st, int64_t* slots);
 
-// (kt,3,3) kernels walking along time with a ring of kt output accumulators (dw3.hip); same return convention
-__attribute__((visibility("hidden"))) bool pb_dw3_eligible(const pb_dwconv_shape* s);
-__attribute__((visibility("hidden"))) int pb_dw3_fwd(const void* src, const float* w, void* dst, const pb_dwconv_shape* s,
-                                                     pb_dtype dtype, int flip, const float* g_scale, const float* g_shift,
-                                                     float* pool, hipStream_t st);
+// (kt,3,3) kernels walking along time with a ring of kt output accumulators (dw3.hip)
+PB_HIDDEN bool pb_dw3_eligible(const pb_dwconv_shape* s);
+PB_HIDDEN int pb_dw3_pool_slots(const pb_dwconv_shape* s);
+PB_HIDDEN int pb_dw3_fwd(const void* src, const float* w, void* dst, const pb_dwconv_shape* s, pb_dtype dtype, int flip,
+                         const float* g_scale, const float* g_shift, float* pool, hipStream_t st);

@@ -18,7 +18,7 @@ struct RowsArgs {
   const float* w;
   const float* g_scale;
   const float* g_shift;
-  float* pool;
+  float* pool;         // squeeze-excite partial sums [Tdst*nbands*nseg][N][C]: one slot per (frame, band, segment)
   int N, C, Tsrc, Hs, Ws, Tdst, Hd, Wd, t_mul, t_off;
   int nseg, nbands, band_rows, CP;
 };
@@ -46,12 +46,15 @@ __global__ __launch_bounds__(256) void dw_rows_fwd_kernel(RowsArgs a) {
   const int w0 = sg * WSEG;
   const int ps = a.C / 2;                                   // pixel stride in raw_t units
   raw_t* dst = (raw_t*)a.dst + (((int64_t)z * a.Hd + h0) * a.Wd * a.C + c0) / 2 + (int64_t)w0 * ps;
+  // this unit's slot of the pooled partial sums (plain store: every slot has exactly one writer)
+  float* pslot = a.pool ? a.pool + ((((int64_t)td * a.nbands + band) * a.nseg + sg) * a.N + n) * a.C + c0 : nullptr;
   if (ts < 0 || ts >= a.Tsrc) {                             // the reference's zero frames
     const raw_t zero = Pair<T>::down(f32x2{0.f, 0.f});
     for (int t = 0; t < nrows; ++t)
 #pragma unroll
       for (int j = 0; j < WSEG; ++j)
         if (w0 + j < a.Wd) dst[((int64_t)t * a.Wd + j) * ps] = zero;
+    if (pslot) *reinterpret_cast<f32x2*>(pslot) = f32x2{0.f, 0.f};
     return;
   }
   const raw_t* src = (const raw_t*)a.src + ((((int64_t)n * a.Tsrc + ts) * a.Hs) * a.Ws * a.C + c0) / 2;
@@ -143,16 +146,13 @@ __global__ __launch_bounds__(256) void dw_rows_fwd_kernel(RowsArgs a) {
       }
     }
   }
-  if (a.pool) {
-    atomicAdd(a.pool + (int64_t)n * a.C + c0, psum[0]);
-    atomicAdd(a.pool + (int64_t)n * a.C + c0 + 1, psum[1]);
-  }
+  if (pslot) *reinterpret_cast<f32x2*>(pslot) = psum;
 }
 
 struct RowsWgArgs {
   const void* x;       // [N, Tsrc, Hs, Ws, C]
   const void* dy;      // [N, Tdst, Hd, Wd, C]
-  float* dw;           // [C][K*K]
+  float* dw;           // partial gradients [slots][C][K*K] (workspace): slot = workgroup (CP <= 256) or (frame group, band, segment)
   const float* g_scale;
   const float* g_shift;
   int N, C, Tsrc, Hs, Ws, Tdst, Hd, Wd, t_mul, t_off;
@@ -265,28 +265,31 @@ __global__ __launch_bounds__(256) void dw_rows_wgrad_kernel(RowsWgArgs a) {
       }
     }
   }
+  const int nall = 2 * a.CP * KK;
   if (a.CP <= 256) {
-    // narrow layers: the whole [C][k*k] gradient fits the workgroup's LDS - every lane adds its taps there (lanes of
-    // different segments / bands / frame groups share channels), then ONE contiguous atomic pass per workgroup
+    // narrow layers: the whole [C][k*k] gradient fits the workgroup's LDS.  Lanes of different segments / bands / frame
+    // groups share channels: they add their taps in rounds (round r = the threads r*CP .. (r+1)*CP-1, which own distinct
+    // channel pairs), so the order of the additions is fixed; then ONE contiguous store of the workgroup's partial.
     float* ra = &red[0][0];
-    const int nall = 2 * a.CP * KK;
     for (int i = threadIdx.x; i < nall; i += 256) ra[i] = 0.f;
     __syncthreads();
-    if (active && nrows > 0) {
+    const int rounds = (256 + a.CP - 1) / a.CP;
+    const int my_round = threadIdx.x / a.CP;
+    for (int r = 0; r < rounds; ++r) {
+      if (r == my_round && active && nrows > 0) {
 #pragma unroll
-      for (int i = 0; i < KK; ++i) {
-        atomicAdd(&ra[c0 * KK + i], acc[i][0]);
-        atomicAdd(&ra[(c0 + 1) * KK + i], acc[i][1]);
+        for (int i = 0; i < KK; ++i) {
+          ra[c0 * KK + i] += acc[i][0];
+          ra[(c0 + 1) * KK + i] += acc[i][1];
+        }
       }
+      __syncthreads();
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < nall; i += 256) {
-      const float v = ra[i];
-      if (v != 0.f) atomicAdd(a.dw + i, v);
-    }
+    float* part = a.dw + (int64_t)blockIdx.x * nall;
+    for (int i = threadIdx.x; i < nall; i += 256) part[i] = ra[i];
     return;
   }
-  // wave-private transposition: lane l holds the 2*KK consecutive floats [c0*KK, (c0+2)*KK) of dw
+  // wave-private transposition: lane l holds the 2*KK consecutive floats [c0*KK, (c0+2)*KK) of its unit's partial
   float* rw = red[wave];
 #pragma unroll
   for (int i = 0; i < KK; ++i) {
@@ -302,10 +305,11 @@ __global__ __launch_bounds__(256) void dw_rows_wgrad_kernel(RowsWgArgs a) {
     const int l2 = e / (2 * KK), off = e - l2 * (2 * KK);   // source lane, offset inside its 2*KK floats
     const int64_t g2 = gu0 + l2;
     if (g2 < units) {
-      const int u2 = (int)(g2 % per_frame);
-      const int cp2 = u2 % a.CP;
-      const float v = rw[e];
-      if (v != 0.f) atomicAdd(a.dw + (int64_t)cp2 * 2 * KK + off, v);
+      const int fb2 = (int)(g2 / per_frame);
+      const int u2 = (int)(g2 - (int64_t)fb2 * per_frame);
+      const int sg2 = u2 / a.CP, cp2 = u2 - sg2 * a.CP;
+      // slot (frame group, band, segment) has exactly one unit per channel pair: plain stores, every element written
+      a.dw[((int64_t)fb2 * a.nseg + sg2) * nall + (int64_t)cp2 * 2 * KK + off] = rw[e];
     }
   }
 }
@@ -324,16 +328,15 @@ bool rows_ok(const pb_dwconv_shape* s) {
          (int64_t)s->Wi * s->C < (1 << 24);
 }
 
-template <typename T, int K, int S, bool NARROW = false>
-int launch_rows_fwd(RowsArgs a, int flip, hipStream_t st) {
-  constexpr int WSEG = NARROW ? wseg_narrow(K, S) : wseg_of(K, S);
-  if constexpr (!NARROW) {
-    // PB_DW_ROWS_NARROW: bit 0 = k3 s1, bit 1 = k3 s2, bit 2 = k5 s1, bit 3 = k5 s2.  Measured on the training step:
-    // k3 s1 gains 8-18 % from 64 channels up (the 16-channel 112x112 stage loses 17 %), the others do not move.
-    static const int narrow = getenv("PB_DW_ROWS_NARROW") ? atoi(getenv("PB_DW_ROWS_NARROW")) : 1;
-    const int bit = (K == 5 ? 2 : 0) + (S == 2 ? 1 : 0);
-    if (((narrow >> bit) & 1) && a.C >= 64) return launch_rows_fwd<T, K, S, true>(a, flip, st);
-  }
+// forward geometry (shared by the launcher and the pool-slot query): segment width, segments, row bands
+bool rows_fwd_narrow(int K, int S, int C) {
+  // PB_DW_ROWS_NARROW: bit 0 = k3 s1, bit 1 = k3 s2, bit 2 = k5 s1, bit 3 = k5 s2.  Measured on the training step:
+  // k3 s1 gains 8-18 % from 64 channels up (the 16-channel 112x112 stage loses 17 %), the others do not move.
+  static const int narrow = getenv("PB_DW_ROWS_NARROW") ? atoi(getenv("PB_DW_ROWS_NARROW")) : 1;
+  const int bit = (K == 5 ? 2 : 0) + (S == 2 ? 1 : 0);
+  return ((narrow >> bit) & 1) && C >= 64;
+}
+void rows_fwd_geom(RowsArgs& a, int K, int WSEG) {
   a.CP = a.C / 2;
   a.nseg = (int)pb_cdiv(a.Wd, WSEG);
   const int64_t per_frame = (int64_t)a.CP * a.nseg;
@@ -345,6 +348,17 @@ int launch_rows_fwd(RowsArgs a, int flip, hipStream_t st) {
   if (nbands < 1) nbands = 1;
   a.band_rows = (int)pb_cdiv(pb_cdiv(a.Hd, nbands), K) * K;
   a.nbands = (int)pb_cdiv(a.Hd, a.band_rows);
+}
+
+template <typename T, int K, int S, bool NARROW = false>
+int launch_rows_fwd(RowsArgs a, int flip, hipStream_t st) {
+  constexpr int WSEG = NARROW ? wseg_narrow(K, S) : wseg_of(K, S);
+  if constexpr (!NARROW) {
+    if (rows_fwd_narrow(K, S, a.C)) return launch_rows_fwd<T, K, S, true>(a, flip, st);
+  }
+  rows_fwd_geom(a, K, WSEG);
+  const int64_t per_frame = (int64_t)a.CP * a.nseg;
+  const int64_t frames = (int64_t)a.N * a.Tdst;
   const dim3 grid((unsigned)pb_cdiv(frames * a.nbands * per_frame, 256));
   const bool pro = a.g_scale || a.g_shift;
   if (flip) {
@@ -358,21 +372,21 @@ int launch_rows_fwd(RowsArgs a, int flip, hipStream_t st) {
   return 0;
 }
 
-template <typename T, int K, int S, bool NARROW = false>
-int launch_rows_wgrad(RowsWgArgs a, hipStream_t st) {
-  constexpr int WSEG = NARROW ? wseg_narrow(K, S) : wseg_of(K, S);
-  if constexpr (!NARROW) {
-    // bits as in the forward.  Measured: only the 16-channel 112x112 stage gains (95 -> 69 us), wider layers lose
-    static const int narrow = getenv("PB_DW_ROWS_WG_NARROW") ? atoi(getenv("PB_DW_ROWS_WG_NARROW")) : 1;
-    const int bit = (K == 5 ? 2 : 0) + (S == 2 ? 1 : 0);
-    if (((narrow >> bit) & 1) && a.C < 64) return launch_rows_wgrad<T, K, S, true>(a, st);
-  }
+bool rows_wgrad_narrow(int K, int S, int C) {
+  // bits as in the forward.  Measured: only the 16-channel 112x112 stage gains (95 -> 69 us), wider layers lose
+  static const int narrow = getenv("PB_DW_ROWS_WG_NARROW") ? atoi(getenv("PB_DW_ROWS_WG_NARROW")) : 1;
+  const int bit = (K == 5 ? 2 : 0) + (S == 2 ? 1 : 0);
+  return ((narrow >> bit) & 1) && C < 64;
+}
+// weight-gradient geometry (shared by the launcher and the workspace query); returns the number of workgroups,
+// *slots = partial gradients [C][K*K] the launch writes
+int64_t rows_wgrad_geom(RowsWgArgs& a, int K, int WSEG, int64_t* slots) {
   a.CP = a.C / 2;
   a.nseg = (int)pb_cdiv(a.Wd, WSEG);
   const int64_t per_frame = (int64_t)a.CP * a.nseg;
   const int64_t frames = (int64_t)a.N * a.Tdst;
-  // ~64K threads (the kernel's registers admit one wave per SIMD); row bands before frame groups, and at most
-  // 128 accumulating threads per filter tap (same-address float atomics serialise)
+  // ~64K threads (the kernel's registers admit one wave per SIMD); row bands before frame groups; wide layers
+  // (one partial gradient per (frame group, band, segment)) at most 128 partials
   int nbands = 1;
   const int max_bands = (int)pb_cdiv(a.Hd, 2 * K);
   int64_t fgroups = pb_cdiv(64 * 1024, per_frame);
@@ -381,7 +395,7 @@ int launch_rows_wgrad(RowsWgArgs a, hipStream_t st) {
     if (nbands > max_bands) nbands = max_bands;
     fgroups = frames;
   }
-  if (a.CP > 256) {                 // (narrow layers reduce in LDS first: one atomic writer per workgroup)
+  if (a.CP > 256) {                 // (narrow layers reduce in LDS first: one partial per workgroup)
     const int64_t writer_cap = pb_cdiv(128, (int64_t)a.nseg * nbands);
     if (fgroups > writer_cap) fgroups = writer_cap;
   }
@@ -389,8 +403,19 @@ int launch_rows_wgrad(RowsWgArgs a, hipStream_t st) {
   a.band_rows = (int)pb_cdiv(pb_cdiv(a.Hd, nbands), K) * K;
   a.nbands = (int)pb_cdiv(a.Hd, a.band_rows);
   a.FG = (int)fgroups;
-  const dim3 grid((unsigned)pb_cdiv(fgroups * a.nbands * per_frame, 256));
-  hipLaunchKernelGGL((dw_rows_wgrad_kernel<T, K, S, WSEG>), grid, dim3(256), 0, st, a);
+  const int64_t blocks = pb_cdiv(fgroups * a.nbands * per_frame, 256);
+  *slots = a.CP <= 256 ? blocks : fgroups * a.nbands * a.nseg;
+  return blocks;
+}
+
+template <typename T, int K, int S, bool NARROW = false>
+int launch_rows_wgrad(RowsWgArgs a, hipStream_t st, int64_t* slots) {
+  constexpr int WSEG = NARROW ? wseg_narrow(K, S) : wseg_of(K, S);
+  if constexpr (!NARROW) {
+    if (rows_wgrad_narrow(K, S, a.C)) return launch_rows_wgrad<T, K, S, true>(a, st, slots);
+  }
+  const int64_t blocks = rows_wgrad_geom(a, K, WSEG, slots);
+  hipLaunchKernelGGL((dw_rows_wgrad_kernel<T, K, S, WSEG>), dim3((unsigned)blocks), dim3(256), 0, st, a);
   if (hipGetLastError() != hipSuccess) { pb_set_error("dw_rows weight-gradient launch failed"); return 1; }
   return 0;
 }
@@ -407,24 +432,44 @@ bool pb_dw_rows_eligible(const pb_dwconv_shape* s, bool wgrad) {
   return s->C >= 480 || (s->Ho * s->Wo >= 28 * 28 && (s->Wi < 112 || s->C < 64));
 }
 
-int pb_dw_rows_wgrad(const void* dy, const void* x, float* dw, const pb_dwconv_shape* s, pb_dtype dtype,
-                     const float* g_scale, const float* g_shift, hipStream_t st) {
+// number of partial gradients [C][k*k] pb_dw_rows_wgrad writes for this shape (0: shape not taken)
+int64_t pb_dw_rows_wgrad_slots(const pb_dwconv_shape* s) {
+  if (!pb_dw_rows_eligible(s, true)) return 0;
+  RowsWgArgs a = {};
+  a.N = s->N; a.C = s->C; a.Tdst = s->To; a.Hd = s->Ho; a.Wd = s->Wo;
+  const int K = s->kh, S = s->sh;
+  int64_t slots = 0;
+  rows_wgrad_geom(a, K, rows_wgrad_narrow(K, S, a.C) ? wseg_narrow(K, S) : wseg_of(K, S), &slots);
+  return slots;
+}
+
+// part: workspace of pb_dw_rows_wgrad_slots(s) partial gradients; *slots = how many were written
+int pb_dw_rows_wgrad(const void* dy, const void* x, float* part, const pb_dwconv_shape* s, pb_dtype dtype,
+                     const float* g_scale, const float* g_shift, hipStream_t st, int64_t* slots) {
   if (!pb_dw_rows_eligible(s, true)) return -1;
   RowsWgArgs a = {};
-  a.x = x; a.dy = dy; a.dw = dw; a.g_scale = g_scale; a.g_shift = g_shift;
+  a.x = x; a.dy = dy; a.dw = part; a.g_scale = g_scale; a.g_shift = g_shift;
   a.N = s->N; a.C = s->C; a.Tsrc = s->Ti; a.Hs = s->Hi; a.Ws = s->Wi; a.Tdst = s->To; a.Hd = s->Ho; a.Wd = s->Wo;
   a.t_mul = s->st; a.t_off = -s->pt;
   const int K = s->kh, S = s->sh;
-#define PB_ROWSW(TT)                                                          \
-  do {                                                                        \
-    if (K == 3 && S == 1) return launch_rows_wgrad<TT, 3, 1>(a, st);          \
-    if (K == 3 && S == 2) return launch_rows_wgrad<TT, 3, 2>(a, st);          \
-    if (K == 5 && S == 1) return launch_rows_wgrad<TT, 5, 1>(a, st);          \
-    return launch_rows_wgrad<TT, 5, 2>(a, st);                                \
+#define PB_ROWSW(TT)                                                                 \
+  do {                                                                               \
+    if (K == 3 && S == 1) return launch_rows_wgrad<TT, 3, 1>(a, st, slots);          \
+    if (K == 3 && S == 2) return launch_rows_wgrad<TT, 3, 2>(a, st, slots);          \
+    if (K == 5 && S == 1) return launch_rows_wgrad<TT, 5, 1>(a, st, slots);          \
+    return launch_rows_wgrad<TT, 5, 2>(a, st, slots);                                \
   } while (0)
   if (dtype == PB_BF16) PB_ROWSW(bf16_t);
   PB_ROWSW(float);
 #undef PB_ROWSW
+}
+
+int pb_dw_rows_pool_slots(const pb_dwconv_shape* s) {
+  RowsArgs a = {};
+  a.N = s->N; a.C = s->C; a.Tdst = s->To; a.Hd = s->Ho; a.Wd = s->Wo;
+  const int K = s->kh, S = s->sh;
+  rows_fwd_geom(a, K, rows_fwd_narrow(K, S, a.C) ? wseg_narrow(K, S) : wseg_of(K, S));
+  return a.Tdst * a.nbands * a.nseg;
 }
 
 int pb_dw_rows_fwd(const void* src, const float* w, void* dst, const pb_dwconv_shape* s, pb_dtype dtype, int flip,

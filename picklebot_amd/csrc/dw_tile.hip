@@ -22,10 +22,9 @@ struct TileArgs {
   const void* dstc;    // backward-weight: dy [N, Tdst, Hd, Wd, C]
   void* dst;           // forward: output [N, Tdst, Hd, Wd, C]
   const float* w;      // [C][K*K]
-  float* dw;           // [C][K*K]
+  float* dw;           // backward-weight: partial gradients [gridDim.x][C][K*K] (workspace)
   const float* g_scale;   // optional [N][C] prologue on src (fwd) / dy (wgrad): v*g_scale + g_shift
   const float* g_shift;
-  float* pool;            // optional [N][C] += sum of outputs
   int N, C, Tsrc, Hs, Ws, Tdst, Hd, Wd, pad, t_mul, t_off, flip;
   int R, row_tiles, Wdp, Wp, rows_x, nseg;
   int F, ftiles;       // frames per tile (tiny frames), ceil(Tdst / F)
@@ -195,7 +194,6 @@ __global__ __launch_bounds__(256) void dw_tile_fwd_kernel(TileArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* xS = smem;                                   // [F][rows_x][Wp][TCW]
   float* wl = xS + a.F * a.rows_x * a.Wp * TCW;       // [K*K][TCW]
-  float* red = wl + K * K * TCW;                      // [TCW]
   const int tid = threadIdx.x;
   const int cbase = blockIdx.y * TCW;
   const int lq = tid % LPP, c_st = cbase + lq * VEC;
@@ -212,7 +210,6 @@ __global__ __launch_bounds__(256) void dw_tile_fwd_kernel(TileArgs a) {
     const int t2 = a.flip ? (K - 1 - kh) * K + (K - 1 - kw) : tap;
     wl[t2 * TCW + cl] = (cbase + cl < a.C) ? a.w[(int64_t)(cbase + cl) * (K * K) + tap] : 0.f;
   }
-  if (tid < TCW) red[tid] = 0.f;
   const bool affine = a.g_scale || a.g_shift;
   const int xlimit = a.F * a.rows_x * a.Wp * LPP;
   const int64_t src_fs = (int64_t)a.Hs * a.Ws * a.C;
@@ -242,27 +239,8 @@ __global__ __launch_bounds__(256) void dw_tile_fwd_kernel(TileArgs a) {
     tc = tile_coord(a, it);
     fetch(tc);
   }
-  int pool_n = -1;
-  f32x4 psum = {0.f, 0.f, 0.f, 0.f};
-  auto flush_pool = [&]() {      // uniform: called by every thread of the workgroup
-    if (cok_cp) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) atomicAdd(&red[cq * 4 + e], psum[e]);
-    }
-    __syncthreads();
-    if (tid < TCW) {
-      if (cbase + tid < a.C && red[tid] != 0.f) atomicAdd(a.pool + (int64_t)pool_n * a.C + cbase + tid, red[tid]);
-      red[tid] = 0.f;
-    }
-    __syncthreads();
-    psum = f32x4{0.f, 0.f, 0.f, 0.f};
-  };
   while (it < it_end) {
     const TileCoord cur = tc;
-    if (a.pool && pool_n != cur.n) {
-      if (pool_n >= 0) flush_pool();
-      pool_n = cur.n;
-    }
     // frame slots that read nothing (the reference's zero frames) are staged as zeros: their outputs
     // come out as zeros through the same arithmetic
     xr.commit(xS, tid, xlimit, gs, gh, affine);
@@ -299,20 +277,13 @@ __global__ __launch_bounds__(256) void dw_tile_fwd_kernel(TileArgs a) {
         T* o = dst + ((z * a.Hd + cur.r0 + r) * a.Wd + wd0) * a.C + c_cp;
 #pragma unroll
         for (int i = 0; i < WT; ++i) {
-          if (wd0 + i < a.Wd) {
-            store_quad<T>(o + (int64_t)i * a.C, acc[i]);
-            if (a.pool) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) psum[e] += to_f32(from_f32<T>(acc[i][e]));
-            }
-          }
+          if (wd0 + i < a.Wd) store_quad<T>(o + (int64_t)i * a.C, acc[i]);
         }
       }
     }
     lds_barrier();
     it = nx;
   }
-  if (a.pool && pool_n >= 0) flush_pool();
 }
 
 // ----------------------------------------------------------------------------- backward-weight
@@ -412,17 +383,22 @@ __global__ __launch_bounds__(256) void dw_tile_wgrad_kernel(TileArgs a) {
     lds_barrier();
     it = nx;
   }
-  if (j < J) {
-#pragma unroll
-    for (int kw = 0; kw < K; ++kw)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) atomicAdd(&red[(kh * K + kw) * TCW + cq * 4 + e], acc[kw][e]);
-  }
+  // threads that share (channel quad, kh) differ in j: they add their taps in J rounds (fixed order, no atomics)
   __syncthreads();
-  // the chunk's [channel][tap] block is contiguous in dw
+  for (int r = 0; r < J; ++r) {
+    if (j == r) {
+#pragma unroll
+      for (int kw = 0; kw < K; ++kw)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[(kh * K + kw) * TCW + cq * 4 + e] += acc[kw][e];
+    }
+    __syncthreads();
+  }
+  // the chunk's [channel][tap] block is contiguous in this workgroup's partial gradient
+  float* part = a.dw + (int64_t)blockIdx.x * a.C * (K * K) + (int64_t)cbase * (K * K);
   for (int i = tid; i < K * K * TCW; i += 256) {
     const int cl = i / (K * K), tap = i - cl * (K * K);
-    if (cbase + cl < a.C) atomicAdd(a.dw + (int64_t)cbase * (K * K) + i, red[tap * TCW + cl]);
+    if (cbase + cl < a.C) part[i] = red[tap * TCW + cl];
   }
 }
 
@@ -462,50 +438,54 @@ bool plan_tile(int K, int S, int Tdst, int Hd, int Wd, bool wgrad, TilePlan& p) 
   }
   p.ftiles = (int)pb_cdiv(Tdst, p.F);
   p.lds_floats = (size_t)p.F * p.rows_x * p.Wp * 32 + (wgrad ? (size_t)p.F * p.R * p.Wdp * 32 : 0) + (size_t)K * K * 32 +
-                 (wgrad ? 0 : 32);
+                 0;
   return true;
 }
 
-// Occupancy queries cost tens of microseconds on the host: remember the answer per (kernel, LDS size).
-template <typename KernelT>
-int persistent_gx(KernelT kernel, size_t lds_bytes, int chunks, int64_t tiles, int device) {
-  struct Memo { size_t lds; int per_cu; };
-  static thread_local Memo memo[8];
-  static thread_local int nmemo = 0;
-  static thread_local int cus = 0;
+// Occupancy queries cost tens of microseconds on the host: remember the answer per (kernel, LDS size, device).  Every
+// dw_tile instantiation has the same function type, so the kernel's address is part of the key; the grid is a function
+// of (kernel, shape, device) only - never of the call history (the slots a launch writes must be reproducible).
+int persistent_gx(const void* kernel, size_t lds_bytes, int chunks, int64_t tiles, int device) {
+  struct Memo { const void* kernel; size_t lds; int device, per_cu; };
+  static thread_local Memo memo[16];
+  static thread_local int nmemo = 0, cursor = 0;
+  static thread_local int cus[16] = {0};
   int per_cu = 0;
   for (int i = 0; i < nmemo; ++i)
-    if (memo[i].lds == lds_bytes) per_cu = memo[i].per_cu;
+    if (memo[i].kernel == kernel && memo[i].lds == lds_bytes && memo[i].device == device) per_cu = memo[i].per_cu;
   if (per_cu == 0) {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, lds_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
-    memo[nmemo % 8] = Memo{lds_bytes, per_cu};
-    ++nmemo;
-    if (nmemo > 8) nmemo = 8;
+    memo[cursor] = Memo{kernel, lds_bytes, device, per_cu};
+    cursor = (cursor + 1) % 16;
+    if (nmemo < 16) ++nmemo;
   }
-  if (cus == 0 && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) cus = 256;
-  int64_t gx = (int64_t)per_cu * cus / chunks;
+  int& ncu = cus[device & 15];
+  if (ncu == 0 && hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) ncu = 256;
+  int64_t gx = (int64_t)per_cu * ncu / chunks;
   gx -= gx % 8;                  // chunks of one tile index land on the same XCD (ids 8k apart)
   if (gx < 8) gx = 8;
   if (gx > tiles) gx = tiles;
   return (int)gx;
 }
 
+// launch == false: only compute the grid (= the number of partial-gradient slots of the weight gradient)
 template <typename T, int K, int S, bool WGRAD>
-int launch_tile(const TileArgs& a, const TilePlan& p, hipStream_t st) {
+int launch_tile(const TileArgs& a, const TilePlan& p, hipStream_t st, bool launch, int64_t* slots) {
   const size_t lds = p.lds_floats * sizeof(float);
   const int chunks = (int)pb_cdiv(a.C, 32);
   int device = 0;
   (void)hipGetDevice(&device);
   if constexpr (WGRAD) {
     auto kern = dw_tile_wgrad_kernel<T, K, S>;
-    const int gx = persistent_gx(kern, lds, chunks, a.tiles, device);
-    hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)chunks), dim3(256), lds, st, a);
+    const int gx = persistent_gx((const void*)kern, lds, chunks, a.tiles, device);
+    if (slots) *slots = gx;
+    if (launch) hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)chunks), dim3(256), lds, st, a);
   } else {
     auto kern = dw_tile_fwd_kernel<T, K, S>;
-    const int gx = persistent_gx(kern, lds, chunks, a.tiles, device);
-    hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)chunks), dim3(256), lds, st, a);
+    const int gx = persistent_gx((const void*)kern, lds, chunks, a.tiles, device);
+    if (launch) hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)chunks), dim3(256), lds, st, a);
   }
-  if (hipGetLastError() != hipSuccess) {
+  if (launch && hipGetLastError() != hipSuccess) {
     pb_set_error("dw_tile launch failed (lds %zu bytes)", lds);
     return 1;
   }
@@ -513,11 +493,11 @@ int launch_tile(const TileArgs& a, const TilePlan& p, hipStream_t st) {
 }
 
 template <typename T, bool WGRAD>
-int dispatch_tile(const TileArgs& a, const TilePlan& p, int K, int S, hipStream_t st) {
-  if (K == 3 && S == 1) return launch_tile<T, 3, 1, WGRAD>(a, p, st);
-  if (K == 3 && S == 2) return launch_tile<T, 3, 2, WGRAD>(a, p, st);
-  if (K == 5 && S == 1) return launch_tile<T, 5, 1, WGRAD>(a, p, st);
-  if (K == 5 && S == 2) return launch_tile<T, 5, 2, WGRAD>(a, p, st);
+int dispatch_tile(const TileArgs& a, const TilePlan& p, int K, int S, hipStream_t st, bool launch = true, int64_t* slots = nullptr) {
+  if (K == 3 && S == 1) return launch_tile<T, 3, 1, WGRAD>(a, p, st, launch, slots);
+  if (K == 3 && S == 2) return launch_tile<T, 3, 2, WGRAD>(a, p, st, launch, slots);
+  if (K == 5 && S == 1) return launch_tile<T, 5, 1, WGRAD>(a, p, st, launch, slots);
+  if (K == 5 && S == 2) return launch_tile<T, 5, 2, WGRAD>(a, p, st, launch, slots);
   return -1;
 }
 
@@ -547,29 +527,42 @@ bool pb_dw_tile_eligible(const pb_dwconv_shape* s, pb_dtype dtype, bool wgrad) {
   return plan_tile(s->kh, s->sh, s->To, s->Ho, s->Wo, wgrad, p);
 }
 
-int pb_dw_tile_wgrad(const void* dy, const void* x, float* dw, const pb_dwconv_shape* s, pb_dtype dtype,
-                     const float* g_scale, const float* g_shift, hipStream_t st) {
+namespace {
+int tile_wgrad_run(const void* dy, const void* x, float* part, const pb_dwconv_shape* s, pb_dtype dtype,
+                   const float* g_scale, const float* g_shift, hipStream_t st, bool launch, int64_t* slots) {
   if (!pb_dw_tile_eligible(s, dtype, true)) return -1;
   TilePlan p;
   plan_tile(s->kh, s->sh, s->To, s->Ho, s->Wo, true, p);
   TileArgs a = {};
-  a.src = x; a.dstc = dy; a.dw = dw; a.g_scale = g_scale; a.g_shift = g_shift;
+  a.src = x; a.dstc = dy; a.dw = part; a.g_scale = g_scale; a.g_shift = g_shift;
   a.N = s->N; a.C = s->C; a.Tsrc = s->Ti; a.Hs = s->Hi; a.Ws = s->Wi; a.Tdst = s->To; a.Hd = s->Ho; a.Wd = s->Wo;
   a.pad = s->ph; a.t_mul = s->st; a.t_off = -s->pt;
   fill_plan(a, p);
-  return dtype == PB_BF16 ? dispatch_tile<bf16_t, true>(a, p, s->kh, s->sh, st)
-                          : dispatch_tile<float, true>(a, p, s->kh, s->sh, st);
+  return dtype == PB_BF16 ? dispatch_tile<bf16_t, true>(a, p, s->kh, s->sh, st, launch, slots)
+                          : dispatch_tile<float, true>(a, p, s->kh, s->sh, st, launch, slots);
+}
+}  // namespace
+
+// number of partial gradients [C][k*k] the launch writes (0: shape not taken)
+int64_t pb_dw_tile_wgrad_slots(const pb_dwconv_shape* s, pb_dtype dtype) {
+  int64_t slots = 0;
+  return tile_wgrad_run(nullptr, nullptr, nullptr, s, dtype, nullptr, nullptr, nullptr, false, &slots) == 0 ? slots : 0;
+}
+
+int pb_dw_tile_wgrad(const void* dy, const void* x, float* part, const pb_dwconv_shape* s, pb_dtype dtype,
+                     const float* g_scale, const float* g_shift, hipStream_t st, int64_t* slots) {
+  return tile_wgrad_run(dy, x, part, s, dtype, g_scale, g_shift, st, true, slots);
 }
 
 // Forward-type correlation dst = corr(src, w).  `s` describes it directly: Ti/Hi/Wi = src extent,
 // To/Ho/Wo = dst extent, kh/sh, ph = spatial padding seen from dst, frame map ts = td*s->st - s->pt.
 int pb_dw_tile_fwd(const void* src, const float* w, void* dst, const pb_dwconv_shape* s, pb_dtype dtype, int flip,
-                   const float* g_scale, const float* g_shift, float* pool, hipStream_t st) {
+                   const float* g_scale, const float* g_shift, hipStream_t st) {
   if (!pb_dw_tile_eligible(s, dtype, false)) return -1;
   TilePlan p;
   plan_tile(s->kh, s->sh, s->To, s->Ho, s->Wo, false, p);
   TileArgs a = {};
-  a.src = src; a.w = w; a.dst = dst; a.g_scale = g_scale; a.g_shift = g_shift; a.pool = pool; a.flip = flip;
+  a.src = src; a.w = w; a.dst = dst; a.g_scale = g_scale; a.g_shift = g_shift; a.flip = flip;
   a.N = s->N; a.C = s->C; a.Tsrc = s->Ti; a.Hs = s->Hi; a.Ws = s->Wi; a.Tdst = s->To; a.Hd = s->Ho; a.Wd = s->Wo;
   a.pad = s->ph; a.t_mul = s->st; a.t_off = -s->pt;
   fill_plan(a, p);

@@ -50,12 +50,35 @@ __device__ __forceinline__ void store_ch(T* p, const float (&o)[CH]) {
   }
 }
 
+// Sum of per-thread channel vectors over the row lanes p of the (cvl, p) thread layout, in a fixed order (no atomics);
+// the CVB*CH channel sums of the workgroup are stored to out[cbase + ...].  red: CH rows of 256 floats.
+template <int CH>
+__device__ __forceinline__ void block_chan_sum(float* red, const float (&v)[CH], bool lane_ok, int CVB, int P, int cbase,
+                                               int C, float* out) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < CH; ++i) red[i * 256 + tid] = lane_ok ? v[i] : 0.f;
+  __syncthreads();
+  for (int o = tid; o < CVB * CH; o += 256) {
+    const int cvl = o / CH, i = o - cvl * CH;
+    const float* src = red + i * 256 + cvl;
+    float s0 = 0.f, s1 = 0.f;
+    int p = 0;
+    for (; p + 2 <= P; p += 2) {
+      s0 += src[p * CVB];
+      s1 += src[(p + 1) * CVB];
+    }
+    if (p < P) s0 += src[p * CVB];
+    if (cbase + o < C) out[cbase + o] = s0 + s1;
+  }
+}
+
 struct StripArgs {
   const void* src;     // [N, Tsrc, Hs, Ws, C]
   const float* w;      // [C][K*K]
   void* dst;           // [N, Tdst, Hd, Wd, C]
   const void* x;       // backward-weight: the forward input
-  float* dw;           // backward-weight: [C][K*K]
+  float* dw;           // backward-weight: partial gradients [gridDim.x][C][K*K] (workspace)
   int N, C, CV, CVB, P;
   int Tsrc, Hs, Ws;
   int Tdst, Hd, Wd;
@@ -64,7 +87,7 @@ struct StripArgs {
   int flip;
   const float* g_scale;   // optional [N][C]: src value = v*g_scale + g_shift (valid positions only)
   const float* g_shift;
-  float* pool;            // optional [N][C] += sum of outputs
+  float* pool;            // optional squeeze-excite partial sums [Tdst*gridDim.x][N][C]: slot (frame, blockIdx.x)
   int HB;                 // ceil(Hd / TH)
   int64_t items;          // backward-weight: N*Tdst*ceil(HB*Wd/P)
   int xblocks;            // ceil(HB*Wd / P)
@@ -107,7 +130,7 @@ struct RowBatch {
 template <typename T, int K, int S, int CH>
 __global__ __launch_bounds__(256) void dw_strip_fwd_kernel(StripArgs a) {
   __shared__ __attribute__((aligned(16))) float wl[K * K * 32 * CH];   // [tap][CVB*CH] filter taps of this channel chunk
-  __shared__ float red[32 * 8];
+  __shared__ float red[CH * 256];
   constexpr int RH = (TH - 1) * S + K;
   constexpr int NB = (RH + GR - 1) / GR;
   const int tid = threadIdx.x;
@@ -132,7 +155,6 @@ __global__ __launch_bounds__(256) void dw_strip_fwd_kernel(StripArgs a) {
       wl[t2 * CW + cl] = (cbase + cl < a.C) ? a.w[(int64_t)(cbase + cl) * (K * K) + tap] : 0.f;
     }
   }
-  if (tid < 256) red[tid] = 0.f;
   __syncthreads();
 
   float gs[CH], gh[CH], psum[CH];
@@ -227,17 +249,9 @@ __global__ __launch_bounds__(256) void dw_strip_fwd_kernel(StripArgs a) {
       }
     }
   }
-  if (a.pool && frame_ok) {
-    if (lane_ok) {
-#pragma unroll
-      for (int i = 0; i < CH; ++i) atomicAdd(&red[cvl * CH + i], psum[i]);
-    }
-    __syncthreads();
-    if (tid < CW) {
-      const int c = blockIdx.y * CW + tid;
-      if (c < a.C && red[tid] != 0.f) atomicAdd(a.pool + (int64_t)n * a.C + c, red[tid]);
-    }
-  }
+  if (a.pool)      // every (frame, blockIdx.x) slot is written (zero frames contribute zeros)
+    block_chan_sum<CH>(red, psum, lane_ok, a.CVB, a.P, blockIdx.y * CW, a.C,
+                       a.pool + (((int64_t)td * gridDim.x + blockIdx.x) * a.N + n) * a.C);
 }
 
 // Weight gradient for the strip family: dst-shaped tensor = dy (gradient of the conv output),
@@ -347,20 +361,24 @@ __global__ __launch_bounds__(256) void dw_strip_wgrad_kernel(StripArgs a) {
       }
     }
   }
-  if (lane_ok) {
+  // threads that share a channel vector differ in the row lane p: they add their taps in P rounds (fixed order)
+  for (int r = 0; r < a.P; ++r) {
+    if (lane_ok && p == r) {
 #pragma unroll
-    for (int kh = 0; kh < K; ++kh)
+      for (int kh = 0; kh < K; ++kh)
 #pragma unroll
-      for (int kw = 0; kw < K; ++kw)
+        for (int kw = 0; kw < K; ++kw)
 #pragma unroll
-        for (int i = 0; i < CH; ++i) atomicAdd(&red[(kh * K + kw) * CW + cvl * CH + i], acc[kh][kw][i]);
+          for (int i = 0; i < CH; ++i) red[(kh * K + kw) * CW + cvl * CH + i] += acc[kh][kw][i];
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  // the chunk's [channel][tap] block is contiguous in dw: consecutive threads -> consecutive floats
+  // the chunk's [channel][tap] block is contiguous in this workgroup's partial gradient
   const int cbase = blockIdx.y * CW;
+  float* part = a.dw + (int64_t)blockIdx.x * a.C * (K * K) + (int64_t)cbase * (K * K);
   for (int i = tid; i < K * K * CW; i += 256) {
     const int cl = i / (K * K), tap = i - cl * (K * K);
-    if (cbase + cl < a.C) atomicAdd(a.dw + (int64_t)cbase * (K * K) + i, red[tap * CW + cl]);
+    if (cbase + cl < a.C) part[i] = red[tap * CW + cl];
   }
 }
 
@@ -538,17 +556,13 @@ __global__ __launch_bounds__(256) void dw_gen_fwd_kernel(GenArgs a) {
     }
   }
   store_ch<T, CH>((T*)a.dst + ((((int64_t)n * s.To + to) * s.Ho + ho) * s.Wo + wo) * s.C + c0, acc);
-  if (a.pool) {
-#pragma unroll
-    for (int i = 0; i < CH; ++i) atomicAdd(a.pool + (int64_t)n * s.C + c0 + i, to_f32(from_f32<T>(acc[i])));
-  }
 }
 
 // pooled variant: block = (channel-vector lanes) x (voxel lanes) over ONE clip (blockIdx.z = n), so the
-// squeeze-excite sums reduce in LDS and cost one global atomic per workgroup and channel
+// squeeze-excite sums reduce in LDS (fixed order) into the workgroup's slot: pool is [gridDim.x][N][C]
 template <typename T, int CH>
 __global__ __launch_bounds__(256) void dw_gen_fwd_pool_kernel(GenArgs a, int CVB, int P, int cchunks) {
-  __shared__ float red[32 * 8];
+  __shared__ float red[CH * 256];
   const pb_dwconv_shape& s = a.s;
   const int tid = threadIdx.x;
   const int cvl = tid % CVB, p = tid / CVB;
@@ -558,8 +572,6 @@ __global__ __launch_bounds__(256) void dw_gen_fwd_pool_kernel(GenArgs a, int CVB
   const int n = blockIdx.z;
   const int taps = s.kt * s.kh * s.kw;
   const T* x = (const T*)a.src;
-  if (tid < 256) red[tid] = 0.f;
-  __syncthreads();
   float psum[CH];
 #pragma unroll
   for (int i = 0; i < CH; ++i) psum[i] = 0.f;
@@ -594,14 +606,9 @@ __global__ __launch_bounds__(256) void dw_gen_fwd_pool_kernel(GenArgs a, int CVB
 #pragma unroll
       for (int i = 0; i < CH; ++i) psum[i] += to_f32(from_f32<T>(acc[i]));
     }
-#pragma unroll
-    for (int i = 0; i < CH; ++i) atomicAdd(&red[cvl * CH + i], psum[i]);
   }
-  __syncthreads();
-  if (tid < CVB * CH) {
-    const int c = blockIdx.y * CVB * CH + tid;
-    if (c < s.C) atomicAdd(a.pool + (int64_t)n * s.C + c, red[tid]);
-  }
+  block_chan_sum<CH>(red, psum, lane_ok, CVB, P, blockIdx.y * CVB * CH, s.C,
+                     a.pool + ((int64_t)blockIdx.x * gridDim.z + n) * s.C);
 }
 
 // backward-data: one thread = CH channels of one INPUT voxel
@@ -656,7 +663,7 @@ __global__ __launch_bounds__(256) void dw_gen_bwd_data_kernel(GenArgs a) {
 // voxels, then a block reduction per channel.
 template <typename T, int CH>
 __global__ __launch_bounds__(256) void dw_gen_wgrad_kernel(GenArgs a, int CVB, int P, int cchunks) {
-  __shared__ float red[32 * 8];
+  __shared__ float red[CH * 256 + 32 * CH];
   const pb_dwconv_shape& s = a.s;
   const int tid = threadIdx.x;
   const int cvl = tid % CVB, p = tid / CVB;
@@ -666,8 +673,6 @@ __global__ __launch_bounds__(256) void dw_gen_wgrad_kernel(GenArgs a, int CVB, i
   const int c0 = cv * CH;
   const int aw = tap % s.kw, ah = (tap / s.kw) % s.kh, at = tap / (s.kw * s.kh);
   const int taps = s.kt * s.kh * s.kw;
-  if (tid < 256) red[tid] = 0.f;
-  __syncthreads();
   const T* dy = (const T*)a.src;
   const T* x = (const T*)a.x;
   float acc[CH];
@@ -693,13 +698,13 @@ __global__ __launch_bounds__(256) void dw_gen_wgrad_kernel(GenArgs a, int CVB, i
         acc[i] += (g[i] * gs + gh) * xv[i];
       }
     }
-#pragma unroll
-    for (int i = 0; i < CH; ++i) atomicAdd(&red[cvl * CH + i], acc[i]);
   }
+  // a.dw: partial gradients [gridDim.x][C][taps]; this workgroup's (tap, channel chunk) entries of its slot
+  block_chan_sum<CH>(red, acc, lane_ok, CVB, P, 0, CVB * CH, red + CH * 256);
   __syncthreads();
   if (tid < CVB * CH) {
     const int c = chunk * CVB * CH + tid;
-    if (c < s.C && red[tid] != 0.f) atomicAdd(a.dw + (int64_t)c * taps + tap, red[tid]);
+    if (c < s.C) a.dw[((int64_t)blockIdx.x * s.C + c) * taps + tap] = red[CH * 256 + tid];
   }
 }
 
@@ -716,8 +721,8 @@ bool strip_ok(const pb_dwconv_shape& s) {
          s.ph == s.pw && s.C % 4 == 0;
 }
 
-template <typename T, int K, int S, int CH>
-void launch_strip_fwd(StripArgs a, hipStream_t st) {
+// strip geometry for CH channels per thread; returns the forward grid's x extent
+int64_t strip_fwd_geom(StripArgs& a, int CH) {
   a.CV = a.C / CH;
   a.CVB = pick_cvb(a.CV);
   a.P = 256 / a.CVB;
@@ -729,11 +734,17 @@ void launch_strip_fwd(StripArgs a, hipStream_t st) {
   int64_t gx = pb_cdiv(2048, chunks * frames);
   if (gx < pb_cdiv(a.xblocks, 8)) gx = pb_cdiv(a.xblocks, 8);
   if (gx > a.xblocks) gx = a.xblocks;
+  return gx;
+}
+template <typename T, int K, int S, int CH>
+void launch_strip_fwd(StripArgs a, hipStream_t st) {
+  const int64_t gx = strip_fwd_geom(a, CH);
+  const int64_t chunks = pb_cdiv(a.CV, a.CVB), frames = (int64_t)a.N * a.Tdst;
   dim3 grid((unsigned)gx, (unsigned)chunks, (unsigned)frames);
   hipLaunchKernelGGL((dw_strip_fwd_kernel<T, K, S, CH>), grid, dim3(256), 0, st, a);
 }
-template <typename T, int K, int S, int CH>
-void launch_strip_wgrad(StripArgs a, hipStream_t st) {
+// returns the weight-gradient grid's x extent = the number of partial gradients the launch writes
+int64_t strip_wgrad_geom(StripArgs& a, int CH) {
   a.CV = a.C / CH;
   a.CVB = pick_cvb(a.CV);
   a.P = 256 / a.CVB;
@@ -741,14 +752,22 @@ void launch_strip_wgrad(StripArgs a, hipStream_t st) {
   a.xblocks = (int)pb_cdiv((int64_t)a.HB * a.Wd, a.P);
   a.items = (int64_t)a.N * a.Tdst * a.xblocks;
   const int chunks = (int)pb_cdiv(a.CV, a.CVB);
-  // persistent grid of ~1024 workgroups; gx is also the number of atomic writers per dw element
+  // persistent grid of ~1024 workgroups, each writing one partial gradient of its channel chunk
   int64_t gx = pb_cdiv(1024, chunks);
-  // every workgroup pays a fixed flush (k*k*CW LDS + global atomics): give it >= 8 items
+  // every workgroup pays a fixed flush (k*k*CW LDS + the partial's stores): give it >= 8 items
   if (gx > pb_cdiv(a.items, 8)) gx = pb_cdiv(a.items, 8);
   if (gx < 1) gx = 1;
-  dim3 grid((unsigned)gx, (unsigned)chunks);
+  return gx;
+}
+template <typename T, int K, int S, int CH>
+void launch_strip_wgrad(StripArgs a, hipStream_t st) {
+  const int64_t gx = strip_wgrad_geom(a, CH);
+  dim3 grid((unsigned)gx, (unsigned)pb_cdiv(a.CV, a.CVB));
   hipLaunchKernelGGL((dw_strip_wgrad_kernel<T, K, S, CH>), grid, dim3(256), 0, st, a);
 }
+
+// channels per thread of the strip kernels (see dispatch_strip)
+int strip_ch(bool bf16, int K, int C) { return (bf16 && K == 3 && C % 8 == 0) ? 8 : 4; }
 
 // bf16: 8 channels/thread for k=3 (16 B), 4 for k=5 (taps live in registers: 25*4 = 100 VGPRs);
 // f32: 4 channels/thread (16 B).
@@ -837,11 +856,51 @@ extern "C" const char* pb_dwconv3d_kernel_name(const pb_dwconv_shape* s, pb_dtyp
   return strip_ok(*s) ? "dw_strip_wgrad_kernel" : "dw_gen_wgrad_kernel";
 }
 
+namespace {
+// generic pooled forward: grid geometry (also the number of pool slots)
+int64_t gen_pool_geom(const pb_dwconv_shape* s, int* ch_o, int* cvb_o, int* P_o, int* cchunks_o) {
+  const int ch = s->C % 4 == 0 ? 4 : 1;
+  const int CV = s->C / ch;
+  const int cvb = pick_cvb(CV), P = 256 / cvb, cchunks = (int)pb_cdiv(CV, cvb);
+  int64_t gx = pb_cdiv((int64_t)s->To * s->Ho * s->Wo, (int64_t)P * 4);
+  const int64_t cap = pb_cdiv(4096, (int64_t)cchunks * s->N);
+  if (gx > cap) gx = cap;
+  if (gx < 1) gx = 1;
+  if (ch_o) *ch_o = ch;
+  if (cvb_o) *cvb_o = cvb;
+  if (P_o) *P_o = P;
+  if (cchunks_o) *cchunks_o = cchunks;
+  return gx;
+}
+StripArgs strip_fwd_args(const void* x, const float* w, void* y, const pb_dwconv_shape* s, float* pool) {
+  StripArgs a = {};
+  a.src = x; a.w = w; a.dst = y; a.N = s->N; a.C = s->C;
+  a.Tsrc = s->Ti; a.Hs = s->Hi; a.Ws = s->Wi; a.Tdst = s->To; a.Hd = s->Ho; a.Wd = s->Wo;
+  a.pad = s->ph; a.t_mul = s->st; a.t_off = -s->pt; a.flip = 0; a.pool = pool;
+  return a;
+}
+}  // namespace
+
+// Number of squeeze-excite partial-sum slots pb_dwconv3d_fwd writes for this shape: follows the kernel dispatch.
+extern "C" int pb_dwconv3d_pool_slots(const pb_dwconv_shape* s, pb_dtype dtype) {
+  if (!s || s->N <= 0 || s->C <= 0) return 0;
+  if (pb_dw3_eligible(s)) return pb_dw3_pool_slots(s);
+  if (pb_dw7_eligible(s)) return s->To;
+  if (pb_dw_rows_eligible(s, false)) return pb_dw_rows_pool_slots(s);
+  if (strip_ok(*s)) {      // (the tile kernel has no fused pooling: pooled forwards skip it)
+    StripArgs a = strip_fwd_args(nullptr, nullptr, nullptr, s, nullptr);
+    return (int)(s->To * strip_fwd_geom(a, strip_ch(dtype == PB_BF16, s->kh, s->C)));
+  }
+  return (int)gen_pool_geom(s, nullptr, nullptr, nullptr, nullptr);
+}
+
 extern "C" int pb_dwconv3d_fwd(const void* x, const float* w, void* y, const pb_dwconv_shape* s, pb_dtype dtype,
-                               float* pool, int device, void* stream) {
+                               float* pool, int pool_slots, int device, void* stream) {
   PB_CHECK_ARG(x && w && y, "pb_dwconv3d_fwd: null pointer");
   if (int rc = check_shape(s, "pb_dwconv3d_fwd")) return rc;
   PB_CHECK_ARG(dtype == PB_F32 || dtype == PB_BF16, "pb_dwconv3d_fwd: bad dtype");
+  PB_CHECK_ARG(!pool || pool_slots == pb_dwconv3d_pool_slots(s, dtype), "pb_dwconv3d_fwd: pool_slots=%d, this shape writes %d",
+               pool_slots, pb_dwconv3d_pool_slots(s, dtype));
   PB_ENTER(device);
   hipStream_t st = (hipStream_t)stream;
   {
@@ -851,14 +910,13 @@ extern "C" int pb_dwconv3d_fwd(const void* x, const float* w, void* y, const pb_
     if (rc >= 0) return rc;
     rc = pb_dw_rows_fwd(x, w, y, s, dtype, 0, nullptr, nullptr, pool, st);
     if (rc >= 0) return rc;
-    rc = pb_dw_tile_fwd(x, w, y, s, dtype, 0, nullptr, nullptr, pool, st);
-    if (rc >= 0) return rc;
+    if (!pool) {
+      rc = pb_dw_tile_fwd(x, w, y, s, dtype, 0, nullptr, nullptr, st);
+      if (rc >= 0) return rc;
+    }
   }
   if (strip_ok(*s)) {
-    StripArgs a = {};
-    a.src = x; a.w = w; a.dst = y; a.N = s->N; a.C = s->C;
-    a.Tsrc = s->Ti; a.Hs = s->Hi; a.Ws = s->Wi; a.Tdst = s->To; a.Hd = s->Ho; a.Wd = s->Wo;
-    a.pad = s->ph; a.t_mul = s->st; a.t_off = -s->pt; a.flip = 0; a.pool = pool;
+    StripArgs a = strip_fwd_args(x, w, y, s, pool);
     int rc = dtype == PB_BF16 ? dispatch_strip<bf16_t, false>(a, s->kh, s->sh, st)
                               : dispatch_strip<float, false>(a, s->kh, s->sh, st);
     if (rc) return rc;
@@ -869,11 +927,8 @@ extern "C" int pb_dwconv3d_fwd(const void* x, const float* w, void* y, const pb_
     a.CV = s->C / ch;
     a.total = (int64_t)s->N * s->To * s->Ho * s->Wo * a.CV;
     if (pool) {
-      const int cvb = pick_cvb(a.CV), P = 256 / cvb, cchunks = (int)pb_cdiv(a.CV, cvb);
-      int64_t gx = pb_cdiv((int64_t)s->To * s->Ho * s->Wo, (int64_t)P * 4);
-      const int64_t cap = pb_cdiv(4096, (int64_t)cchunks * s->N);
-      if (gx > cap) gx = cap;
-      if (gx < 1) gx = 1;
+      int cvb, P, cchunks;
+      const int64_t gx = gen_pool_geom(s, nullptr, &cvb, &P, &cchunks);
       dim3 pg((unsigned)gx, (unsigned)cchunks, (unsigned)s->N);
       if (dtype == PB_BF16) {
         if (ch == 4) hipLaunchKernelGGL((dw_gen_fwd_pool_kernel<bf16_t, 4>), pg, dim3(256), 0, st, a, cvb, P, cchunks);
@@ -918,7 +973,7 @@ extern "C" int pb_dwconv3d_bwd_data(const void* dy, const float* w, void* dx, co
     if (rc >= 0) return rc;
     rc = pb_dw_rows_fwd(dy, w, dx, &c, dtype, 1, g_scale, g_shift, nullptr, st);
     if (rc >= 0) return rc;
-    rc = pb_dw_tile_fwd(dy, w, dx, &c, dtype, 1, g_scale, g_shift, nullptr, st);
+    rc = pb_dw_tile_fwd(dy, w, dx, &c, dtype, 1, g_scale, g_shift, st);
     if (rc >= 0) return rc;
   }
   if (bwd_is_s1_corr(*s)) {
@@ -973,42 +1028,84 @@ extern "C" int pb_dwconv3d_bwd_data(const void* dy, const float* w, void* dx, co
   return 0;
 }
 
+namespace {
+StripArgs strip_wgrad_args(const void* dy, const void* x, float* part, const pb_dwconv_shape* s, const float* g_scale,
+                           const float* g_shift) {
+  StripArgs a = {};
+  a.dst = const_cast<void*>(dy); a.x = x; a.dw = part; a.N = s->N; a.C = s->C;
+  a.Tsrc = s->Ti; a.Hs = s->Hi; a.Ws = s->Wi; a.Tdst = s->To; a.Hd = s->Ho; a.Wd = s->Wo;
+  a.pad = s->ph; a.t_mul = s->st; a.t_off = -s->pt;
+  a.g_scale = g_scale; a.g_shift = g_shift;
+  return a;
+}
+int64_t gen_wgrad_gx(const pb_dwconv_shape* s, int* ch_o, int* cvb_o, int* P_o, int* cchunks_o) {
+  const int ch = s->C % 4 == 0 ? 4 : 1;
+  const int CV = s->C / ch;
+  const int cvb = pick_cvb(CV), P = 256 / cvb, cchunks = (int)pb_cdiv(CV, cvb);
+  const int taps = s->kt * s->kh * s->kw;
+  const int64_t nvox = (int64_t)s->N * s->To * s->Ho * s->Wo;
+  int64_t gx = pb_cdiv(nvox, P);
+  const int64_t cap = pb_cdiv(4096, (int64_t)taps * cchunks);
+  if (gx > cap) gx = cap;
+  if (gx < 1) gx = 1;
+  if (ch_o) *ch_o = ch;
+  if (cvb_o) *cvb_o = cvb;
+  if (P_o) *P_o = P;
+  if (cchunks_o) *cchunks_o = cchunks;
+  return gx;
+}
+// partial gradients [slots][C][taps] the weight-gradient dispatch writes for this shape
+int64_t wgrad_slots(const pb_dwconv_shape* s, pb_dtype dtype) {
+  if (int64_t n = pb_dw7_wgrad_slots(s)) return n;
+  if (int64_t n = pb_dw_rows_wgrad_slots(s)) return n;
+  if (int64_t n = pb_dw_tile_wgrad_slots(s, dtype)) return n;
+  if (strip_ok(*s)) {
+    StripArgs a = strip_wgrad_args(nullptr, nullptr, nullptr, s, nullptr, nullptr);
+    return strip_wgrad_geom(a, strip_ch(dtype == PB_BF16, s->kh, s->C));
+  }
+  return gen_wgrad_gx(s, nullptr, nullptr, nullptr, nullptr);
+}
+}  // namespace
+
+extern "C" int64_t pb_dwconv3d_bwd_weight_ws_bytes(const pb_dwconv_shape* s, pb_dtype dtype) {
+  if (!s || s->N <= 0 || s->C <= 0 || s->kt <= 0 || s->kh <= 0 || s->kw <= 0) return 0;
+  return wgrad_slots(s, dtype) * s->C * s->kt * s->kh * s->kw * 4;
+}
+
 extern "C" int pb_dwconv3d_bwd_weight(const void* dy, const void* x, float* dw, const pb_dwconv_shape* s,
-                                      pb_dtype dtype, const float* g_scale, const float* g_shift, int device,
-                                      void* stream) {
-  PB_CHECK_ARG(dy && x && dw, "pb_dwconv3d_bwd_weight: null pointer");
+                                      pb_dtype dtype, const float* g_scale, const float* g_shift, void* ws,
+                                      int64_t ws_bytes, pb_reduce_job* deferred, int device, void* stream) {
+  PB_CHECK_ARG(dy && x && dw && ws, "pb_dwconv3d_bwd_weight: null pointer");
   if (int rc = check_shape(s, "pb_dwconv3d_bwd_weight")) return rc;
   PB_CHECK_ARG(dtype == PB_F32 || dtype == PB_BF16, "pb_dwconv3d_bwd_weight: bad dtype");
+  PB_CHECK_ARG(((uintptr_t)ws % 16) == 0 && ws_bytes >= pb_dwconv3d_bwd_weight_ws_bytes(s, dtype),
+               "pb_dwconv3d_bwd_weight: workspace too small or unaligned (%lld bytes needed)",
+               (long long)pb_dwconv3d_bwd_weight_ws_bytes(s, dtype));
   PB_ENTER(device);
   hipStream_t st = (hipStream_t)stream;
+  float* part = (float*)ws;
+  const int taps = s->kt * s->kh * s->kw;
+  int64_t slots = -1;
   {
-    int rc = pb_dw7_wgrad(dy, x, dw, s, dtype, g_scale, g_shift, st);
-    if (rc >= 0) return rc;
-    rc = pb_dw_rows_wgrad(dy, x, dw, s, dtype, g_scale, g_shift, st);
-    if (rc >= 0) return rc;
-    rc = pb_dw_tile_wgrad(dy, x, dw, s, dtype, g_scale, g_shift, st);
-    if (rc >= 0) return rc;
+    int rc = pb_dw7_wgrad(dy, x, part, s, dtype, g_scale, g_shift, st, &slots);
+    if (rc < 0) rc = pb_dw_rows_wgrad(dy, x, part, s, dtype, g_scale, g_shift, st, &slots);
+    if (rc < 0) rc = pb_dw_tile_wgrad(dy, x, part, s, dtype, g_scale, g_shift, st, &slots);
+    if (rc > 0) return rc;
+    if (rc < 0) slots = -1;
   }
-  if (strip_ok(*s)) {
-    StripArgs a = {};
-    a.dst = const_cast<void*>(dy); a.x = x; a.dw = dw; a.N = s->N; a.C = s->C;
-    a.Tsrc = s->Ti; a.Hs = s->Hi; a.Ws = s->Wi; a.Tdst = s->To; a.Hd = s->Ho; a.Wd = s->Wo;
-    a.pad = s->ph; a.t_mul = s->st; a.t_off = -s->pt;
-    a.g_scale = g_scale; a.g_shift = g_shift;
+  if (slots < 0 && strip_ok(*s)) {
+    StripArgs a = strip_wgrad_args(dy, x, part, s, g_scale, g_shift);
+    StripArgs g = a;
+    slots = strip_wgrad_geom(g, strip_ch(dtype == PB_BF16, s->kh, s->C));
     int rc = dtype == PB_BF16 ? dispatch_strip<bf16_t, true>(a, s->kh, s->sh, st) : dispatch_strip<float, true>(a, s->kh, s->sh, st);
     if (rc) return rc;
-  } else {
+  } else if (slots < 0) {
     GenArgs a = {};
-    a.src = dy; a.x = x; a.dw = dw; a.s = *s; a.g_scale = g_scale; a.g_shift = g_shift;
-    const int ch = s->C % 4 == 0 ? 4 : 1;
+    a.src = dy; a.x = x; a.dw = part; a.s = *s; a.g_scale = g_scale; a.g_shift = g_shift;
+    int ch, cvb, P, cchunks;
+    const int64_t gx = gen_wgrad_gx(s, &ch, &cvb, &P, &cchunks);
     a.CV = s->C / ch;
-    const int cvb = pick_cvb(a.CV), P = 256 / cvb, cchunks = (int)pb_cdiv(a.CV, cvb);
-    const int taps = s->kt * s->kh * s->kw;
-    const int64_t nvox = (int64_t)s->N * s->To * s->Ho * s->Wo;
-    int64_t gx = pb_cdiv(nvox, P);
-    const int64_t cap = pb_cdiv(4096, (int64_t)taps * cchunks);
-    if (gx > cap) gx = cap;
-    if (gx < 1) gx = 1;
+    slots = gx;
     dim3 grid((unsigned)gx, (unsigned)(taps * cchunks));
     if (dtype == PB_BF16) {
       if (ch == 4) hipLaunchKernelGGL((dw_gen_wgrad_kernel<bf16_t, 4>), grid, dim3(256), 0, st, a, cvb, P, cchunks);
@@ -1019,5 +1116,10 @@ extern "C" int pb_dwconv3d_bwd_weight(const void* dy, const void* x, float* dw, 
     }
   }
   PB_LAUNCH_CHECK();
+  // dw += sum of the partial gradients, in slot order
+  const int64_t n = (int64_t)s->C * taps;
+  const pb_reduce_job job = {part, dw, n, n, (int)slots, 1};
+  if (deferred) { *deferred = job; return 0; }
+  if (pb_launch_partials_reduce(&job, 1, st)) { pb_set_error("pb_dwconv3d_bwd_weight: combine launch failed"); return 2; }
   return 0;
 }

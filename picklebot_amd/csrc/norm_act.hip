@@ -73,22 +73,34 @@ __device__ __forceinline__ void stv(T* p, const float (&o)[CH]) {
   }
 }
 
-// block-level reduction of NRED per-thread channel vectors, then global atomics.
-// red must hold NRED * CVB*CH floats and be zeroed (and synced) by the caller.
+// Block-level reduction of NRED per-thread channel vectors over the row lanes p of the (cvl, p) thread layout, in a
+// fixed order (no atomics: results are bit-reproducible), then ONE plain store per channel into this workgroup's
+// own slot of the output.  red holds NRED*CH rows of 256 floats.
 template <int CH, int NRED>
-__device__ __forceinline__ void block_chan_reduce(float* red, const float (&v)[NRED][CH], bool lane_ok, int cvl,
-                                                  int CW, int cbase, int C, float* const (&out)[NRED]) {
-  if (lane_ok) {
+__device__ __forceinline__ void block_chan_reduce(float* red, const float (&v)[NRED][CH], bool lane_ok, int CVB, int P,
+                                                  int cbase, int C, float* const (&out)[NRED]) {
+  const int tid = threadIdx.x;
 #pragma unroll
-    for (int r = 0; r < NRED; ++r)
+  for (int r = 0; r < NRED; ++r)
 #pragma unroll
-      for (int i = 0; i < CH; ++i) atomicAdd(&red[r * CW + cvl * CH + i], v[r][i]);
-  }
+    for (int i = 0; i < CH; ++i) red[(r * CH + i) * 256 + tid] = lane_ok ? v[r][i] : 0.f;
   __syncthreads();
-  for (int i = threadIdx.x; i < NRED * CW; i += 256) {
-    const int r = i / CW, cl = i - r * CW;
+  const int CW = CVB * CH;
+  for (int o = tid; o < NRED * CW; o += 256) {
+    const int r = o / CW, cl = o - r * CW;
+    const int cvl = cl / CH, i = cl - cvl * CH;
+    const float* src = red + (r * CH + i) * 256 + cvl;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int p = 0;
+    for (; p + 4 <= P; p += 4) {
+      s0 += src[p * CVB];
+      s1 += src[(p + 1) * CVB];
+      s2 += src[(p + 2) * CVB];
+      s3 += src[(p + 3) * CVB];
+    }
+    for (; p < P; ++p) s0 += src[p * CVB];
     const int c = cbase + cl;
-    if (c < C) atomicAdd(out[r] + c, red[i]);
+    if (c < C) out[r][c] = (s0 + s1) + (s2 + s3);
   }
 }
 
@@ -116,7 +128,6 @@ struct EwArgs {
   RowMap map;
 };
 
-constexpr int RED_MAX = 2 * 32 * 8;
 
 // MODE 0: chan_stats   sums += (sum a, sum a^2)
 // MODE 1: affine_act   out = act(a*scale+shift)*row_scale ; optional sums of out
@@ -124,7 +135,7 @@ constexpr int RED_MAX = 2 * 32 * 8;
 // MODE 3: affine2      out = cA*a + cB*b + cC
 template <typename T, int CH, int MODE>
 __global__ __launch_bounds__(256) void ew_kernel(EwArgs a) {
-  __shared__ float red[RED_MAX];
+  __shared__ float red[(MODE == 3 || MODE == 4) ? 1 : 2 * CH * 256];
   const int tid = threadIdx.x;
   const RowMap& mp = a.map;
   const int cvl = tid % mp.CVB, p = tid / mp.CVB;
@@ -133,10 +144,6 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs a) {
   const int c0 = cv * CH;
   const int CW = mp.CVB * CH;
   const bool want_sums = a.sums != nullptr;
-  if (want_sums) {
-    for (int i = tid; i < 2 * CW; i += 256) red[i] = 0.f;
-    __syncthreads();
-  }
   float acc[2][CH];
   float sc[CH], sh[CH], mu[CH], rs[CH], kA[CH], kB[CH], kC[CH];
 #pragma unroll
@@ -268,9 +275,9 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs a) {
   }
   if constexpr (MODE != 3 && MODE != 4) {
     if (want_sums) {
-      float* rep = a.sums + (size_t)((blockIdx.x + blockIdx.y) % PB_STAT_REPLICAS) * 2 * a.C;
+      float* rep = a.sums + (size_t)blockIdx.x * 2 * a.C;      // slot = row-range index (gridDim.x <= PB_STAT_SLOTS)
       float* const outs[2] = {rep, rep + a.C};
-      block_chan_reduce<CH, 2>(red, acc, lane_ok, cvl, CW, blockIdx.y * CW, a.C, outs);
+      block_chan_reduce<CH, 2>(red, acc, lane_ok, mp.CVB, mp.P, blockIdx.y * CW, a.C, outs);
     }
   }
 }
@@ -281,7 +288,7 @@ int launch_ew(EwArgs a, hipStream_t st) {
   const bool vec = (a.C % VEC) == 0;
   a.map = vec ? make_map<VEC>(a.C) : make_map<1>(a.C);
   // >= 4 rows per thread; reducing launches stay <= ~512 workgroups per channel chunk so that, with the
-  // 16 stats replicas, an address sees <= 32 same-address atomics
+  // every workgroup owns one statistics slot (PB_STAT_SLOTS of them)
   PB_CHECK_ARG(a.M < 0x7fffffffLL, "elementwise kernels: M must fit 31 bits");
   // as many workgroups as there are row groups, up to the cap: small tensors (the 7x7 / 14x14 stages) were
   // running 1 workgroup per CU with 8 dependent rows per thread - latency-bound at ~1 TB/s
@@ -291,7 +298,7 @@ int launch_ew(EwArgs a, hipStream_t st) {
     gx = pb_cdiv(a.M, (int64_t)a.map.P);                      // small tensor: spread it over ~1024 workgroups
     if (gx * a.map.chunks > 1024) gx = pb_cdiv(1024, a.map.chunks);
   }
-  const int64_t cap = a.sums ? 512 : pb_cdiv(8192, a.map.chunks);
+  const int64_t cap = a.sums ? PB_STAT_SLOTS : pb_cdiv(8192, a.map.chunks);
   if (gx > cap) gx = cap;
   if (gx < 1) gx = 1;
   dim3 grid((unsigned)gx, (unsigned)a.map.chunks);
@@ -309,7 +316,7 @@ int launch_ew_dt(const EwArgs& a, pb_dtype dtype, hipStream_t st) {
 struct RgArgs {
   const void* a;
   const void* b;
-  float* out;
+  float* out;          // partial sums [gridDim.x][G][C] (gridDim.x == 1: the result itself)
   int64_t R;
   int C;
   RowMap map;
@@ -317,7 +324,7 @@ struct RgArgs {
 
 template <typename T, int CH>
 __global__ __launch_bounds__(256) void rowgroup_kernel(RgArgs a) {
-  __shared__ float red[32 * 8];
+  __shared__ float red[CH * 256];
   const int tid = threadIdx.x;
   const RowMap& mp = a.map;
   const int cvl = tid % mp.CVB, p = tid / mp.CVB;
@@ -325,8 +332,6 @@ __global__ __launch_bounds__(256) void rowgroup_kernel(RgArgs a) {
   const bool lane_ok = p < mp.P && cv < mp.CV;
   const int c0 = cv * CH, CW = mp.CVB * CH;
   const int64_t g = blockIdx.z;
-  for (int i = tid; i < CW; i += 256) red[i] = 0.f;
-  __syncthreads();
   float acc[1][CH];
 #pragma unroll
   for (int i = 0; i < CH; ++i) acc[0][i] = 0.f;
@@ -361,25 +366,49 @@ __global__ __launch_bounds__(256) void rowgroup_kernel(RgArgs a) {
       }
     }
   }
-  float* const outs[1] = {a.out + g * a.C};
-  block_chan_reduce<CH, 1>(red, acc, lane_ok, cvl, CW, blockIdx.y * CW, a.C, outs);
+  float* const outs[1] = {a.out + ((int64_t)blockIdx.x * gridDim.z + g) * a.C};
+  block_chan_reduce<CH, 1>(red, acc, lane_ok, mp.CVB, mp.P, blockIdx.y * CW, a.C, outs);
 }
 
-__global__ void bn_finalize_kernel(const float* stats, double count, const float* gamma, const float* beta,
-                                   float eps, float momentum, float* running_mean, float* running_var,
-                                   int use_running, float* scale, float* shift, float* mean_o, float* rstd_o, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// Sum of the PB_STAT_SLOTS slots of one [slot][2][C] statistics buffer for the 32 channels of this workgroup:
+// thread (cl, sg) adds the slots sg, sg+8, ... in double, the eight groups are combined through LDS in index order.
+__device__ __forceinline__ void slot_sums(const float* stats, int C, int c0, double (*red)[2][32], double& s1, double& s2) {
+  const int cl = threadIdx.x & 31, sg = threadIdx.x >> 5;
+  const int c = c0 + cl;
+  double a1 = 0, a2 = 0;
+  if (c < C) {
+    for (int r = sg; r < PB_STAT_SLOTS; r += 8) {
+      a1 += stats[(size_t)r * 2 * C + c];
+      a2 += stats[(size_t)r * 2 * C + C + c];
+    }
+  }
+  red[sg][0][cl] = a1;
+  red[sg][1][cl] = a2;
+  __syncthreads();
+  s1 = s2 = 0;
+  if (sg == 0) {
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      s1 += red[g][0][cl];
+      s2 += red[g][1][cl];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* stats, double count, const float* gamma, const float* beta,
+                                                          float eps, float momentum, float* running_mean, float* running_var,
+                                                          int64_t* num_batches_tracked, int use_running, float* scale,
+                                                          float* shift, float* mean_o, float* rstd_o, int C) {
+  __shared__ double red[8][2][32];
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+  double s1 = 0, s2 = 0;
+  if (!use_running) slot_sums(stats, C, blockIdx.x * 32, red, s1, s2);
+  if (threadIdx.x >= 32 || c >= C) return;
   double mean, var;
   if (use_running) {
     mean = running_mean[c];
     var = running_var[c];
   } else {
-    double s1 = 0, s2 = 0;
-    for (int r = 0; r < PB_STAT_REPLICAS; ++r) {
-      s1 += stats[(size_t)r * 2 * C + c];
-      s2 += stats[(size_t)r * 2 * C + C + c];
-    }
     mean = s1 / count;
     var = s2 / count - mean * mean;
     if (var < 0) var = 0;
@@ -388,6 +417,7 @@ __global__ void bn_finalize_kernel(const float* stats, double count, const float
       const double unb = count > 1 ? var * count / (count - 1) : var;
       running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
     }
+    if (num_batches_tracked && c == 0) *num_batches_tracked += 1;        // nn.BatchNorm's step counter (train mode)
   }
   const double rstd = 1.0 / sqrt(var + (double)eps);
   const double g = gamma ? gamma[c] : 1.0, b = beta ? beta[c] : 0.0;
@@ -397,16 +427,14 @@ __global__ void bn_finalize_kernel(const float* stats, double count, const float
   if (rstd_o) rstd_o[c] = (float)rstd;
 }
 
-__global__ void bn_bwd_finalize_kernel(const float* sums, double count, const float* gamma, const float* mean,
-                                       const float* rstd, int training, float* cA, float* cB, float* cC,
-                                       float* dgamma, float* dbeta, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* sums, double count, const float* gamma, const float* mean,
+                                                              const float* rstd, int training, float* cA, float* cB, float* cC,
+                                                              float* dgamma, float* dbeta, int C) {
+  __shared__ double red[8][2][32];
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31);
   double sg = 0, sgx = 0;
-  for (int r = 0; r < PB_STAT_REPLICAS; ++r) {
-    sg += sums[(size_t)r * 2 * C + c];
-    sgx += sums[(size_t)r * 2 * C + C + c];
-  }
+  slot_sums(sums, C, blockIdx.x * 32, red, sg, sgx);
+  if (threadIdx.x >= 32 || c >= C) return;
   const double g = gamma ? gamma[c] : 1.0, r = rstd[c];
   if (training) {
     // dz = A*g + B*(z - mean) + C: the mean is subtracted from z in the consumer, never folded into C
@@ -451,15 +479,16 @@ extern "C" int pb_chan_stats(const void* x, int64_t M, int C, pb_dtype dtype, fl
 }
 
 extern "C" int pb_bn_finalize(const float* stats, double count, const float* gamma, const float* beta, float eps,
-                              float momentum, float* running_mean, float* running_var, int use_running,
-                              float* scale, float* shift, float* mean, float* rstd, int C, int device, void* stream) {
+                              float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                              int use_running, float* scale, float* shift, float* mean, float* rstd, int C, int device,
+                              void* stream) {
   PB_CHECK_ARG(scale && shift && C > 0, "pb_bn_finalize: null output / bad C");
   PB_CHECK_ARG(use_running ? (running_mean && running_var) : (stats && count > 0),
                "pb_bn_finalize: missing statistics (use_running=%d)", use_running);
   PB_ENTER(device);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)pb_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, stats,
-                     count, gamma, beta, eps, momentum, running_mean, running_var, use_running, scale, shift, mean,
-                     rstd, C);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)pb_cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, stats,
+                     count, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, use_running, scale,
+                     shift, mean, rstd, C);
   PB_LAUNCH_CHECK();
   return 0;
 }
@@ -506,7 +535,7 @@ extern "C" int pb_bn_bwd_finalize(const float* sums, double count, const float* 
                                   float* dgamma, float* dbeta, int C, int device, void* stream) {
   PB_CHECK_ARG(sums && mean && rstd && coefA && coefB && coefC && C > 0 && count > 0, "pb_bn_bwd_finalize: bad args");
   PB_ENTER(device);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)pb_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)pb_cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream,
                      sums, count, gamma, mean, rstd, training, coefA, coefB, coefC, dgamma, dbeta, C);
   PB_LAUNCH_CHECK();
   return 0;
@@ -534,21 +563,41 @@ extern "C" int pb_affine2(const void* g, const void* z, void* out, int64_t M, in
   return 0;
 }
 
+namespace {
+// row-group reduction plan: gx workgroups along the rows of a group, each writing one partial row
+int64_t rowgroup_gx(int64_t G, int64_t rows_per_group, int C, pb_dtype dtype, RowMap* map_out) {
+  const int vec = dtype == PB_BF16 ? 8 : 4;
+  const bool v = (C % vec) == 0;
+  const RowMap map = v ? (vec == 8 ? make_map<8>(C) : make_map<4>(C)) : make_map<1>(C);
+  int64_t gx = pb_cdiv(rows_per_group, map.P);
+  const int64_t cap = pb_cdiv(2048, (int64_t)map.chunks * G);
+  if (gx > cap) gx = cap;
+  if (gx < 1) gx = 1;
+  if (map_out) *map_out = map;
+  return gx;
+}
+}  // namespace
+
+extern "C" int64_t pb_rowgroup_reduce_ws_bytes(int64_t G, int64_t rows_per_group, int C, pb_dtype dtype) {
+  if (G <= 0 || rows_per_group <= 0 || C <= 0) return 0;
+  const int64_t gx = rowgroup_gx(G, rows_per_group, C, dtype, nullptr);
+  return gx > 1 ? gx * G * C * 4 : 0;
+}
+
 extern "C" int pb_rowgroup_reduce(const void* a_, const void* b_, float* out, int64_t G, int64_t rows_per_group,
-                                  int C, pb_dtype dtype, int device, void* stream) {
+                                  int C, pb_dtype dtype, void* ws, int64_t ws_bytes, int device, void* stream) {
   PB_CHECK_ARG(a_ && out, "pb_rowgroup_reduce: null pointer");
   PB_CHECK_ARG(G > 0 && G <= 65535 && rows_per_group > 0 && C > 0, "pb_rowgroup_reduce: bad sizes");
   PB_CHECK_ARG(dtype == PB_F32 || dtype == PB_BF16, "pb_rowgroup_reduce: bad dtype");
   PB_ENTER(device);
   RgArgs a;
-  a.a = a_; a.b = b_; a.out = out; a.R = rows_per_group; a.C = C;
+  a.a = a_; a.b = b_; a.R = rows_per_group; a.C = C;
   const int vec = dtype == PB_BF16 ? 8 : 4;
   const bool v = (C % vec) == 0;
-  a.map = v ? (vec == 8 ? make_map<8>(C) : make_map<4>(C)) : make_map<1>(C);
-  int64_t gx = pb_cdiv(rows_per_group, a.map.P);
-  const int64_t cap = pb_cdiv(2048, (int64_t)a.map.chunks * G);
-  if (gx > cap) gx = cap;
-  if (gx < 1) gx = 1;
+  const int64_t gx = rowgroup_gx(G, rows_per_group, C, dtype, &a.map);
+  PB_CHECK_ARG(gx == 1 || (ws && ws_bytes >= gx * G * C * 4), "pb_rowgroup_reduce: workspace of %lld bytes needed",
+               (long long)(gx * G * C * 4));
+  a.out = gx == 1 ? out : (float*)ws;
   dim3 grid((unsigned)gx, (unsigned)a.map.chunks, (unsigned)G);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == PB_BF16) {
@@ -559,6 +608,10 @@ extern "C" int pb_rowgroup_reduce(const void* a_, const void* b_, float* out, in
     else hipLaunchKernelGGL((rowgroup_kernel<float, 1>), grid, dim3(256), 0, st, a);
   }
   PB_LAUNCH_CHECK();
+  if (gx > 1) {
+    pb_reduce_job job = {(const float*)ws, out, G * C, G * C, (int)gx, 0};
+    if (pb_launch_partials_reduce(&job, 1, st)) { pb_set_error("pb_rowgroup_reduce: combine launch failed"); return 2; }
+  }
   return 0;
 }
 

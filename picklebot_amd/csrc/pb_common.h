@@ -34,6 +34,9 @@ void pb_set_error(const char* fmt, ...);
 
 static inline int64_t pb_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// fixed-order reduction of partial results (reduce.hip); 0 on success
+__attribute__((visibility("hidden"))) int pb_launch_partials_reduce(const pb_reduce_job* jobs, int count, hipStream_t st);
+
 // ----------------------------------------------------------------------------- device side
 typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;

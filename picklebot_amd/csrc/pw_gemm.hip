@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
       csum[j] = csq[j] = 0.f;
     }
     __syncthreads();
-    float* st = a.stats + (size_t)(blockIdx.x % PB_STAT_REPLICAS) * 2 * a.N;
+    float* st = a.stats + (size_t)blockIdx.x * 2 * a.N;      // this workgroup's own slot (grid <= PB_STAT_SLOTS): plain read-modify-write
     for (int c = tid; c < BN; c += 256) {
       const int n = n0 + c;
       if (n < a.N) {
@@ -388,8 +388,8 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
           s += sred[(w * BN + c) * 2 + 0];
           q += sred[(w * BN + c) * 2 + 1];
         }
-        atomicAdd(st + n, s);
-        atomicAdd(st + a.N + n, q);
+        st[n] += s;
+        st[a.N + n] += q;
       }
     }
     __syncthreads();
@@ -573,7 +573,7 @@ struct WgArgs {
 // bf16 fragments come from ds_read_b64_tr_b16 (the hardware transposing read), f32 from plain
 // 4-byte reads.  No workgroup barrier in the loop (waves are independent); the next block's global
 // loads are issued before the current block's MFMAs.  At the end the four waves' tiles are summed
-// in LDS and added to dW with contiguous float atomics (one writer per workgroup and address).
+// in LDS (wave order) and stored as this row range's partial tile of the workspace a.P[range][N][K].
 template <typename T, int TNW, int TKW, bool CONV = false>
 __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgArgs a) {
   constexpr int VEC = ElemTraits<T>::VEC;
@@ -733,9 +733,10 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgArgs a) {
   }
   const int64_t ldw = CONV ? (int64_t)a.ckt * a.ckh * a.ckw * a.K : a.K;
   const int64_t woff = CONV ? (int64_t)blockIdx.z * a.K : 0;
+  // this row range's partial tile (plain stores; the ranges are added up in a fixed order afterwards)
   for (int e = tid; e < TN * TK; e += 256) {
     const int n = n0 + e / TK, k = k0 + e % TK;
-    if (n < a.N && k < a.K) atomicAdd(a.dW + (int64_t)n * ldw + woff + k, R[e]);
+    if (n < a.N && k < a.K) a.P[((int64_t)blockIdx.y * a.N + n) * ldw + woff + k] = R[e];
   }
 }
 
@@ -862,7 +863,8 @@ __global__ __launch_bounds__(256) void pw_wgrad128_kernel(WgArgs a) {
     }
     buf ^= 1;
   }
-  // quadrants are disjoint: each wave adds its own 64 x 64 block (row = n = (lane>>4)*4 + r, col = k = lane & 15)
+  // quadrants are disjoint: each wave stores its own 64 x 64 block of the range's partial tile (row = n = (lane>>4)*4 + r,
+  // col = k = lane & 15)
   const int64_t ldw = CONV ? (int64_t)a.ckt * a.ckh * a.ckw * a.K : a.K;
   const int64_t woff = CONV ? (int64_t)blockIdx.z * a.K : 0;
   float sk[4] = {1.f, 1.f, 1.f, 1.f};
@@ -881,7 +883,7 @@ __global__ __launch_bounds__(256) void pw_wgrad128_kernel(WgArgs a) {
       for (int r = 0; r < 4; ++r) {
         const int n = n0 + wn * 64 + i * 16 + (lane >> 4) * 4 + r;
         const int k = k0 + wk * 64 + j * 16 + (lane & 15);
-        if (n < a.N && k < a.K) atomicAdd(a.dW + (int64_t)n * ldw + woff + k, acc[i][j][r] * sk[j]);
+        if (n < a.N && k < a.K) a.P[((int64_t)srange * a.N + n) * ldw + woff + k] = acc[i][j][r] * sk[j];
       }
 }
 
@@ -1211,44 +1213,15 @@ __global__ __launch_bounds__(256) void pw_wgrad128_dma_kernel(WgArgs a) {
         const int n = n0 + wn * 64 + i * 16 + (lane >> 4) * 4 + r;
         const int k = k0 + wk * 64 + j * 16 + (lane & 15);
         if (n < a.N && k < a.K) {
-          // a CU retires float atomics at ~1 per clock: 16 K of them per workgroup cost 25-30 us whatever the layer
-          // (measured: 39 -> 11 us without them at M = 8192).  With a workspace every range stores its partial
-          // tile (64-byte runs, plain stores) and pw_wgrad_reduce_kernel adds the ranges up.
+          // every range stores its partial tile (64-byte runs, plain stores) and the ranges are added up afterwards in a
+          // fixed order: no atomics (a CU retires float atomics at ~1 per clock - 16 K of them per workgroup cost
+          // 25-30 us whatever the layer, measured 39 -> 11 us without them at M = 8192 - and their order is not
+          // reproducible)
           const int64_t ldw = CONV ? (int64_t)a.ckt * a.ckh * a.ckw * a.K : a.K;      // dW is [N][taps][K] for CONV
           const int64_t col = (CONV ? (int64_t)tap * a.K : 0) + k;
-          if (a.P) a.P[((int64_t)srange * a.N + n) * ldw + col] = acc[i][j][r] * sk[j];
-          else atomicAdd(a.dW + (int64_t)n * ldw + col, acc[i][j][r] * sk[j]);
+          a.P[((int64_t)srange * a.N + n) * ldw + col] = acc[i][j][r] * sk[j];
         }
       }
-}
-
-// dW[e] += sum over the row ranges of P[s][e].  A workgroup = 32 float4 columns x 8 range groups (N*K/4 columns alone
-// are ~100 workgroups of serial loops: measured 13 us per launch), combined through LDS.
-__global__ __launch_bounds__(256) void pw_wgrad_reduce_kernel(const float* P, float* dW, int64_t nk4, int split) {
-  __shared__ f32x4 red[8][32];
-  const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
-  const int64_t e = (int64_t)blockIdx.x * 32 + col;
-  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
-  if (e < nk4) {
-    const f32x4* p = reinterpret_cast<const f32x4*>(P) + e;
-    int i = grp;
-    for (; i + 24 < split; i += 32) {
-      s0 += p[(int64_t)i * nk4];
-      s1 += p[(int64_t)(i + 8) * nk4];
-      s2 += p[(int64_t)(i + 16) * nk4];
-      s3 += p[(int64_t)(i + 24) * nk4];
-    }
-    for (; i < split; i += 8) s0 += p[(int64_t)i * nk4];
-  }
-  red[grp][col] = (s0 + s1) + (s2 + s3);
-  __syncthreads();
-  if (grp == 0 && e < nk4) {
-    f32x4 t = red[0][col];
-#pragma unroll
-    for (int g = 1; g < 8; ++g) t += red[g][col];
-    f32x4* o = reinterpret_cast<f32x4*>(dW) + e;
-    *o = *o + t;
-  }
 }
 
 int pick_nt(int N, bool f32) {
@@ -1284,6 +1257,7 @@ void launch_one(const PwArgs& a, int64_t total, int device, hipStream_t st) {
   int64_t blocks = cached[d];
   if (blocks > total) blocks = total;
   blocks = pb_cdiv(blocks, 8) * 8;
+  if (a.stats && blocks > PB_STAT_SLOTS) blocks = PB_STAT_SLOTS;   // one statistics slot per workgroup
   hipLaunchKernelGGL((pw_gemm_kernel<T, NT, TRANS, ALIGNED, PRO>), dim3((unsigned)blocks), dim3(256), 0, st, a);
 }
 
@@ -1431,86 +1405,102 @@ bool wgrad_is_big(int K, int N, pb_dtype dtype) {
 
 }  // namespace
 
-extern "C" int64_t pb_pwconv_bwd_weight_ws_bytes(int64_t M, int K, int N, pb_dtype dtype, int has_affine, int has_row_scale,
-                                                 int64_t rows_per_group, int device) {
-  static const bool ws_on = !(getenv("PB_WGRAD_WS") && atoi(getenv("PB_WGRAD_WS")) == 0);
-  if (!ws_on || M <= 0 || K <= 0 || N <= 0 || !wgrad_is_big(K, N, dtype)) return 0;
-  const WgPlan p = wgrad128_plan(M, K, N, has_row_scale != 0, has_affine != 0, rows_per_group > 0 ? rows_per_group : 1, true, device);
-  return p.dma ? p.split * (int64_t)N * K * 4 : 0;
-}
-
-extern "C" int pb_pwconv_bwd_weight_ws(const void* dy, const void* x, float* dw, int64_t M, int K, int N,
-                                       pb_dtype dtype, const float* in_scale, const float* in_shift, pb_act in_act,
-                                       float in_slope, const float* row_scale, int64_t rows_per_group, void* ws,
-                                       int64_t ws_bytes, int device, void* stream) {
-  PB_CHECK_ARG(dy && x && dw, "pb_pwconv_bwd_weight: null pointer");
-  PB_CHECK_ARG(M >= 0 && K > 0 && N > 0, "pb_pwconv_bwd_weight: bad sizes");
-  PB_CHECK_ARG(dtype == PB_F32 || dtype == PB_BF16, "pb_pwconv_bwd_weight: bad dtype %d", (int)dtype);
-  PB_CHECK_ARG(!row_scale || rows_per_group > 0, "pb_pwconv_bwd_weight: row_scale needs rows_per_group > 0");
-  PB_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0, "pb_pwconv_bwd_weight: unaligned pointer");
-  PB_CHECK_ARG(!ws || ((uintptr_t)ws % 16) == 0, "pb_pwconv_bwd_weight: unaligned workspace");
-  if (M == 0) return 0;
-  PB_ENTER(device);
-  WgArgs a;
-  a.P = nullptr;
-  a.dY = dy; a.X = x; a.dW = dw; a.M = M; a.K = K; a.N = N;
-  a.in_scale = in_scale; a.in_shift = in_shift; a.in_act = (int)in_act; a.in_slope = in_slope;
-  a.row_scale = row_scale; a.rows_per_group = rows_per_group > 0 ? rows_per_group : 1;
-  const bool big = wgrad_is_big(K, N, dtype);
-  if (big) {
-    const bool affine = in_scale || in_shift || in_act != PB_ACT_NONE;
-    WgPlan p = wgrad128_plan(M, K, N, row_scale != nullptr, affine, a.rows_per_group, ws != nullptr, device);
-    if (ws && !(p.dma && ws_bytes >= p.split * (int64_t)N * K * 4 && ((uintptr_t)dw % 16) == 0)) {
-      ws = nullptr;                                   // no use for it (or too small): atomic epilogue
-      p = wgrad128_plan(M, K, N, row_scale != nullptr, affine, a.rows_per_group, false, device);
-    }
-    a.n_tiles = p.n_tiles; a.k_tiles = p.k_tiles;
-    const int64_t tiles128 = (int64_t)a.n_tiles * a.k_tiles;
-    a.rows_per_wg = p.rows_per_wg;
-    a.ranges_per_group = p.ranges_per_group;
-    a.split = (int)p.split;
-    const int ns = p.ns;
-    const dim3 grid((unsigned)(tiles128 * 8 * pb_cdiv(p.split, 8)));
-    if (p.dma) {
-      a.P = (float*)ws;
-      static bool attr_done = false;
-      if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)pw_wgrad128_dma_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 16384);
-        attr_done = true;
-      }
-      if (ns == 6) hipLaunchKernelGGL((pw_wgrad128_dma_kernel<6>), grid, dim3(256), 6 * 16384, (hipStream_t)stream, a);
-      else if (ns == 4) hipLaunchKernelGGL((pw_wgrad128_dma_kernel<4>), grid, dim3(256), 4 * 16384, (hipStream_t)stream, a);
-      else hipLaunchKernelGGL((pw_wgrad128_dma_kernel<3>), grid, dim3(256), 3 * 16384, (hipStream_t)stream, a);
-      if (a.P) {
-        const int64_t nk4 = (int64_t)N * K / 4;
-        hipLaunchKernelGGL(pw_wgrad_reduce_kernel, dim3((unsigned)pb_cdiv(nk4, 32)), dim3(256), 0, (hipStream_t)stream, a.P, dw,
-                           nk4, a.split);
-      }
-    } else {
-      hipLaunchKernelGGL((pw_wgrad128_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, a);
-    }
-    PB_LAUNCH_CHECK();
-    return 0;
-  }
-  const int tile = dtype == PB_BF16 ? 64 : 32;
-  a.n_tiles = (int)pb_cdiv(N, tile);
-  a.k_tiles = (int)pb_cdiv(K, tile);
-  const int64_t tiles = (int64_t)a.n_tiles * a.k_tiles;
-  // ~1024 workgroups (4 per CU is what the 36 KB of LDS admits); every workgroup is one atomic writer
-  // per address of its tile, so the M split is also capped for the atomics' sake
+namespace {
+// launch plan of the 64x64 (bf16) / 32x32 (fp32) tile kernel for small N, K
+struct WgSmallPlan {
+  int tile, n_tiles, k_tiles;
+  int64_t msplit, rows_per_wg;
+};
+WgSmallPlan wgrad_small_plan(int64_t M, int K, int N, pb_dtype dtype) {
+  WgSmallPlan p;
+  p.tile = dtype == PB_BF16 ? 64 : 32;
+  p.n_tiles = (int)pb_cdiv(N, p.tile);
+  p.k_tiles = (int)pb_cdiv(K, p.tile);
+  const int64_t tiles = (int64_t)p.n_tiles * p.k_tiles;
+  // ~512 workgroups (4 per CU is what the 36 KB of LDS admits), each writing one partial tile
   static const int small_wgs = getenv("PB_WGRAD_SMALL_WGS") ? atoi(getenv("PB_WGRAD_SMALL_WGS")) : 512;
   int64_t msplit = pb_cdiv(small_wgs, tiles);
   const int64_t max_split = pb_cdiv(M, 128);
   if (msplit > max_split) msplit = max_split;
   if (msplit > 65535) msplit = 65535;
-  a.rows_per_wg = pb_cdiv(pb_cdiv(M, msplit), 128) * 128;
-  msplit = pb_cdiv(M, a.rows_per_wg);
-  dim3 grid((unsigned)tiles, (unsigned)msplit), block(256);
-  if (dtype == PB_BF16)
-    hipLaunchKernelGGL((pw_wgrad_kernel<bf16_t, 4, 4>), grid, block, 0, (hipStream_t)stream, a);
-  else
-    hipLaunchKernelGGL((pw_wgrad_kernel<float, 2, 2>), grid, block, 0, (hipStream_t)stream, a);
+  if (msplit < 1) msplit = 1;
+  p.rows_per_wg = pb_cdiv(pb_cdiv(M, msplit), 128) * 128;
+  p.msplit = pb_cdiv(M, p.rows_per_wg);
+  return p;
+}
+}  // namespace
+
+extern "C" int64_t pb_pwconv_bwd_weight_ws_bytes(int64_t M, int K, int N, pb_dtype dtype, int has_affine, int has_row_scale,
+                                                 int64_t rows_per_group, int device) {
+  if (M <= 0 || K <= 0 || N <= 0) return 0;
+  if (wgrad_is_big(K, N, dtype)) {
+    const WgPlan p = wgrad128_plan(M, K, N, has_row_scale != 0, has_affine != 0, rows_per_group > 0 ? rows_per_group : 1, true, device);
+    return p.split * (int64_t)N * K * 4;
+  }
+  return wgrad_small_plan(M, K, N, dtype).msplit * (int64_t)N * K * 4;
+}
+
+extern "C" int pb_pwconv_bwd_weight_ws(const void* dy, const void* x, float* dw, int64_t M, int K, int N,
+                                       pb_dtype dtype, const float* in_scale, const float* in_shift, pb_act in_act,
+                                       float in_slope, const float* row_scale, int64_t rows_per_group, void* ws,
+                                       int64_t ws_bytes, pb_reduce_job* deferred, int device, void* stream) {
+  PB_CHECK_ARG(dy && x && dw, "pb_pwconv_bwd_weight: null pointer");
+  PB_CHECK_ARG(M >= 0 && K > 0 && N > 0, "pb_pwconv_bwd_weight: bad sizes");
+  PB_CHECK_ARG(dtype == PB_F32 || dtype == PB_BF16, "pb_pwconv_bwd_weight: bad dtype %d", (int)dtype);
+  PB_CHECK_ARG(!row_scale || rows_per_group > 0, "pb_pwconv_bwd_weight: row_scale needs rows_per_group > 0");
+  PB_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0, "pb_pwconv_bwd_weight: unaligned pointer");
+  if (deferred) *deferred = pb_reduce_job{nullptr, dw, 0, 0, 0, 1};
+  if (M == 0) return 0;
+  const bool affine = in_scale || in_shift || in_act != PB_ACT_NONE;
+  const int64_t need = pb_pwconv_bwd_weight_ws_bytes(M, K, N, dtype, affine, row_scale != nullptr, rows_per_group, device);
+  PB_CHECK_ARG(ws && ((uintptr_t)ws % 16) == 0 && ws_bytes >= need, "pb_pwconv_bwd_weight: workspace of %lld bytes needed (16-byte aligned)",
+               (long long)need);
+  PB_ENTER(device);
+  WgArgs a;
+  a.P = (float*)ws;
+  a.dY = dy; a.X = x; a.dW = dw; a.M = M; a.K = K; a.N = N;
+  a.in_scale = in_scale; a.in_shift = in_shift; a.in_act = (int)in_act; a.in_slope = in_slope;
+  a.row_scale = row_scale; a.rows_per_group = rows_per_group > 0 ? rows_per_group : 1;
+  int64_t nsplit;
+  if (wgrad_is_big(K, N, dtype)) {
+    const WgPlan p = wgrad128_plan(M, K, N, row_scale != nullptr, affine, a.rows_per_group, true, device);
+    a.n_tiles = p.n_tiles; a.k_tiles = p.k_tiles;
+    const int64_t tiles128 = (int64_t)a.n_tiles * a.k_tiles;
+    a.rows_per_wg = p.rows_per_wg;
+    a.ranges_per_group = p.ranges_per_group;
+    a.split = (int)p.split;
+    nsplit = p.split;
+    const int ns = p.ns;
+    const dim3 grid((unsigned)(tiles128 * 8 * pb_cdiv(p.split, 8)));
+    if (p.dma) {
+      static bool attr_done[16] = {false};
+      if (!attr_done[device & 15]) {
+        PB_HIP(hipFuncSetAttribute((const void*)pw_wgrad128_dma_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 16384));
+        PB_HIP(hipFuncSetAttribute((const void*)pw_wgrad128_dma_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 16384));
+        attr_done[device & 15] = true;
+      }
+      if (ns == 6) hipLaunchKernelGGL((pw_wgrad128_dma_kernel<6>), grid, dim3(256), 6 * 16384, (hipStream_t)stream, a);
+      else if (ns == 4) hipLaunchKernelGGL((pw_wgrad128_dma_kernel<4>), grid, dim3(256), 4 * 16384, (hipStream_t)stream, a);
+      else hipLaunchKernelGGL((pw_wgrad128_dma_kernel<3>), grid, dim3(256), 3 * 16384, (hipStream_t)stream, a);
+    } else {
+      hipLaunchKernelGGL((pw_wgrad128_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    }
+  } else {
+    const WgSmallPlan p = wgrad_small_plan(M, K, N, dtype);
+    a.n_tiles = p.n_tiles; a.k_tiles = p.k_tiles; a.rows_per_wg = p.rows_per_wg;
+    a.ranges_per_group = 0; a.split = (int)p.msplit;
+    nsplit = p.msplit;
+    dim3 grid((unsigned)(p.n_tiles * p.k_tiles), (unsigned)p.msplit), block(256);
+    if (dtype == PB_BF16)
+      hipLaunchKernelGGL((pw_wgrad_kernel<bf16_t, 4, 4>), grid, block, 0, (hipStream_t)stream, a);
+    else
+      hipLaunchKernelGGL((pw_wgrad_kernel<float, 2, 2>), grid, block, 0, (hipStream_t)stream, a);
+  }
   PB_LAUNCH_CHECK();
+  // dw += sum of the row ranges' partial tiles, in range order
+  const pb_reduce_job job = {(const float*)ws, dw, (int64_t)N * K, (int64_t)N * K, (int)nsplit, 1};
+  if (deferred) { *deferred = job; return 0; }
+  if (pb_launch_partials_reduce(&job, 1, (hipStream_t)stream)) { pb_set_error("pb_pwconv_bwd_weight: combine launch failed"); return 2; }
   return 0;
 }
 
@@ -1551,6 +1541,7 @@ void launch_conv_nt(const PwArgs& a, int64_t total, int device, hipStream_t st) 
   int64_t blocks = cached[d];
   if (blocks > total) blocks = total;
   blocks = pb_cdiv(blocks, 8) * 8;
+  if (a.stats && blocks > PB_STAT_SLOTS) blocks = PB_STAT_SLOTS;   // one statistics slot per workgroup
   hipLaunchKernelGGL((pw_gemm_kernel<T, NT, false, true, false, true>), dim3((unsigned)blocks), dim3(256), 0, st, a);
 }
 
@@ -1626,94 +1617,64 @@ extern "C" int pb_conv3d_fwd(const void* x, const float* wp, void* y, const pb_c
   return 0;
 }
 
-extern "C" int pb_conv3d_bwd_weight(const void* dy, const void* x, float* dwp, const pb_conv_shape* s, pb_dtype dtype,
-                                    int device, void* stream) {
-  PB_CHECK_ARG(dy && x && dwp, "pb_conv3d_bwd_weight: null pointer");
-  if (int rc = check_conv(s, dtype, "pb_conv3d_bwd_weight")) return rc;
-  PB_ENTER(device);
-  WgArgs a = {};
-  a.dY = dy; a.X = x; a.dW = dwp;
-  a.M = (int64_t)s->N * s->To * s->Ho * s->Wo;
-  a.K = s->Cin; a.N = s->Cout; a.rows_per_group = 1;
-  a.cTi = s->Ti; a.cHi = s->Hi; a.cWi = s->Wi; a.cTo = s->To; a.cHo = s->Ho; a.cWo = s->Wo;
-  a.ckt = s->kt; a.ckh = s->kh; a.ckw = s->kw; a.cst = s->st; a.csh = s->sh; a.csw = s->sw;
-  a.cpt = s->pt; a.cph = s->ph; a.cpw = s->pw;
-  const int taps = s->kt * s->kh * s->kw;
-  const int tile = dtype == PB_BF16 ? 64 : 32;
-  a.n_tiles = (int)pb_cdiv(a.N, tile);
-  a.k_tiles = (int)pb_cdiv(a.K, tile);
-  const int64_t tiles = (int64_t)a.n_tiles * a.k_tiles;
-  int64_t msplit = pb_cdiv(2048, tiles * taps);
-  const int64_t max_split = pb_cdiv(a.M, 128);
-  if (msplit > max_split) msplit = max_split;
-  if (msplit < 1) msplit = 1;
-  a.rows_per_wg = pb_cdiv(pb_cdiv(a.M, msplit), 128) * 128;
-  msplit = pb_cdiv(a.M, a.rows_per_wg);
-  PB_CHECK_ARG(taps <= 65535 && msplit <= 65535, "pb_conv3d_bwd_weight: grid too large");
-  dim3 grid((unsigned)tiles, (unsigned)msplit, (unsigned)taps), block(256);
-  if (dtype == PB_BF16) {
-    a.n_tiles = (int)pb_cdiv(a.N, 128);
-    a.k_tiles = (int)pb_cdiv(a.K, 128);
-    const int64_t t128 = (int64_t)a.n_tiles * a.k_tiles;
-    static const int conv_wgs = getenv("PB_CONV_WGRAD_WGS") ? atoi(getenv("PB_CONV_WGRAD_WGS")) : 2048;
-    int64_t split = pb_cdiv(conv_wgs, t128 * taps);
-    if (split > pb_cdiv(a.M, 256)) split = pb_cdiv(a.M, 256);
-    if (split < 1) split = 1;
-    a.rows_per_wg = pb_cdiv(pb_cdiv(a.M, split), 32) * 32;
-    split = pb_cdiv(a.M, a.rows_per_wg);
-    a.split = (int)split;
-    hipLaunchKernelGGL((pw_wgrad128_kernel<true>), dim3((unsigned)(t128 * 8 * pb_cdiv(split, 8)), 1, (unsigned)taps),
-                       block, 0, (hipStream_t)stream, a);
-  } else {
-    hipLaunchKernelGGL((pw_wgrad_kernel<float, 2, 2, true>), grid, block, 0, (hipStream_t)stream, a);
-  }
-  PB_LAUNCH_CHECK();
-  return 0;
-}
-
-extern "C" int pb_pwconv_bwd_weight(const void* dy, const void* x, float* dw, int64_t M, int K, int N,
-                                    pb_dtype dtype, const float* in_scale, const float* in_shift, pb_act in_act,
-                                    float in_slope, const float* row_scale, int64_t rows_per_group, int device,
-                                    void* stream) {
-  return pb_pwconv_bwd_weight_ws(dy, x, dw, M, K, N, dtype, in_scale, in_shift, in_act, in_slope, row_scale, rows_per_group,
-                                 nullptr, 0, device, stream);
-}
-
-// Dense-conv weight gradient on the LDS-DMA kernel (bf16, any stride): grid z = filter taps, partial tiles into the
-// workspace, one reduction.  zero16: any 16 zero bytes of device memory.
+// Dense-conv weight gradient: grid z = filter taps, per-range partial tiles into the workspace, one fixed-order
+// reduction.  bf16 with channel counts that are multiples of 8: the LDS-DMA kernel (any stride; zero16 = any 16 zero
+// bytes of device memory for the padding voxels); everything else: the register-staged kernels.
 namespace {
-// row ranges of the DMA conv weight gradient: ~1536 workgroups over (128x128 tiles) x taps x ranges; 0 = not eligible
-int64_t conv_wgrad_dma_plan(const pb_conv_shape* s, pb_dtype dtype, int64_t* rows_per_wg) {
-  static const bool on = !(getenv("PB_CONV_WGRAD_DMA") && atoi(getenv("PB_CONV_WGRAD_DMA")) == 0);
-  if (!on || !s || dtype != PB_BF16 || s->Cin % 8 || s->Cout % 8) return 0;
+struct ConvWgPlan {
+  bool dma, big;          // big: 128x128 tiles (bf16), else the 32x32 fp32 kernel
+  int n_tiles, k_tiles;
+  int64_t split, rows_per_wg;
+};
+ConvWgPlan conv_wgrad_plan(const pb_conv_shape* s, pb_dtype dtype) {
+  ConvWgPlan p = {};
   const int taps = s->kt * s->kh * s->kw;
   const int64_t M = (int64_t)s->N * s->To * s->Ho * s->Wo;
-  if (M <= 0 || M >= (1LL << 31) || taps > 65535) return 0;
-  const int64_t t128 = pb_cdiv(s->Cout, 128) * pb_cdiv(s->Cin, 128);
-  static const int conv_wgs = getenv("PB_CONV_WGRAD_DMA_WGS") ? atoi(getenv("PB_CONV_WGRAD_DMA_WGS")) : 1536;
-  int64_t split = conv_wgs / (t128 * taps);
-  if (split > pb_cdiv(M, 256)) split = pb_cdiv(M, 256);
-  if (split < 1) split = 1;
-  *rows_per_wg = pb_cdiv(pb_cdiv(M, split), 32) * 32;
-  return pb_cdiv(M, *rows_per_wg);
+  static const bool dma_on = !(getenv("PB_CONV_WGRAD_DMA") && atoi(getenv("PB_CONV_WGRAD_DMA")) == 0);
+  p.big = dtype == PB_BF16;
+  p.dma = dma_on && p.big && s->Cin % 8 == 0 && s->Cout % 8 == 0 && M < (1LL << 31);
+  if (p.big) {
+    p.n_tiles = (int)pb_cdiv(s->Cout, 128);
+    p.k_tiles = (int)pb_cdiv(s->Cin, 128);
+    const int64_t t128 = (int64_t)p.n_tiles * p.k_tiles;
+    // ~1536 (DMA kernel) / 2048 workgroups over (128x128 tiles) x taps x row ranges
+    static const int dma_wgs = getenv("PB_CONV_WGRAD_DMA_WGS") ? atoi(getenv("PB_CONV_WGRAD_DMA_WGS")) : 1536;
+    static const int reg_wgs = getenv("PB_CONV_WGRAD_WGS") ? atoi(getenv("PB_CONV_WGRAD_WGS")) : 2048;
+    int64_t split = p.dma ? dma_wgs / (t128 * taps) : pb_cdiv(reg_wgs, t128 * taps);
+    if (split > pb_cdiv(M, 256)) split = pb_cdiv(M, 256);
+    if (split < 1) split = 1;
+    p.rows_per_wg = pb_cdiv(pb_cdiv(M, split), 32) * 32;
+    p.split = pb_cdiv(M, p.rows_per_wg);
+  } else {
+    p.n_tiles = (int)pb_cdiv(s->Cout, 32);
+    p.k_tiles = (int)pb_cdiv(s->Cin, 32);
+    const int64_t tiles = (int64_t)p.n_tiles * p.k_tiles;
+    int64_t msplit = pb_cdiv(2048, tiles * taps);
+    const int64_t max_split = pb_cdiv(M, 128);
+    if (msplit > max_split) msplit = max_split;
+    if (msplit > 65535) msplit = 65535;
+    if (msplit < 1) msplit = 1;
+    p.rows_per_wg = pb_cdiv(pb_cdiv(M, msplit), 128) * 128;
+    p.split = pb_cdiv(M, p.rows_per_wg);
+  }
+  return p;
 }
 }  // namespace
 
 extern "C" int64_t pb_conv3d_bwd_weight_ws_bytes(const pb_conv_shape* s, pb_dtype dtype, int device) {
   (void)device;
-  int64_t rows = 0;
-  const int64_t split = conv_wgrad_dma_plan(s, dtype, &rows);
-  return split ? split * (int64_t)s->Cout * (s->kt * s->kh * s->kw) * s->Cin * 4 : 0;
+  if (!s || s->N <= 0 || s->Cin <= 0 || s->Cout <= 0 || s->To <= 0 || s->Ho <= 0 || s->Wo <= 0) return 0;
+  return conv_wgrad_plan(s, dtype).split * (int64_t)s->Cout * (s->kt * s->kh * s->kw) * s->Cin * 4;
 }
 
 extern "C" int pb_conv3d_bwd_weight_ws(const void* dy, const void* x, float* dwp, const pb_conv_shape* s, pb_dtype dtype,
                                        void* ws, int64_t ws_bytes, const void* zero16, int device, void* stream) {
-  const int64_t need = pb_conv3d_bwd_weight_ws_bytes(s, dtype, device);
-  if (!ws || !zero16 || need == 0 || ws_bytes < need || ((uintptr_t)ws % 16) || ((uintptr_t)dwp % 16))
-    return pb_conv3d_bwd_weight(dy, x, dwp, s, dtype, device, stream);
-  PB_CHECK_ARG(dy && x && dwp, "pb_conv3d_bwd_weight_ws: null pointer");
+  PB_CHECK_ARG(dy && x && dwp && ws && zero16, "pb_conv3d_bwd_weight_ws: null pointer");
   if (int rc = check_conv(s, dtype, "pb_conv3d_bwd_weight_ws")) return rc;
-  PB_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0 && ((uintptr_t)zero16 % 16) == 0, "pb_conv3d_bwd_weight_ws: unaligned pointer");
+  PB_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0 && ((uintptr_t)zero16 % 16) == 0 && ((uintptr_t)ws % 16) == 0,
+               "pb_conv3d_bwd_weight_ws: unaligned pointer");
+  PB_CHECK_ARG(ws_bytes >= pb_conv3d_bwd_weight_ws_bytes(s, dtype, device), "pb_conv3d_bwd_weight_ws: workspace of %lld bytes needed",
+               (long long)pb_conv3d_bwd_weight_ws_bytes(s, dtype, device));
   PB_ENTER(device);
   WgArgs a = {};
   a.dY = dy; a.X = x; a.dW = dwp; a.P = (float*)ws; a.zero = zero16;
@@ -1723,19 +1684,25 @@ extern "C" int pb_conv3d_bwd_weight_ws(const void* dy, const void* x, float* dwp
   a.ckt = s->kt; a.ckh = s->kh; a.ckw = s->kw; a.cst = s->st; a.csh = s->sh; a.csw = s->sw;
   a.cpt = s->pt; a.cph = s->ph; a.cpw = s->pw;
   const int taps = s->kt * s->kh * s->kw;
-  a.n_tiles = (int)pb_cdiv(a.N, 128);
-  a.k_tiles = (int)pb_cdiv(a.K, 128);
-  const int64_t t128 = (int64_t)a.n_tiles * a.k_tiles;
-  int64_t rows = 0;
-  const int64_t split = conv_wgrad_dma_plan(s, dtype, &rows);
-  a.rows_per_wg = rows;
-  a.split = (int)split;
+  PB_CHECK_ARG(taps <= 65535, "pb_conv3d_bwd_weight_ws: too many taps");
+  const ConvWgPlan p = conv_wgrad_plan(s, dtype);
+  a.n_tiles = p.n_tiles; a.k_tiles = p.k_tiles;
+  a.rows_per_wg = p.rows_per_wg;
+  a.split = (int)p.split;
   a.ranges_per_group = 0;
-  hipLaunchKernelGGL((pw_wgrad128_dma_kernel<3, true>), dim3((unsigned)(t128 * 8 * pb_cdiv(split, 8)), 1, (unsigned)taps), dim3(256),
-                     3 * 16384, (hipStream_t)stream, a);
-  const int64_t nk4 = (int64_t)s->Cout * taps * s->Cin / 4;
-  hipLaunchKernelGGL(pw_wgrad_reduce_kernel, dim3((unsigned)pb_cdiv(nk4, 32)), dim3(256), 0, (hipStream_t)stream, a.P, dwp, nk4,
-                     a.split);
+  const int64_t tiles = (int64_t)p.n_tiles * p.k_tiles;
+  if (p.dma)
+    hipLaunchKernelGGL((pw_wgrad128_dma_kernel<3, true>), dim3((unsigned)(tiles * 8 * pb_cdiv(p.split, 8)), 1, (unsigned)taps), dim3(256),
+                       3 * 16384, (hipStream_t)stream, a);
+  else if (p.big)
+    hipLaunchKernelGGL((pw_wgrad128_kernel<true>), dim3((unsigned)(tiles * 8 * pb_cdiv(p.split, 8)), 1, (unsigned)taps), dim3(256), 0,
+                       (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL((pw_wgrad_kernel<float, 2, 2, true>), dim3((unsigned)tiles, (unsigned)p.split, (unsigned)taps), dim3(256), 0,
+                       (hipStream_t)stream, a);
   PB_LAUNCH_CHECK();
+  const int64_t nk = (int64_t)s->Cout * taps * s->Cin;
+  const pb_reduce_job job = {(const float*)ws, dwp, nk, nk, (int)p.split, 1};
+  if (pb_launch_partials_reduce(&job, 1, (hipStream_t)stream)) { pb_set_error("pb_conv3d_bwd_weight_ws: combine launch failed"); return 2; }
   return 0;
 }

@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void pw_gemm_dma_kernel(DmaArgs a) {
       csum[j] = csq[j] = 0.f;
     }
     lds_barrier();
-    float* st = a.stats + (size_t)(blockIdx.x % PB_STAT_REPLICAS) * 2 * a.N;
+    float* st = a.stats + (size_t)blockIdx.x * 2 * a.N;      // this workgroup's own slot (grid <= PB_STAT_SLOTS): plain read-modify-write
     for (int c = tid; c < BN; c += 256) {
       const int n = n0 + c;
       if (n < a.N) {
@@ -224,8 +224,8 @@ __global__ __launch_bounds__(256) void pw_gemm_dma_kernel(DmaArgs a) {
           s += sred[(w * BN + c) * 2 + 0];
           q += sred[(w * BN + c) * 2 + 1];
         }
-        atomicAdd(st + n, s);
-        atomicAdd(st + a.N + n, q);
+        st[n] += s;
+        st[a.N + n] += q;
       }
     }
     lds_barrier();
@@ -452,9 +452,13 @@ int launch_dma(const DmaArgs& a, int64_t total, int device, hipStream_t st) {
   constexpr int BN = NT * 16;
   constexpr int ER = (NT >= 8 && NS == 2) ? 8 : 16;
   constexpr size_t lds = (size_t)NS * (BM * 128 + BN * 128) + 4 * ER * (BN + 8) * 2 + 4 * BN * 2 * 4;
-  static int resident = 0;
+  static int resident_dev[16] = {0};                 // per device: the attribute is per (function, device)
+  int& resident = resident_dev[device & 15];
   if (resident == 0) {
-    (void)hipFuncSetAttribute((const void*)pw_gemm_dma_kernel<NT, NS, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (hipFuncSetAttribute((const void*)pw_gemm_dma_kernel<NT, NS, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      pb_set_error("pw_gemm_dma: cannot reserve %d bytes of LDS", (int)lds);
+      return 1;
+    }
     int per_cu = 0, cus = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pw_gemm_dma_kernel<NT, NS, CONV>, 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) cus = 256;
@@ -463,6 +467,7 @@ int launch_dma(const DmaArgs& a, int64_t total, int device, hipStream_t st) {
   int64_t blocks = resident;
   if (blocks > total) blocks = total;
   blocks = pb_cdiv(blocks, 8) * 8;
+  if (a.stats && blocks > PB_STAT_SLOTS) blocks = PB_STAT_SLOTS;   // one statistics slot per workgroup
   hipLaunchKernelGGL((pw_gemm_dma_kernel<NT, NS, CONV>), dim3((unsigned)blocks), dim3(256), lds, st, a);
   return 0;
 }
@@ -525,34 +530,39 @@ extern "C" int pb_pwconv_fwd_bf16w(const void* x, const void* wb, void* y, int64
   const int64_t total = a.n_tiles == 1 ? a.m_tiles : pb_cdiv(a.m_tiles, 8) * 8 * a.n_tiles;
   PB_CHECK_ARG(total <= 0x3fffffffLL, "pb_pwconv_fwd_bf16w: too many tiles");
   hipStream_t st = (hipStream_t)stream;
+  int rc = 0;
   // narrow tiles (BN <= 96): a 2-stage ring leaves room for two workgroups per CU, whose epilogues overlap each
   // other's streaming (measured -7 % on the family); wide tiles need the LDS for a 3-stage ring of one workgroup
   static const int ns2 = getenv("PB_GEMM_DMA_NS2") ? atoi(getenv("PB_GEMM_DMA_NS2")) : 1;
   if (ns2 && nt <= 6) {
-    if (nt == 2) launch_dma<2, 2>(a, total, device, st);
-    else if (nt == 4) launch_dma<4, 2>(a, total, device, st);
-    else launch_dma<6, 2>(a, total, device, st);
+    if (nt == 2) rc = launch_dma<2, 2>(a, total, device, st);
+    else if (nt == 4) rc = launch_dma<4, 2>(a, total, device, st);
+    else rc = launch_dma<6, 2>(a, total, device, st);
+    if (rc) return rc;
     PB_LAUNCH_CHECK();
     return 0;
   }
   static const int ns2w = getenv("PB_GEMM_DMA_NS2W") ? atoi(getenv("PB_GEMM_DMA_NS2W")) : 0;
   if (ns2w == 1 && nt == 8) {
-    launch_dma<8, 2>(a, total, device, st);
+    rc = launch_dma<8, 2>(a, total, device, st);
+    if (rc) return rc;
     PB_LAUNCH_CHECK();
     return 0;
   }
   if (ns2w == 4 && nt == 8) {
-    launch_dma<8, 4>(a, total, device, st);
+    rc = launch_dma<8, 4>(a, total, device, st);
+    if (rc) return rc;
     PB_LAUNCH_CHECK();
     return 0;
   }
   switch (nt) {
-    case 2: launch_dma<2, 4>(a, total, device, st); break;
-    case 4: launch_dma<4, 4>(a, total, device, st); break;
-    case 6: launch_dma<6, 3>(a, total, device, st); break;
-    case 8: launch_dma<8, 3>(a, total, device, st); break;
-    default: launch_dma<12, 3>(a, total, device, st); break;
+    case 2: rc = launch_dma<2, 4>(a, total, device, st); break;
+    case 4: rc = launch_dma<4, 4>(a, total, device, st); break;
+    case 6: rc = launch_dma<6, 3>(a, total, device, st); break;
+    case 8: rc = launch_dma<8, 3>(a, total, device, st); break;
+    default: rc = launch_dma<12, 3>(a, total, device, st); break;
   }
+  if (rc) return rc;
   PB_LAUNCH_CHECK();
   return 0;
 }
@@ -598,16 +608,18 @@ extern "C" int pb_conv3d_fwd_bf16w(const void* x, const void* wb, void* y, const
   a.n_tiles = (int)pb_cdiv(a.N, nt * 16);
   const int64_t total = a.n_tiles == 1 ? a.m_tiles : pb_cdiv(a.m_tiles, 8) * 8 * a.n_tiles;
   hipStream_t st = (hipStream_t)stream;
+  int rc = 0;
   static const int ns = getenv("PB_CONV_DMA_NS") ? atoi(getenv("PB_CONV_DMA_NS")) : 2;
   if (ns == 2) {
-    if (nt == 2) launch_dma<2, 2, true>(a, total, device, st);
-    else if (nt == 4) launch_dma<4, 2, true>(a, total, device, st);
-    else launch_dma<6, 2, true>(a, total, device, st);
+    if (nt == 2) rc = launch_dma<2, 2, true>(a, total, device, st);
+    else if (nt == 4) rc = launch_dma<4, 2, true>(a, total, device, st);
+    else rc = launch_dma<6, 2, true>(a, total, device, st);
   } else {
-    if (nt == 2) launch_dma<2, 4, true>(a, total, device, st);
-    else if (nt == 4) launch_dma<4, 4, true>(a, total, device, st);
-    else launch_dma<6, 3, true>(a, total, device, st);
+    if (nt == 2) rc = launch_dma<2, 4, true>(a, total, device, st);
+    else if (nt == 4) rc = launch_dma<4, 4, true>(a, total, device, st);
+    else rc = launch_dma<6, 3, true>(a, total, device, st);
   }
+  if (rc) return rc;
   PB_LAUNCH_CHECK();
   return 0;
 }

@@ -31,7 +31,7 @@ template <> __device__ __forceinline__ float ldx<bf16_t>(const bf16_t* p) { retu
 template <typename XT, typename T>
 __global__ __launch_bounds__(256) void stem_fwd_kernel(StemArgs a) {
   __shared__ __attribute__((aligned(16))) float wl[MAX_CT * OCB];
-  __shared__ float red[2 * OCB];
+  __shared__ float red[2 * OCB * 256];       // statistics: one column per thread, summed in thread order
   const pb_stem_shape& s = a.s;
   const int tid = threadIdx.x;
   const int taps = s.kt * s.kh * s.kw, CT = s.Cin * taps;
@@ -40,9 +40,13 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemArgs a) {
     const int ct = i / OCB, oc = i - ct * OCB;
     wl[i] = (oc0 + oc < s.Cout) ? a.w[(int64_t)(oc0 + oc) * CT + ct] : 0.f;
   }
-  if (tid < 2 * OCB) red[tid] = 0.f;
   __syncthreads();
-  const int64_t pix = (int64_t)blockIdx.x * 256 + tid;
+  float ssum[OCB], ssq[OCB];
+#pragma unroll
+  for (int oc = 0; oc < OCB; ++oc) ssum[oc] = ssq[oc] = 0.f;
+  const int64_t nblk = (a.npix + 255) / 256;
+  for (int64_t pb = blockIdx.x; pb < nblk; pb += gridDim.x) {
+  const int64_t pix = pb * 256 + tid;
   const bool valid = pix < a.npix;
   float acc[OCB];
 #pragma unroll
@@ -91,21 +95,28 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemArgs a) {
       for (int oc = 0; oc < OCB; ++oc)
         if (oc0 + oc < s.Cout) yp[oc] = from_f32<T>(acc[oc]);
     }
+#pragma unroll
+    for (int oc = 0; oc < OCB; ++oc) {
+      const float v = to_f32(from_f32<T>(acc[oc]));
+      ssum[oc] += v;
+      ssq[oc] += v * v;
+    }
+  }
   }
   if (a.stats) {
-    if (valid) {
 #pragma unroll
-      for (int oc = 0; oc < OCB; ++oc) {
-        const float v = to_f32(from_f32<T>(acc[oc]));
-        atomicAdd(&red[oc], v);
-        atomicAdd(&red[OCB + oc], v * v);
-      }
+    for (int oc = 0; oc < OCB; ++oc) {
+      red[oc * 256 + tid] = ssum[oc];
+      red[(OCB + oc) * 256 + tid] = ssq[oc];
     }
     __syncthreads();
-    if (tid < OCB && oc0 + tid < s.Cout) {
-      float* st = a.stats + (size_t)(blockIdx.x % PB_STAT_REPLICAS) * 2 * s.Cout;
-      atomicAdd(st + oc0 + tid, red[tid]);
-      atomicAdd(st + s.Cout + oc0 + tid, red[OCB + tid]);
+    if (tid < 2 * OCB) {
+      const float* src = red + tid * 256;
+      float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+      for (int i = 0; i < 256; i += 4) { t0 += src[i]; t1 += src[i + 1]; t2 += src[i + 2]; t3 += src[i + 3]; }
+      const int oc = tid & (OCB - 1);
+      if (oc0 + oc < s.Cout)      // this workgroup's own slot (gridDim.x <= PB_STAT_SLOTS)
+        a.stats[(size_t)blockIdx.x * 2 * s.Cout + (tid >= OCB ? s.Cout : 0) + oc0 + oc] = (t0 + t1) + (t2 + t3);
     }
   }
 }
@@ -165,7 +176,7 @@ template <typename XT, typename T>
 __global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(StemArgs a) {
   __shared__ __attribute__((aligned(16))) T win_s[4][SW_MAXWIN];
   __shared__ __attribute__((aligned(16))) T out_s[4][SW_PIX * OCB];
-  __shared__ float red[2 * OCB];
+  __shared__ float red[4][2 * OCB];
   const pb_stem_shape& s = a.s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int taps = s.kt * s.kh * s.kw, CT = s.Cin * taps;
@@ -178,8 +189,6 @@ __global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(StemArgs a) {
   T* y = (T*)a.y;
   T* win = win_s[wave];
   T* outt = out_s[wave];
-  if (tid < 2 * OCB) red[tid] = 0.f;
-  __syncthreads();
   const int row = lane & 15, g = lane >> 4;          // A: pixel row / k group; B: oc / k group; D: oc column, row group
   // filter fragments: lane (oc = row, g) holds W[oc][32*ks + 8g + j]; window offsets of this lane's 8 columns
   float wf[SW_KS][8];
@@ -278,14 +287,14 @@ __global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(StemArgs a) {
     ssum += __shfl_xor(ssum, 16, 64); ssum += __shfl_xor(ssum, 32, 64);
     ssq += __shfl_xor(ssq, 16, 64); ssq += __shfl_xor(ssq, 32, 64);
     if (lane < 16) {
-      atomicAdd(&red[lane], ssum);
-      atomicAdd(&red[OCB + lane], ssq);
+      red[wave][lane] = ssum;
+      red[wave][OCB + lane] = ssq;
     }
     __syncthreads();
     if (tid < OCB && oc0 + tid < s.Cout) {
-      float* st = a.stats + (size_t)(blockIdx.x % PB_STAT_REPLICAS) * 2 * s.Cout;
-      atomicAdd(st + oc0 + tid, red[tid]);
-      atomicAdd(st + s.Cout + oc0 + tid, red[OCB + tid]);
+      float* st = a.stats + (size_t)blockIdx.x * 2 * s.Cout;        // this workgroup's own slot (gridDim.x <= PB_STAT_SLOTS)
+      st[oc0 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+      st[s.Cout + oc0 + tid] = (red[0][OCB + tid] + red[1][OCB + tid]) + (red[2][OCB + tid] + red[3][OCB + tid]);
     }
   }
 }
@@ -397,21 +406,27 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemArgs a) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
   }
-  // cross-wave sum (C/D map: row = oc = (lane>>4)*4 + r, col = lane & 15), then contiguous atomics
+  // cross-wave sum in wave order (C/D map: row = oc = (lane>>4)*4 + r, col = lane & 15; every lane owns its elements
+  // of the wave's tile), then plain stores into this workgroup's slot of the partial-gradient workspace
   for (int i = tid; i < OCB * SW_NB * 16; i += 256) red[i] = 0.f;
   __syncthreads();
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
 #pragma unroll
-  for (int b = 0; b < SW_NB; ++b)
-    if (b < nb)
+      for (int b = 0; b < SW_NB; ++b)
+        if (b < nb)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) atomicAdd(&red[((lane >> 4) * 4 + r) * (SW_NB * 16) + b * 16 + (lane & 15)], acc[b][r]);
-  __syncthreads();
+          for (int r = 0; r < 4; ++r) red[((lane >> 4) * 4 + r) * (SW_NB * 16) + b * 16 + (lane & 15)] += acc[b][r];
+    }
+    __syncthreads();
+  }
+  float* part = a.dw + (size_t)blockIdx.x * ((size_t)s.Cout * (CT + 1));     // [Cout][CT] then [Cout] (bias)
   for (int i = tid; i < OCB * (CT + 1); i += 256) {
     const int oc = i / (CT + 1), c = i - oc * (CT + 1);
     if (oc0 + oc >= s.Cout) continue;
     const float v = red[oc * (SW_NB * 16) + c];
-    if (c < CT) atomicAdd(a.dw + (int64_t)(oc0 + oc) * CT + c, v);
-    else if (a.dbias) atomicAdd(a.dbias + oc0 + oc, v);
+    if (c < CT) part[(int64_t)(oc0 + oc) * CT + c] = v;
+    else part[(int64_t)s.Cout * CT + oc0 + oc] = v;
   }
 }
 
@@ -553,15 +568,21 @@ __global__ __launch_bounds__(64 * S3W_NW) void stem3_wgrad_kernel(StemArgs a) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
   }
-  // D[oc][n] per window row: n < 6 -> tap (aw = n/3, ci = n%3); 8 <= n < 11 -> (aw = 2, ci = n-8); row 0, n = 6 -> bias
+  // D[oc][n] per window row: n < 6 -> tap (aw = n/3, ci = n%3); 8 <= n < 11 -> (aw = 2, ci = n-8); row 0, n = 6 -> bias.
+  // Cross-wave sum in wave order (no atomics), then plain stores into this workgroup's slot of the workspace.
   for (int i = tid; i < OCB * S3_MAXROWS * 16; i += 64 * S3W_NW) red[i] = 0.f;
   __syncthreads();
+  for (int w = 0; w < S3W_NW; ++w) {
+    if (wave == w) {
 #pragma unroll
-  for (int r = 0; r < S3_MAXROWS; ++r)
-    if (r < nrows)
+      for (int r = 0; r < S3_MAXROWS; ++r)
+        if (r < nrows)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) atomicAdd(&red[((lane >> 4) * 4 + i) * (S3_MAXROWS * 16) + r * 16 + (lane & 15)], acc[r][i]);
-  __syncthreads();
+          for (int i = 0; i < 4; ++i) red[((lane >> 4) * 4 + i) * (S3_MAXROWS * 16) + r * 16 + (lane & 15)] += acc[r][i];
+    }
+    __syncthreads();
+  }
+  float* part = a.dw + (size_t)blockIdx.x * ((size_t)s.Cout * (CT + 1));     // [Cout][CT] then [Cout] (bias)
   for (int i = tid; i < OCB * (CT + 1); i += 64 * S3W_NW) {
     const int oc = i / (CT + 1), c = i - oc * (CT + 1);
     if (oc0 + oc >= s.Cout) continue;
@@ -569,9 +590,9 @@ __global__ __launch_bounds__(64 * S3W_NW) void stem3_wgrad_kernel(StemArgs a) {
       const int ci = c / taps, tp = c - ci * taps;
       const int r = tp / 3, aw = tp - r * 3;
       const int nn = aw < 2 ? aw * 3 + ci : 8 + ci;
-      atomicAdd(a.dw + (int64_t)(oc0 + oc) * CT + c, red[oc * (S3_MAXROWS * 16) + r * 16 + nn]);
-    } else if (a.dbias) {
-      atomicAdd(a.dbias + oc0 + oc, red[oc * (S3_MAXROWS * 16) + 6]);
+      part[(int64_t)(oc0 + oc) * CT + c] = red[oc * (S3_MAXROWS * 16) + r * 16 + nn];
+    } else {
+      part[(int64_t)s.Cout * CT + oc0 + oc] = red[oc * (S3_MAXROWS * 16) + 6];
     }
   }
 }
@@ -583,7 +604,7 @@ __global__ __launch_bounds__(256) void stem3_fwd_kernel(StemArgs a) {
   typedef bf16_t T;
   __shared__ __attribute__((aligned(16))) T win_s[4][S3_MAXROWS * S3_SP * 8];
   __shared__ __attribute__((aligned(16))) T out_s[4][SW_PIX * OCB];
-  __shared__ float red[2 * OCB];
+  __shared__ float red[4][2 * OCB];
   const pb_stem_shape& s = a.s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nrows = s.kt * s.kh, taps = nrows * 3, CT = 3 * taps;
@@ -593,8 +614,6 @@ __global__ __launch_bounds__(256) void stem3_fwd_kernel(StemArgs a) {
   T* y = (T*)a.y;
   T* win = win_s[wave];
   T* outt = out_s[wave];
-  if (tid < 2 * OCB) red[tid] = 0.f;
-  __syncthreads();
   const int row = lane & 15, g = lane >> 4;
   constexpr int NKS = 5;                                   // 5 x 32 = 160 >= 18 groups x 8
   bf16x8 wf[NKS], wl[NKS];                                 // filter as a bf16 hi + lo pair: the first layer's rounding
@@ -672,14 +691,14 @@ __global__ __launch_bounds__(256) void stem3_fwd_kernel(StemArgs a) {
     ssum += __shfl_xor(ssum, 16, 64); ssum += __shfl_xor(ssum, 32, 64);
     ssq += __shfl_xor(ssq, 16, 64); ssq += __shfl_xor(ssq, 32, 64);
     if (lane < 16) {
-      atomicAdd(&red[lane], ssum);
-      atomicAdd(&red[OCB + lane], ssq);
+      red[wave][lane] = ssum;
+      red[wave][OCB + lane] = ssq;
     }
     __syncthreads();
     if (tid < OCB) {
-      float* st = a.stats + (size_t)(blockIdx.x % PB_STAT_REPLICAS) * 2 * s.Cout;
-      atomicAdd(st + tid, red[tid]);
-      atomicAdd(st + s.Cout + tid, red[OCB + tid]);
+      float* st = a.stats + (size_t)blockIdx.x * 2 * s.Cout;        // this workgroup's own slot (gridDim.x <= PB_STAT_SLOTS)
+      st[tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+      st[s.Cout + tid] = (red[0][OCB + tid] + red[1][OCB + tid]) + (red[2][OCB + tid] + red[3][OCB + tid]);
     }
   }
 }
@@ -734,41 +753,65 @@ extern "C" int pb_stem_conv3d_fwd(const void* x, int x_dtype, float x_scale, con
     const int64_t items = (int64_t)s->N * s->To * s->Ho * pb_cdiv(s->Wo, SW_PIX);
     int64_t gx = pb_cdiv(items, 4);
     if (gx > 2048) gx = 2048;
+    if (stats && gx > PB_STAT_SLOTS) gx = PB_STAT_SLOTS;       // one statistics slot per workgroup
     dim3 grid((unsigned)gx, (unsigned)pb_cdiv(s->Cout, OCB));
     if (stem3_ok(s, x_dtype, dtype) && x_scale == 1.f) hipLaunchKernelGGL(stem3_fwd_kernel, grid, dim3(256), 0, st, a);
     else PB_STEM_DISPATCH(stem_fwd_mfma_kernel, grid);
   } else {
-    dim3 grid((unsigned)pb_cdiv(a.npix, 256), (unsigned)pb_cdiv(s->Cout, OCB));
+    int64_t gx = pb_cdiv(a.npix, 256);
+    if (gx > PB_STAT_SLOTS) gx = PB_STAT_SLOTS;
+    dim3 grid((unsigned)gx, (unsigned)pb_cdiv(s->Cout, OCB));
     PB_STEM_DISPATCH(stem_fwd_kernel, grid);
   }
   PB_LAUNCH_CHECK();
   return 0;
 }
 
+namespace {
+// workgroups along x of the weight-gradient launch (= partial-gradient slots in the workspace)
+int64_t stem_wgrad_gx(const pb_stem_shape* s, int x_dtype, float x_scale, pb_dtype dtype) {
+  const int64_t items = (int64_t)s->N * s->To * s->Ho * pb_cdiv(s->Wo, SW_PIX);
+  if (stem3_ok(s, x_dtype, dtype) && x_scale == 1.f) {
+    static const int wg_cap = getenv("PB_STEM_WGRAD_WGS") ? atoi(getenv("PB_STEM_WGRAD_WGS")) : 256;
+    int64_t g3 = pb_cdiv(items, S3W_NW);
+    return g3 > wg_cap ? wg_cap : g3;
+  }
+  int64_t gx = pb_cdiv(items, 4);
+  return gx > 512 ? 512 : gx;
+}
+}  // namespace
+
+extern "C" int64_t pb_stem_conv3d_bwd_weight_ws_bytes(const pb_stem_shape* s, int x_dtype, float x_scale, pb_dtype dtype) {
+  if (!s || s->Cout <= 0 || s->Cin <= 0) return 0;
+  const int64_t CT = (int64_t)s->Cin * s->kt * s->kh * s->kw;
+  return stem_wgrad_gx(s, x_dtype, x_scale, dtype) * s->Cout * (CT + 1) * 4;
+}
+
 extern "C" int pb_stem_conv3d_bwd_weight(const void* dy, const void* x, int x_dtype, float x_scale, float* dw,
-                                         float* dbias, const pb_stem_shape* s, pb_dtype dtype, int device,
-                                         void* stream) {
-  PB_CHECK_ARG(dy && x && dw, "pb_stem_conv3d_bwd_weight: null pointer");
+                                         float* dbias, const pb_stem_shape* s, pb_dtype dtype, void* ws,
+                                         int64_t ws_bytes, int device, void* stream) {
+  PB_CHECK_ARG(dy && x && dw && ws, "pb_stem_conv3d_bwd_weight: null pointer");
   if (int rc = check_stem(s, x_dtype, dtype, "pb_stem_conv3d_bwd_weight")) return rc;
+  PB_CHECK_ARG(ws_bytes >= pb_stem_conv3d_bwd_weight_ws_bytes(s, x_dtype, x_scale, dtype) && ((uintptr_t)ws % 16) == 0,
+               "pb_stem_conv3d_bwd_weight: workspace too small or unaligned");
   PB_ENTER(device);
   hipStream_t st = (hipStream_t)stream;
   StemArgs a = {};
-  a.x = x; a.x_scale = x_scale; a.y = const_cast<void*>(dy); a.dw = dw; a.dbias = dbias; a.s = *s;
+  a.x = x; a.x_scale = x_scale; a.y = const_cast<void*>(dy); a.dw = (float*)ws; a.dbias = nullptr; a.s = *s;
   a.npix = (int64_t)s->N * s->To * s->Ho * s->Wo;
   const int wl = 31 * s->sw + s->kw;
   PB_CHECK_ARG(s->kt * s->kh * wl * s->Cin <= SW_MAXWIN && s->kt * s->kh <= FW_R && wl * s->Cin <= 64 * FW_I,
                "pb_stem_conv3d_bwd_weight: window (%d rows x %d) exceeds the staged maximum", s->kt * s->kh, wl * s->Cin);
-  const int64_t items = (int64_t)s->N * s->To * s->Ho * pb_cdiv(s->Wo, SW_PIX);
-  int64_t gx = pb_cdiv(items, 4);
-  if (gx > 1024) gx = 1024;
+  const int64_t gx = stem_wgrad_gx(s, x_dtype, x_scale, dtype);
   dim3 grid((unsigned)gx, (unsigned)pb_cdiv(s->Cout, OCB));
-  if (stem3_ok(s, x_dtype, dtype) && x_scale == 1.f) {
-    static const int wg_cap = getenv("PB_STEM_WGRAD_WGS") ? atoi(getenv("PB_STEM_WGRAD_WGS")) : 256;
-    int64_t g3 = pb_cdiv(items, S3W_NW);
-    if (g3 > wg_cap) g3 = wg_cap;
-    hipLaunchKernelGGL(stem3_wgrad_kernel, dim3((unsigned)g3, grid.y), dim3(64 * S3W_NW), 0, st, a);
-  }
+  if (stem3_ok(s, x_dtype, dtype) && x_scale == 1.f) hipLaunchKernelGGL(stem3_wgrad_kernel, grid, dim3(64 * S3W_NW), 0, st, a);
   else PB_STEM_DISPATCH(stem_wgrad_kernel, grid);
   PB_LAUNCH_CHECK();
+  // dw += sum of the workgroups' partial gradients, in slot order
+  const int64_t CT = (int64_t)s->Cin * s->kt * s->kh * s->kw;
+  const int64_t stride = (int64_t)s->Cout * (CT + 1);
+  pb_reduce_job jobs[2] = {{(const float*)ws, dw, (int64_t)s->Cout * CT, stride, (int)gx, 1},
+                           {(const float*)ws + (int64_t)s->Cout * CT, dbias, s->Cout, stride, (int)gx, 1}};
+  if (pb_launch_partials_reduce(jobs, dbias ? 2 : 1, st)) { pb_set_error("pb_stem_conv3d_bwd_weight: combine launch failed"); return 2; }
   return 0;
 }

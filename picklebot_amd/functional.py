@@ -81,16 +81,17 @@ def _contig5(t):
 
 
 def _bn_state(bn):
-    """(gamma, beta, running_mean, running_var, eps, momentum) from an nn.BatchNorm module or None."""
+    """(gamma, beta, running_mean, running_var, eps, momentum, num_batches_tracked) from an nn.BatchNorm module or None."""
     if bn is None:
         return None
     if bn.momentum is None:
         raise NotImplementedError("picklebot_amd: BatchNorm with momentum=None (cumulative average) is not supported")
-    return (bn.weight, bn.bias, bn.running_mean, bn.running_var, float(bn.eps), float(bn.momentum))
+    return (bn.weight, bn.bias, bn.running_mean, bn.running_var, float(bn.eps), float(bn.momentum),
+            getattr(bn, "num_batches_tracked", None))
 
 
-def _bn_forward(z2, stats, count, gamma, beta, rmean, rvar, eps, momentum, training):
-    """-> (scale, shift, mean, rstd); updates running stats in training."""
+def _bn_forward(z2, stats, count, gamma, beta, rmean, rvar, eps, momentum, training, nbt=None):
+    """-> (scale, shift, mean, rstd); updates running stats (and the step counter nbt) in training."""
     use_running = not training
     if not use_running and rmean is None:
         rmean_, rvar_ = None, None
@@ -98,7 +99,7 @@ def _bn_forward(z2, stats, count, gamma, beta, rmean, rvar, eps, momentum, train
         rmean_, rvar_ = rmean, rvar
     C = (stats.shape[-1] if stats is not None else rmean.shape[0])
     return K.bn_finalize(None if use_running else stats, count, gamma, beta, eps, momentum, rmean_, rvar_,
-                         use_running, C, z2.device)
+                         use_running, C, z2.device, num_batches_tracked=None if use_running else nbt)
 
 
 class _BnCtx:
@@ -186,7 +187,7 @@ class _Bottleneck(torch.autograd.Function):
             eps, momentum = cfg["bn"]
             bnc = _BnCtx()
             bnc.scale, bnc.shift, bnc.mean, bnc.rstd = _bn_forward(z2, stats, z2.shape[0], gamma, beta, rmean, rvar,
-                                                                   eps, momentum, training)
+                                                                   eps, momentum, training, cfg.get("nbt"))
             bnc.training, bnc.count, bnc.beta = training, z2.shape[0], beta
             scale, shift = bnc.scale, beta
         y2 = K.affine_act_fwd(z2, scale, shift, act, slope, row_scale=drop, rows_per_group=R2,
@@ -212,25 +213,26 @@ class _Bottleneck(torch.autograd.Function):
             dz, dgamma, dbeta = _bn_act_backward(dy2, z2, bnc, gamma, cfg["act"], cfg["slope"], drop, R2)
         d2 = d5.view(-1, E)
         dw2, dwdw, dw1 = _zeros_many(x5, (Cout, E), (E, wdw[0].numel()), (E, Cin))
-        # projection conv: weight gradient sees the SE-scaled input, data gradient is w.r.t. it
-        K.pw_bwd_weight(dz, d2, dw2, row_scale=se_scale, rows_per_group=R2)
-        dS2 = K.pw_fwd(dz, w2.view(Cout, E), w_transposed=True)
         g_scale = g_shift = dse_w1 = dse_b1 = dse_w2 = dse_b2 = None
-        if has_se:
-            Cm = se_w1.shape[0]
-            dscale = K.rowgroup_reduce(dS2, d2, N)
-            g_shift, dse_w1, dse_b1, dse_w2, dse_b2 = K.se_fc_bwd(dscale, pool, 1.0 / R2, se_scale, hidden,
-                                                                  se_w1.view(Cm, E), se_w2.view(E, Cm))
-            g_scale = se_scale
-            dse_w1, dse_w2 = dse_w1.view_as(se_w1), dse_w2.view_as(se_w2)
-        dS5 = dS2.view(N, To, Ho, Wo, E)
-        K.dw_bwd_weight(dS5, e5, dwdw, kernel, stride, pad, g_scale, g_shift)
-        dE5 = K.dw_bwd_data(dS5, wdw.view(E, -1), (T, H, W), kernel, stride, pad, g_scale, g_shift)
-        dE2 = dE5.view(-1, E)
-        K.pw_bwd_weight(dE2, x5.view(-1, Cin), dw1)
-        dx5 = None
-        if ctx.needs_input_grad[0]:
-            dx5 = K.pw_fwd(dE2, w1.view(E, Cin), w_transposed=True).view(N, T, H, W, Cin)
+        with K.deferred_reductions():      # the three weight gradients' partial tiles are added up by ONE launch
+            # projection conv: weight gradient sees the SE-scaled input, data gradient is w.r.t. it
+            K.pw_bwd_weight(dz, d2, dw2, row_scale=se_scale, rows_per_group=R2)
+            dS2 = K.pw_fwd(dz, w2.view(Cout, E), w_transposed=True)
+            if has_se:
+                Cm = se_w1.shape[0]
+                dscale = K.rowgroup_reduce(dS2, d2, N)
+                g_shift, dse_w1, dse_b1, dse_w2, dse_b2 = K.se_fc_bwd(dscale, pool, 1.0 / R2, se_scale, hidden,
+                                                                      se_w1.view(Cm, E), se_w2.view(E, Cm))
+                g_scale = se_scale
+                dse_w1, dse_w2 = dse_w1.view_as(se_w1), dse_w2.view_as(se_w2)
+            dS5 = dS2.view(N, To, Ho, Wo, E)
+            K.dw_bwd_weight(dS5, e5, dwdw, kernel, stride, pad, g_scale, g_shift)
+            dE5 = K.dw_bwd_data(dS5, wdw.view(E, -1), (T, H, W), kernel, stride, pad, g_scale, g_shift)
+            dE2 = dE5.view(-1, E)
+            K.pw_bwd_weight(dE2, x5.view(-1, Cin), dw1)
+            dx5 = None
+            if ctx.needs_input_grad[0]:
+                dx5 = K.pw_fwd(dE2, w1.view(E, Cin), w_transposed=True).view(N, T, H, W, Cin)
         return (dx5, dw1.view_as(w1), dwdw.view_as(wdw), dw2.view_as(w2), dse_w1, dse_b1, dse_w2, dse_b2, dgamma,
                 dbeta, None, None, None, None)
 
@@ -242,7 +244,7 @@ def bottleneck(x5, w1, wdw, w2, se, bn, drop, *, kernel, stride, pad, act, slope
     params = [w1, wdw, w2] + ([p for p in se] if se else []) + ([gamma, beta] if gamma is not None else [])
     need_grad = torch.is_grad_enabled() and (x5.requires_grad or any(p.requires_grad for p in params if p is not None))
     cfg = dict(kernel=tuple(kernel), stride=tuple(stride), pad=tuple(pad), act=act, slope=slope, training=training,
-               bn=(st[4], st[5]) if st else None, need_grad=need_grad)
+               bn=(st[4], st[5]) if st else None, nbt=st[6] if st else None, need_grad=need_grad)
     se_w1, se_b1, se_w2, se_b2 = se if se else (None, None, None, None)
     return _Bottleneck.apply(x5, w1, wdw, w2, se_w1, se_b1, se_w2, se_b2, gamma, beta, rmean, rvar, drop, cfg)
 
@@ -262,7 +264,7 @@ class _StemBnAct(torch.autograd.Function):
             eps, momentum = cfg["bn"]
             bnc = _BnCtx()
             bnc.scale, bnc.shift, bnc.mean, bnc.rstd = _bn_forward(z2, stats, z2.shape[0], gamma, beta, rmean, rvar,
-                                                                   eps, momentum, training)
+                                                                   eps, momentum, training, cfg.get("nbt"))
             bnc.training, bnc.count, bnc.beta = training, z2.shape[0], beta
             scale, shift = bnc.scale, beta
         y2 = K.affine_act_fwd(z2, scale, shift, cfg["act"], cfg["slope"], mean=bnc.mean if bnc is not None else None)
@@ -295,8 +297,8 @@ def stem_bn_act(x, conv, bn, *, act, slope, training, dtype, x_scale=1.0):
     params = [conv.weight, conv.bias, gamma, beta]
     need_grad = torch.is_grad_enabled() and any(p is not None and p.requires_grad for p in params)
     cfg = dict(kernel=tuple(conv.kernel_size), stride=tuple(conv.stride), pad=tuple(conv.padding), act=act,
-               slope=slope, training=training, bn=(st[4], st[5]) if st else None, need_grad=need_grad, dtype=dtype,
-               x_scale=x_scale)
+               slope=slope, training=training, bn=(st[4], st[5]) if st else None, nbt=st[6] if st else None,
+               need_grad=need_grad, dtype=dtype, x_scale=x_scale)
     return _StemBnAct.apply(x, conv.weight, conv.bias, gamma, beta, rmean, rvar, cfg)
 
 
@@ -332,7 +334,7 @@ class _PwBnAct(torch.autograd.Function):
             eps, momentum = cfg["bn"]
             bnc = _BnCtx()
             bnc.scale, bnc.shift, bnc.mean, bnc.rstd = _bn_forward(u2, stats, M, gamma, beta, rmean, rvar, eps,
-                                                                   momentum, training)
+                                                                   momentum, training, cfg.get("nbt"))
             bnc.training, bnc.count, bnc.beta = training, M, beta
             scale, shift = bnc.scale, beta
         y2 = K.affine_act_fwd(u2, scale, shift, act, slope, row_scale=drop, rows_per_group=R if drop is not None else 0,
@@ -390,7 +392,8 @@ def pw_bn_act(x5, weight, bias, bn, *, act, slope, training, se=None, drop=None)
     gamma, beta, rmean, rvar = (st[0], st[1], st[2], st[3]) if st else (None, None, None, None)
     params = [weight, bias, gamma, beta] + (list(se) if se else [])
     need_grad = torch.is_grad_enabled() and (x5.requires_grad or any(p is not None and p.requires_grad for p in params))
-    cfg = dict(act=act, slope=slope, training=training, bn=(st[4], st[5]) if st else None, need_grad=need_grad)
+    cfg = dict(act=act, slope=slope, training=training, bn=(st[4], st[5]) if st else None, nbt=st[6] if st else None,
+               need_grad=need_grad)
     se_w1, se_b1, se_w2, se_b2 = se if se else (None, None, None, None)
     x5 = x5 if x5.is_contiguous() else x5.contiguous()
     return _PwBnAct.apply(x5, weight, bias, se_w1, se_b1, se_w2, se_b2, gamma, beta, rmean, rvar, drop, cfg)
@@ -513,7 +516,7 @@ class _ConvBnAct(torch.autograd.Function):
             eps, momentum = cfg["bn"]
             bnc = _BnCtx()
             bnc.scale, bnc.shift, bnc.mean, bnc.rstd = _bn_forward(z2, stats, z2.shape[0], gamma, beta, rmean, rvar, eps,
-                                                                   momentum, training)
+                                                                   momentum, training, cfg.get("nbt"))
             bnc.training, bnc.count, bnc.beta = training, z2.shape[0], beta
             scale, shift = bnc.scale, beta
         plain = not has_bn and cfg["act"] == "none"
@@ -566,7 +569,7 @@ def conv_bn_act(x5, conv_weight, conv_bias, bn, *, stride, pad_front, pad_back=N
     need_grad = torch.is_grad_enabled() and (x5.requires_grad or any(p is not None and p.requires_grad for p in params))
     cfg = dict(kernel=tuple(conv_weight.shape[2:]), stride=tuple(stride), pad_front=tuple(pad_front),
                pad_back=tuple(pad_back if pad_back is not None else pad_front), act=act, slope=slope, training=training,
-               bn=(st[4], st[5]) if st else None, need_grad=need_grad)
+               bn=(st[4], st[5]) if st else None, nbt=st[6] if st else None, need_grad=need_grad)
     return _ConvBnAct.apply(_contig5(x5), conv_weight, conv_bias, gamma, beta, rmean, rvar, cfg)
 
 

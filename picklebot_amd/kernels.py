@@ -13,7 +13,7 @@ import torch
 
 from . import _C
 
-REPL = _C.STAT_REPLICAS     # stats buffers are [REPL, 2, C] (include/picklebot_amd.h)
+REPL = _C.STAT_SLOTS        # stats buffers are [REPL, 2, C]: one slot per producing workgroup (include/picklebot_amd.h)
 
 ACT = {"none": _C.ACT_NONE, "relu": _C.ACT_RELU, "leaky_relu": _C.ACT_LEAKY_RELU, "hardswish": _C.ACT_HSWISH,
        "hardsigmoid": _C.ACT_HSIGMOID, "silu": _C.ACT_SILU}
@@ -22,9 +22,8 @@ ACT = {"none": _C.ACT_NONE, "relu": _C.ACT_RELU, "leaky_relu": _C.ACT_LEAKY_RELU
 # ---- zero-initialised fp32 scratch (statistics, pools, gradient accumulators) -------------------
 class _ZeroArena:
     """Hands out zero-filled fp32 buffers carved from 16 MB chunks that are zeroed by ONE fill kernel.
-    A training step needs ~90 small zero buffers (BN statistics replicas, SE pools, weight-gradient
-    accumulators for the atomics); as separate torch.zeros calls they were 91 fill launches = 0.44 ms of a
-    13.4 ms step on MI355X.  Every carved range is handed out once (the offset only advances), so it is
+    A training step needs ~90 small zero buffers (BN statistics slots, weight-gradient accumulators);
+    as separate torch.zeros calls they were 91 fill launches = 0.44 ms of a 13.4 ms step on MI355X.  Every carved range is handed out once (the offset only advances), so it is
     zero when handed out; a chunk is freed by the allocator when its last view dies."""
     CHUNK = 16 << 20                 # bytes
 
@@ -142,6 +141,63 @@ def _rows(t, name="activation"):
     if t.dim() != 2 or not t.is_contiguous():
         raise ValueError(f"{name}: expected a contiguous [M, C] matrix, got shape {tuple(t.shape)} strides {t.stride()}")
     return t
+
+
+# ------------------------------------------------------------------------------ fixed-order reduction of partials
+def _scratch(nbytes, device):
+    """Uninitialised fp32 workspace of at least `nbytes` (16-byte aligned: allocator blocks are 512-byte aligned)."""
+    return torch.empty(max(int(nbytes) // 4, 4), dtype=torch.float32, device=device)
+
+
+def partials_reduce(jobs, device):
+    """jobs: list of (part, out, n, stride, split, accumulate) - out[e] (+)= sum_s part[s*stride + e], slots in a fixed
+    order, ALL jobs in one launch (pb_partials_reduce)."""
+    arr = (_C.ReduceJob * len(jobs))()
+    keep = []
+    for i, (part, out, n, stride, split, acc) in enumerate(jobs):
+        arr[i].part, arr[i].out = part.data_ptr(), out.data_ptr()
+        arr[i].n, arr[i].stride, arr[i].split, arr[i].accumulate = int(n), int(stride), int(split), int(acc)
+        keep.append((part, out))
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    st = ctypes.c_void_p(torch.cuda.current_stream(idx).cuda_stream)
+    _launch("partials_reduce", sum(j[2] * 4 * (j[4] + 1) for j in jobs), "pb_partials_reduce", arr, len(jobs), idx, st)
+
+
+# A block's backward computes several weight gradients; each leaves per-workgroup partial tiles in a workspace.
+# Inside `deferred_reductions()` their fixed-order reductions are collected and issued as ONE launch at exit
+# (one launch per bottleneck instead of three).
+_deferred = threading.local()
+
+
+class deferred_reductions:
+    def __enter__(self):
+        self.prev = getattr(_deferred, "jobs", None)
+        _deferred.jobs = []
+        return self
+
+    def __exit__(self, *exc):
+        jobs, _deferred.jobs = _deferred.jobs, self.prev
+        if exc[0] is None and jobs:
+            flush = [(j.part, j.out, j.n, j.stride, j.split, j.accumulate) for j, _ in jobs]
+            arr = (_C.ReduceJob * len(jobs))(*[j for j, _ in jobs])
+            dev = jobs[0][1][0].device
+            idx = dev.index if dev.index is not None else torch.cuda.current_device()
+            st = ctypes.c_void_p(torch.cuda.current_stream(idx).cuda_stream)
+            _launch("partials_reduce", sum(f[2] * 4 * (f[4] + 1) for f in flush), "pb_partials_reduce", arr, len(jobs), idx, st)
+        return False
+
+
+def _defer_job():
+    """-> (ctypes job or None, byref argument): None when reductions are not being deferred."""
+    if getattr(_deferred, "jobs", None) is None:
+        return None, None
+    job = _C.ReduceJob()
+    return job, ctypes.byref(job)
+
+
+def _keep_job(job, *tensors):
+    if job is not None and job.split > 0:
+        _deferred.jobs.append((job, tensors))      # the workspace and the output stay alive until the flush
 
 
 # ------------------------------------------------------------------------------ pointwise conv
@@ -344,16 +400,18 @@ def pw_bwd_weight(dy, x, dw, *, in_scale=None, in_shift=None, in_act="none", in_
     affine = in_scale is not None or in_shift is not None or in_act != "none"
     se_inloop = row_scale is not None and (rows_per_group < 64 or M % max(rows_per_group, 1))
     family = "pw_wgrad_kernel" if not big else ("pw_wgrad128_kernel" if (affine or se_inloop) else "pw_wgrad128_dma_kernel")
-    # workspace for the row ranges' partial tiles (plain stores + a reduction instead of 16 K float atomics per workgroup)
+    # workspace for the row ranges' partial tiles (plain stores + a fixed-order reduction: no atomics anywhere)
     key = (M, K, N, x.dtype, affine, row_scale is not None, int(rows_per_group), dev)
     nws = _ws_bytes.get(key)
     if nws is None:
         nws = _ws_bytes[key] = int(_C.load().pb_pwconv_bwd_weight_ws_bytes(M, K, N, _dt(x), int(affine), int(row_scale is not None),
                                                                            int(rows_per_group), dev))
-    ws = torch.empty(nws // 4, dtype=torch.float32, device=x.device) if nws and dw.data_ptr() % 16 == 0 else None
+    ws = _scratch(nws, x.device)
+    job, jref = _defer_job()
     _launch(family, _nb(dy, x, dw), "pb_pwconv_bwd_weight_ws", _p(dy), _p(x), _p(dw), M, K, N, _dt(x), _p(in_scale), _p(in_shift),
-            ACT[in_act], float(in_slope), _p(row_scale), int(rows_per_group), _p(ws), nws if ws is not None else 0, dev, st,
+            ACT[in_act], float(in_slope), _p(row_scale), int(rows_per_group), _p(ws), ws.numel() * 4, jref, dev, st,
             detail=f"M{M} K{K} N{N}")
+    _keep_job(job, ws, dw)
     return dw
 
 
@@ -388,7 +446,8 @@ def _ndhwc(t, name):
 
 
 def dw_fwd(x, w, kernel, stride, pad_front, pad_back=None, pool=None):
-    """x [N,T,H,W,C] -> y [N,To,Ho,Wo,C]; w fp32 [C, kt*kh*kw]; pool fp32 [N,C] += sum_THW(y)."""
+    """x [N,T,H,W,C] -> y [N,To,Ho,Wo,C]; w fp32 [C, kt*kh*kw]; pool fp32 [N,C] = sum_THW(y) (overwritten).
+    The kernels write one partial sum per work unit (no atomics); the units are added up in a fixed order."""
     _ndhwc(x, "x")
     N, T, H, W, C = x.shape
     taps = kernel[0] * kernel[1] * kernel[2]
@@ -400,8 +459,14 @@ def dw_fwd(x, w, kernel, stride, pad_front, pad_back=None, pool=None):
     y = torch.empty((N,) + out + (C,), dtype=x.dtype, device=x.device)
     s = _dw_shape(N, C, (T, H, W), out, kernel, stride, pad_front)
     dev, st = _dev_stream(x)
-    _launch(_dw_kernel_name(0, s, _dt(x)), _nb(x, y, w), "pb_dwconv3d_fwd", _p(x), _p(w), _p(y), ctypes.byref(s), _dt(x), _p(pool), dev, st,
-            detail=f"C{C} {T}x{H}x{W}->{out[0]}x{out[1]}x{out[2]} k{kernel} s{stride}")
+    part, slots = None, 0
+    if pool is not None:
+        slots = int(_C.load().pb_dwconv3d_pool_slots(ctypes.byref(s), _dt(x)))
+        part = pool.view(1, N, C) if slots == 1 else torch.empty((slots, N, C), dtype=torch.float32, device=x.device)
+    _launch(_dw_kernel_name(0, s, _dt(x)), _nb(x, y, w), "pb_dwconv3d_fwd", _p(x), _p(w), _p(y), ctypes.byref(s), _dt(x), _p(part), slots,
+            dev, st, detail=f"C{C} {T}x{H}x{W}->{out[0]}x{out[1]}x{out[2]} k{kernel} s{stride}")
+    if pool is not None and slots > 1:
+        partials_reduce([(part, pool, N * C, N * C, slots, 0)], x.device)
     return y
 
 
@@ -427,8 +492,11 @@ def dw_bwd_weight(dy, x, dw, kernel, stride, pad_front, g_scale=None, g_shift=No
     _f32(g_scale, (N, C), "g_scale"); _f32(g_shift, (N, C), "g_shift")
     s = _dw_shape(N, C, tuple(x.shape[1:4]), (To, Ho, Wo), kernel, stride, pad_front)
     dev, st = _dev_stream(dy)
-    _launch(_dw_kernel_name(2, s, _dt(dy)), _nb(dy, x, dw), "pb_dwconv3d_bwd_weight", _p(dy), _p(x), _p(dw), ctypes.byref(s), _dt(dy), _p(g_scale), _p(g_shift), dev, st,
-            detail=f"C{C} {tuple(x.shape[1:4])}->{To}x{Ho}x{Wo} k{kernel} s{stride}")
+    ws = _scratch(_C.load().pb_dwconv3d_bwd_weight_ws_bytes(ctypes.byref(s), _dt(dy)), dy.device)
+    job, jref = _defer_job()
+    _launch(_dw_kernel_name(2, s, _dt(dy)), _nb(dy, x, dw), "pb_dwconv3d_bwd_weight", _p(dy), _p(x), _p(dw), ctypes.byref(s), _dt(dy), _p(g_scale), _p(g_shift),
+            _p(ws), ws.numel() * 4, jref, dev, st, detail=f"C{C} {tuple(x.shape[1:4])}->{To}x{Ho}x{Wo} k{kernel} s{stride}")
+    _keep_job(job, ws, dw)
     return dw
 
 
@@ -480,8 +548,9 @@ def stem_bwd_weight(dy, x, dw, dbias, kernel, stride, pad, x_scale=1.0):
     _f32(dw, (cout, x.shape[1], *kernel), "dw"); _f32(dbias, (cout,), "dbias")
     s = _stem_shape(x, cout, tuple(dy.shape[1:4]), kernel, stride, pad)
     dev, st = _dev_stream(dy)
+    ws = _scratch(_C.load().pb_stem_conv3d_bwd_weight_ws_bytes(ctypes.byref(s), _XDT[x.dtype], float(x_scale), _dt(dy)), dy.device)
     _launch(_stem_kernel_name("wgrad", x, dw.shape[0], kernel, stride, pad, dy.dtype, x_scale), _nb(dy, x, dw), "pb_stem_conv3d_bwd_weight", _p(dy), _p(x), _XDT[x.dtype], float(x_scale), _p(dw), _p(dbias),
-            ctypes.byref(s), _dt(dy), dev, st)
+            ctypes.byref(s), _dt(dy), _p(ws), ws.numel() * 4, dev, st)
     return dw
 
 
@@ -494,16 +563,20 @@ def chan_stats(x, stats):
     return stats
 
 
-def bn_finalize(stats, count, gamma, beta, eps, momentum, running_mean, running_var, use_running, C, device):
-    """-> (scale, shift, mean, rstd), each fp32 [C]; running stats updated in place when training."""
+def bn_finalize(stats, count, gamma, beta, eps, momentum, running_mean, running_var, use_running, C, device,
+                num_batches_tracked=None):
+    """-> (scale, shift, mean, rstd), each fp32 [C]; running stats (and nn.BatchNorm's int64 step counter) updated in
+    place when training."""
+    if num_batches_tracked is not None and (num_batches_tracked.dtype != torch.int64 or num_batches_tracked.numel() != 1):
+        raise TypeError("bn_finalize: num_batches_tracked must be a 1-element int64 tensor")
     _f32(stats, (REPL, 2, C), "stats"); _f32(gamma, (C,), "gamma"); _f32(beta, (C,), "beta")
     _f32(running_mean, (C,), "running_mean"); _f32(running_var, (C,), "running_var")
     out = torch.empty((4, C), dtype=torch.float32, device=device)
     ref = stats if stats is not None else running_mean
     dev, st = _dev_stream(ref)
     _launch("bn_finalize", _nb(out), "pb_bn_finalize", _p(stats), float(count), _p(gamma), _p(beta), float(eps), float(momentum),
-            _p(running_mean), _p(running_var), int(use_running), _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]),
-            C, dev, st)
+            _p(running_mean), _p(running_var), _p(None if use_running else num_batches_tracked), int(use_running), _p(out[0]),
+            _p(out[1]), _p(out[2]), _p(out[3]), C, dev, st)
     return out[0], out[1], out[2], out[3]
 
 
@@ -589,7 +662,8 @@ def affine2(g, z, A, B=None, Cc=None, mean=None, row_scale=None, rows_per_group=
 
 
 def rowgroup_reduce(a, b, G):
-    """out[G,C] = per-group sum over rows of a (b None) or a*b; a is [G*R, C]."""
+    """out[G,C] = per-group sum over rows of a (b None) or a*b; a is [G*R, C].  Per-workgroup partial rows in a
+    workspace, added in a fixed order (no atomics)."""
     _rows(a, "a")
     M, C = a.shape
     if M % G:
@@ -598,9 +672,12 @@ def rowgroup_reduce(a, b, G):
         _rows(b, "b")
         if b.shape != a.shape or b.dtype != a.dtype:
             raise ValueError("rowgroup_reduce: a/b mismatch")
-    out = zeros((G, C), a.device)
+    out = torch.empty((G, C), dtype=torch.float32, device=a.device)
     dev, st = _dev_stream(a)
-    _launch("rowgroup_kernel", _nb(a, b, out), "pb_rowgroup_reduce", _p(a), _p(b), _p(out), G, M // G, C, _dt(a), dev, st, detail=f"M{M} C{C} G{G}")
+    nws = int(_C.load().pb_rowgroup_reduce_ws_bytes(G, M // G, C, _dt(a)))
+    ws = _scratch(nws, a.device) if nws else None
+    _launch("rowgroup_kernel", _nb(a, b, out), "pb_rowgroup_reduce", _p(a), _p(b), _p(out), G, M // G, C, _dt(a), _p(ws), nws, dev, st,
+            detail=f"M{M} C{C} G{G}")
     return out
 
 
@@ -704,13 +781,10 @@ def conv3d_bwd_weight(dy, x, kernel, stride, pad_front):
     s = _conv_shape(N, cin, cout, tuple(x.shape[1:4]), (To, Ho, Wo), kernel, stride, pad_front)
     dev, st = _dev_stream(x)
     nws = int(_C.load().pb_conv3d_bwd_weight_ws_bytes(ctypes.byref(s), _dt(x), dev))
-    if nws:
-        ws = torch.empty(nws // 4, dtype=torch.float32, device=x.device)
-        _launch("conv3d_wgrad_dma_kernel", _nb(dy, x, dwp), "pb_conv3d_bwd_weight_ws", _p(dy), _p(x), _p(dwp), ctypes.byref(s), _dt(x),
-                _p(ws), nws, _p(zeros(8, x.device)), dev, st, detail=f"Cin{cin} Cout{cout} {tuple(x.shape[1:4])} k{kernel}")
-        return dwp
-    _launch("pw_wgrad_kernel<conv>", _nb(dy, x, dwp), "pb_conv3d_bwd_weight", _p(dy), _p(x), _p(dwp), ctypes.byref(s), _dt(x), dev, st,
-            detail=f"Cin{cin} Cout{cout} {tuple(x.shape[1:4])} k{kernel}")
+    ws = _scratch(nws, x.device)
+    family = "conv3d_wgrad_dma_kernel" if (x.dtype == torch.bfloat16 and cin % 8 == 0 and cout % 8 == 0) else "pw_wgrad_kernel<conv>"
+    _launch(family, _nb(dy, x, dwp), "pb_conv3d_bwd_weight_ws", _p(dy), _p(x), _p(dwp), ctypes.byref(s), _dt(x),
+            _p(ws), ws.numel() * 4, _p(zeros(8, x.device)), dev, st, detail=f"Cin{cin} Cout{cout} {tuple(x.shape[1:4])} k{kernel}")
     return dwp
 
 

@@ -23,7 +23,7 @@ def test_library_builds_loads_and_exports_header_symbols():
     assert len(names) >= 18
     for n in names:
         assert hasattr(lib, n), f"{n} declared in the header but not exported"
-    assert set(names) == set(_C.SIGNATURES) | set(_C.STRING_SIGNATURES) | set(_C.SIZE_SIGNATURES) | {"pb_last_error", "pb_abi_version"}
+    assert set(names) == set(_C.SIGNATURES) | set(_C.STRING_SIGNATURES) | set(_C.SIZE_SIGNATURES) | set(_C.COUNT_SIGNATURES) | {"pb_last_error", "pb_abi_version"}
     assert lib.pb_abi_version() == _C.ABI_VERSION
 
 

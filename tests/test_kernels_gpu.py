@@ -64,7 +64,7 @@ def test_pw_fwd_prologue_epilogue_stats(K, M, Kd, N, G, dtype):
               out_shift=rnd((N,), seed=8) * 0.1, out_act="relu")
     st_ref = torch.zeros(R.REPL, 2, N)
     want = R.pw_fwd(x, w, stats=st_ref, **kw)
-    st = torch.zeros(R.REPL, 2, N, device=DEV)
+    st = torch.zeros(K.REPL, 2, N, device=DEV)
     got = K.pw_fwd(dev(x), dev(w), stats=st, **{k: (dev(v) if torch.is_tensor(v) else v) for k, v in kw.items()})
     check("pw_fwd_fused", got, want, dtype)
     check("pw_fwd_stats", st.sum(0), st_ref.sum(0), dtype)
@@ -94,7 +94,7 @@ def test_pw_fwd_training_projection(K, M, Kd, N, G, dtype):
     rs = torch.rand(G, Kd) + 0.5
     st_ref = torch.zeros(R.REPL, 2, N)
     want = R.pw_fwd(x, w, row_scale=rs, rows_per_group=M // G, stats=st_ref)
-    st = torch.zeros(R.REPL, 2, N, device=DEV)
+    st = torch.zeros(K.REPL, 2, N, device=DEV)
     got = K.pw_fwd(dev(x), dev(w), row_scale=dev(rs), rows_per_group=M // G, stats=st)
     check("pw_fwd_se", got, want, dtype)
     check("pw_fwd_se_stats", st.sum(0), st_ref.sum(0), dtype)
@@ -209,7 +209,7 @@ def test_stem_bf16_wide_rows(K, kernel, stride, pad, bias):
     x = base.permute(0, 4, 1, 2, 3)
     w = rnd((Cout, 3, *kernel), seed=27, scale=0.2)
     b = rnd((Cout,), seed=28, scale=0.1) if bias else None
-    st_ref, st = torch.zeros(R.REPL, 2, Cout), torch.zeros(R.REPL, 2, Cout, device=DEV)
+    st_ref, st = torch.zeros(R.REPL, 2, Cout), torch.zeros(K.REPL, 2, Cout, device=DEV)
     y_ref = R.stem_fwd(x, w, b, kernel, stride, pad, torch.bfloat16, 1.0, st_ref)
     xd = base.to(DEV).permute(0, 4, 1, 2, 3)
     y = K.stem_fwd(xd, dev(w), dev(b), kernel, stride, pad, torch.bfloat16, 1.0, st)
@@ -242,7 +242,7 @@ def test_stem(K, dtype, xdtype, layout, kernel, stride, pad, bias):
         x = x.contiguous()
     w = rnd((Cout, 3, *kernel), seed=17, scale=0.2)
     b = rnd((Cout,), seed=18, scale=0.1) if bias else None
-    st_ref, st = torch.zeros(R.REPL, 2, Cout), torch.zeros(R.REPL, 2, Cout, device=DEV)
+    st_ref, st = torch.zeros(R.REPL, 2, Cout), torch.zeros(K.REPL, 2, Cout, device=DEV)
     y_ref = R.stem_fwd(x, w, b, kernel, stride, pad, dtype, scale, st_ref)
     xd = base.to(DEV).permute(0, 4, 1, 2, 3)
     if layout == "ncdhw":
@@ -265,7 +265,7 @@ def test_stem(K, dtype, xdtype, layout, kernel, stride, pad, bias):
                                    (5 * 7, 2048, 5)])
 def test_norm_act_family(K, M, C, G, dtype):
     x = rnd((M, C), dtype, 20)
-    st_ref, st = torch.zeros(R.REPL, 2, C), torch.zeros(R.REPL, 2, C, device=DEV)
+    st_ref, st = torch.zeros(R.REPL, 2, C), torch.zeros(K.REPL, 2, C, device=DEV)
     R.chan_stats(x, st_ref); K.chan_stats(dev(x), st)
     check("chan_stats", st.sum(0), st_ref.sum(0), dtype)
     gamma, beta = rnd((C,), seed=21) * 0.1 + 1, rnd((C,), seed=22) * 0.1
@@ -280,13 +280,13 @@ def test_norm_act_family(K, M, C, G, dtype):
     scale, shift, mean, rstd = out_ref
     rs, rsh = torch.rand(G, C) + 0.5, rnd((G, C), seed=24) * 0.1
     for act in ("none", "relu", "leaky_relu", "hardswish", "silu", "hardsigmoid"):
-        s2_ref, s2 = torch.zeros(R.REPL, 2, C), torch.zeros(R.REPL, 2, C, device=DEV)
+        s2_ref, s2 = torch.zeros(R.REPL, 2, C), torch.zeros(K.REPL, 2, C, device=DEV)
         y_ref = R.affine_act_fwd(x, scale, shift, act, 0.01, rs, M // G, s2_ref, rsh, mean=mean)
         y = K.affine_act_fwd(dev(x), dev(scale), dev(shift), act, 0.01, dev(rs), M // G, s2, dev(rsh), mean=dev(mean))
         check("affine_act_" + act, y, y_ref, dtype)
         check("affine_act_stats_" + act, s2.sum(0), s2_ref.sum(0), dtype, 2.0)
         dy = rnd((M, C), dtype, 25)
-        sm_ref, sm = torch.zeros(R.REPL, 2, C), torch.zeros(R.REPL, 2, C, device=DEV)
+        sm_ref, sm = torch.zeros(R.REPL, 2, C), torch.zeros(K.REPL, 2, C, device=DEV)
         g_ref = R.act_bwd_reduce(dy, x, scale=scale, shift=shift, act=act, slope=0.01, row_scale=rs, rows_per_group=M // G,
                                  mean=mean, rstd=rstd, sums=sm_ref)
         g = K.act_bwd_reduce(dev(dy), dev(x), scale=dev(scale), shift=dev(shift), act=act, slope=0.01, row_scale=dev(rs),
@@ -295,7 +295,7 @@ def test_norm_act_family(K, M, C, G, dtype):
         check("act_bwd_sums_" + act, sm.sum(0), sm_ref.sum(0), dtype, 3.0)
     # broadcast gradient (pool backward)
     dyb = rnd((G, C), dtype, 26)
-    sm_ref, sm = torch.zeros(R.REPL, 2, C), torch.zeros(R.REPL, 2, C, device=DEV)
+    sm_ref, sm = torch.zeros(R.REPL, 2, C), torch.zeros(K.REPL, 2, C, device=DEV)
     g_ref = R.act_bwd_reduce(dyb, x, scale=scale, shift=shift, act="hardswish", dy_rows_per_group=M // G, dy_mul=0.25,
                              mean=mean, rstd=rstd, sums=sm_ref)
     g = K.act_bwd_reduce(dev(dyb), dev(x), scale=dev(scale), shift=dev(shift), act="hardswish", dy_rows_per_group=M // G,
@@ -308,7 +308,7 @@ def test_norm_act_family(K, M, C, G, dtype):
     A, B, Cc = fin_ref[:3]
     check("affine2", K.affine2(dev(g_ref), dev(x), dev(A), dev(B), dev(Cc), dev(mean)), R.affine2(g_ref, x, A, B, Cc, mean), dtype)
     # the bottleneck's BatchNorm backward: sums without materialising g, mask applied by the final pass
-    sm_ref, sm = torch.zeros(R.REPL, 2, C), torch.zeros(R.REPL, 2, C, device=DEV)
+    sm_ref, sm = torch.zeros(R.REPL, 2, C), torch.zeros(K.REPL, 2, C, device=DEV)
     assert R.act_bwd_reduce(dy, x, scale=scale, shift=shift, row_scale=rs, rows_per_group=M // G, mean=mean, rstd=rstd,
                             sums=sm_ref, want_g=False) is None
     assert K.act_bwd_reduce(dev(dy), dev(x), scale=dev(scale), shift=dev(shift), row_scale=dev(rs), rows_per_group=M // G,
@@ -379,7 +379,7 @@ def test_conv3d_dense(K, N, Cin, Cout, thw, kernel, stride, pad, dtype):
     wp_ref = R.conv_weight_prep(w.reshape(-1), 0, Cout, Cin, taps)
     wp = K.conv_weight_prep(dev(w).reshape(-1), 0, Cout, Cin, taps)
     check("conv_prep0", wp, wp_ref, torch.float32)
-    st_ref, st = torch.zeros(R.REPL, 2, Cout), torch.zeros(R.REPL, 2, Cout, device=DEV)
+    st_ref, st = torch.zeros(R.REPL, 2, Cout), torch.zeros(K.REPL, 2, Cout, device=DEV)
     y_ref = R.conv3d_fwd(x, wp_ref, Cout, kernel, stride, pad, out_thw, out_shift=bias, stats=st_ref)
     y = K.conv3d_fwd(dev(x), wp, Cout, kernel, stride, pad, out_thw, out_shift=dev(bias), stats=st)
     check("conv3d_fwd", y, y_ref, dtype)
