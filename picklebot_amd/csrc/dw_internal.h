@@ -51,7 +51,7 @@ PB_HIDDEN bool pb_dw_rows_eligible(const pb_dwconv_shape* s, bool wgrad);
 PB_HIDDEN int pb_dw_rows_pool_slots(const pb_dwconv_shape* s);
 PB_HIDDEN int pb_dw_rows_fwd(const void* src, const float* w, void* dst, const pb_dwconv_shape* s, pb_dtype dtype, int flip,
                              const float* g_scale, const float* g_shift, float* pool, hipStream_t st);
-PB_HIDDEN int64_t pb_dw_rows_wgrad_slots(const pb_dwconv_shape* s);
+PB_HIDDEN int64_t pb_dw_rows_wgrad_slots(const pb_dwconv_shape* s, pb_dtype dtype);
 PB_HIDDEN int pb_dw_rows_wgrad(const void* dy, const void* x, float* part, const pb_dwconv_shape* s, pb_dtype dtype,
                                const float* g_scale, const float* g_shift, hipStream_t st, int64_t* slots);
 

@@ -408,7 +408,12 @@ int64_t rows_wgrad_geom(RowsWgArgs& a, int K, int WSEG, int64_t* slots) {
   return blocks;
 }
 
-template <typename T, int K, int S, bool NARROW = false>
+// fp32 always takes the half-width segments: the full-width fp32 instantiations need 358-368 registers, and hipcc
+// (ROCm 7.2) then splits live ranges into AGPRs with the save placed in a control-flow join block AHEAD of the exec
+// restore - lanes that skipped the branch never save their value and later read back whatever the previous kernel left
+// in that AGPR (observed on MI355X: the frame counter of dw_rows_wgrad_kernel<float,3,1,14>, i.e. waves that never
+// leave the frame loop, depending on which kernels ran before).  tools/lint_isa.py scans the ISA for that pattern.
+template <typename T, int K, int S, bool NARROW = (sizeof(T) == 4)>
 int launch_rows_wgrad(RowsWgArgs a, hipStream_t st, int64_t* slots) {
   constexpr int WSEG = NARROW ? wseg_narrow(K, S) : wseg_of(K, S);
   if constexpr (!NARROW) {
@@ -433,13 +438,14 @@ bool pb_dw_rows_eligible(const pb_dwconv_shape* s, bool wgrad) {
 }
 
 // number of partial gradients [C][k*k] pb_dw_rows_wgrad writes for this shape (0: shape not taken)
-int64_t pb_dw_rows_wgrad_slots(const pb_dwconv_shape* s) {
+int64_t pb_dw_rows_wgrad_slots(const pb_dwconv_shape* s, pb_dtype dtype) {
   if (!pb_dw_rows_eligible(s, true)) return 0;
   RowsWgArgs a = {};
   a.N = s->N; a.C = s->C; a.Tdst = s->To; a.Hd = s->Ho; a.Wd = s->Wo;
   const int K = s->kh, S = s->sh;
   int64_t slots = 0;
-  rows_wgrad_geom(a, K, rows_wgrad_narrow(K, S, a.C) ? wseg_narrow(K, S) : wseg_of(K, S), &slots);
+  const bool narrow = dtype == PB_F32 || rows_wgrad_narrow(K, S, a.C);      // as launch_rows_wgrad
+  rows_wgrad_geom(a, K, narrow ? wseg_narrow(K, S) : wseg_of(K, S), &slots);
   return slots;
 }
 

@@ -1057,7 +1057,7 @@ int64_t gen_wgrad_gx(const pb_dwconv_shape* s, int* ch_o, int* cvb_o, int* P_o, 
 // partial gradients [slots][C][taps] the weight-gradient dispatch writes for this shape
 int64_t wgrad_slots(const pb_dwconv_shape* s, pb_dtype dtype) {
   if (int64_t n = pb_dw7_wgrad_slots(s)) return n;
-  if (int64_t n = pb_dw_rows_wgrad_slots(s)) return n;
+  if (int64_t n = pb_dw_rows_wgrad_slots(s, dtype)) return n;
   if (int64_t n = pb_dw_tile_wgrad_slots(s, dtype)) return n;
   if (strip_ok(*s)) {
     StripArgs a = strip_wgrad_args(nullptr, nullptr, nullptr, s, nullptr, nullptr);

@@ -1279,14 +1279,17 @@ int launch_gemm(const PwArgs& a0, int device, hipStream_t st) {
   const bool aligned = (a.K % VEC) == 0 && (a.N % VEC) == 0 && (a.ldw % 4) == 0;
   const bool pro = a.in_scale || a.in_shift || a.in_act != PB_ACT_NONE || a.row_scale;
   // the generic (unaligned) path exists for the tiny classifier-sized problems: one tile width only
-  const int nt = aligned ? pick_nt(a.N, sizeof(T) == 4) : 8;
+  // (fp32: 4 column tiles - the 8-tile unaligned fp32 instantiation needs 328 registers and trips the AGPR-save-ahead-of-
+  // the-exec-restore code generation that tools/lint_isa.py looks for)
+  constexpr int UNT = sizeof(T) == 4 ? 4 : 8;
+  const int nt = aligned ? pick_nt(a.N, sizeof(T) == 4) : UNT;
   a.n_tiles = (int)pb_cdiv(a.N, nt * 16);
   a.m_tiles = pb_cdiv(a.M, BM);
   const int64_t total = a.n_tiles == 1 ? a.m_tiles : pb_cdiv(a.m_tiles, 8) * 8 * a.n_tiles;
   if (total > 0x3fffffffLL) { pb_set_error("pb_pwconv_fwd: too many tiles"); return 1; }
   if (!aligned) {
-    if (a.w_transposed) launch_one<T, 8, true, false, true>(a, total, device, st);
-    else launch_one<T, 8, false, false, true>(a, total, device, st);
+    if (a.w_transposed) launch_one<T, UNT, true, false, true>(a, total, device, st);
+    else launch_one<T, UNT, false, false, true>(a, total, device, st);
     return 0;
   }
   switch (nt) {

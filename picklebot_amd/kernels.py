@@ -96,8 +96,16 @@ def _nb(*ts):
     return sum(t.numel() * t.element_size() for t in ts if t is not None)
 
 
+_SYNC_DEBUG = os.environ.get("PB_SYNC_DEBUG", "0") != "0"    # print every launch and synchronise after it (fault / hang hunting)
+
+
 def _launch(family, nbytes, fn, *args, detail=""):
     """Algorithmic bytes = every external input/output tensor once at its stored dtype."""
+    if _SYNC_DEBUG:
+        print(f"[pb] {fn} {family} {detail}", flush=True)
+        _C.call(fn, *args)
+        torch.cuda.synchronize()
+        return
     if _spans is None:
         _C.call(fn, *args)
         return
@@ -146,7 +154,15 @@ def _rows(t, name="activation"):
 # ------------------------------------------------------------------------------ fixed-order reduction of partials
 def _scratch(nbytes, device):
     """Uninitialised fp32 workspace of at least `nbytes` (16-byte aligned: allocator blocks are 512-byte aligned)."""
+    pad = int(os.environ.get("PB_SCRATCH_PAD", "0"))
+    if pad:      # diagnostic: sentinel-filled slack behind the workspace (tools/probe_block.py checks it)
+        t = torch.full((max(int(nbytes) // 4, 4) + pad // 4,), 12345.0, dtype=torch.float32, device=device)
+        _pads.append(t[max(int(nbytes) // 4, 4):])
+        return t[:max(int(nbytes) // 4, 4)]
     return torch.empty(max(int(nbytes) // 4, 4), dtype=torch.float32, device=device)
+
+
+_pads = []
 
 
 def partials_reduce(jobs, device):
@@ -189,7 +205,7 @@ class deferred_reductions:
 
 def _defer_job():
     """-> (ctypes job or None, byref argument): None when reductions are not being deferred."""
-    if getattr(_deferred, "jobs", None) is None:
+    if getattr(_deferred, "jobs", None) is None or os.environ.get("PB_DEFER", "1") == "0":
         return None, None
     job = _C.ReduceJob()
     return job, ctypes.byref(job)

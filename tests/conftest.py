@@ -110,3 +110,9 @@ def golden():
             cache[name] = load_golden(name)
         return cache[name]
     return get
+
+
+def golden_mode(gold, mode):
+    """Sub-dictionary of a grad_<case>.npz fixture for one protocol mode ("evalgrad" / "train8"), prefix stripped."""
+    p = mode + "/"
+    return {k[len(p):]: v for k, v in gold.items() if k.startswith(p)}

@@ -14,7 +14,7 @@ import pytest
 import torch
 
 import picklebot_amd
-from conftest import check_model_result, compare_full, rel_err
+from conftest import check_model_result, compare_full, golden_mode, rel_err
 from oracle import formula, protocol
 
 pytestmark = pytest.mark.gpu
@@ -106,6 +106,50 @@ def test_model_bf16_autocast_vs_golden(case, golden):
     q50, q90 = np.percentile(ratios, 50), np.percentile(ratios, 90)
     print(f"[{case}] bf16 gradient error ratio vs reference bf16 path: median {q50:.2f}, p90 {q90:.2f}, max {max(ratios):.2f}")
     assert q50 <= 1.25 and q90 <= 3.0, (q50, q90)
+
+
+GRADS = [c for c in protocol.GRAD_CASES if c in MODELS]
+# train mode at batch 8: the reference's own fp32 run is within 2.5e-4 of its fp64 run for four of the five models, so
+# the flat north_star tolerance is asserted with nothing widened.  MobileNetLarge3D stays ill-conditioned in train mode
+# even at batch 8 (reference fp32 vs fp64: median 3.5e-2 per gradient tensor - BatchNorm over the 8 x T x 4 x 4 frames of
+# its last stages): its train-mode bound keeps the multiple of the reference's own deviation, its eval-mode gradients
+# (reference deviation 4e-6) carry the flat 1e-3.
+FLAT_TRAIN8 = [c for c in GRADS if c != "large3d"]
+
+
+@pytest.mark.parametrize("case", GRADS)
+def test_gradients_evalmode_fp32_flat_1e3(case, golden):
+    """Eval-mode (running-statistics BatchNorm) logits, loss and per-parameter gradients (norm, full-tensor projections,
+    sampled elements) within a FLAT 1e-3 of the reference's fp64 values: no widening by the reference's deviation."""
+    with contextlib.redirect_stdout(io.StringIO()):
+        res = protocol.run_grad_case(picklebot_amd, case, "evalgrad", device=DEV)
+    bad, worst = check_model_result(res, golden_mode(golden("grad_" + case), "evalgrad"), 1e-3, 1e-3, dev="ref32_err", factor=0.0,
+                                    samp_factor=4.0)
+    assert not bad, f"{len(bad)} keys off, first {bad[:5]}, worst {worst}"
+
+
+@pytest.mark.parametrize("case", GRADS)
+def test_gradients_train8_fp32(case, golden):
+    with contextlib.redirect_stdout(io.StringIO()):
+        res = protocol.run_grad_case(picklebot_amd, case, "train8", device=DEV)
+    factor = 0.0 if case in FLAT_TRAIN8 else 4.0
+    bad, worst = check_model_result(res, golden_mode(golden("grad_" + case), "train8"), 1e-3, 1e-3, dev="ref32_err", factor=factor,
+                                    samp_factor=4.0)
+    assert not bad, f"{len(bad)} keys off, first {bad[:5]}, worst {worst}"
+
+
+@pytest.mark.parametrize("mode", ["evalgrad", "train8"])
+@pytest.mark.parametrize("case", GRADS)
+def test_gradients_bf16_per_tensor(case, mode, golden):
+    """bf16 autocast (train.py:264), PER TENSOR (norm and every full-tensor projection of every parameter gradient; no
+    median): within max(1e-2, 2 x the reference's own bf16-autocast deviation from fp64 for that tensor).  The reference's
+    own bf16 gradients are 0.8-4e-2 off in eval mode and 15-60 % off in train mode at batch 8, so a flat 1e-2 is a bar
+    the reference does not meet against itself; twice its own deviation is."""
+    with contextlib.redirect_stdout(io.StringIO()):
+        res = protocol.run_grad_case(picklebot_amd, case, mode, device=DEV, autocast=True)
+    res = {k: v for k, v in res.items() if not k.startswith("gsamp/")}
+    bad, worst = check_model_result(res, golden_mode(golden("grad_" + case), mode), 1e-2, 1e-2, dev="refbf16_err", factor=2.0)
+    assert not bad, f"{len(bad)} keys off, first {bad[:5]}, worst {worst}"
 
 
 def _large(n, dtype=torch.bfloat16):

@@ -7,7 +7,7 @@ import io
 
 import pytest
 
-from conftest import check_model_result, compare_full, rel_err
+from conftest import check_model_result, compare_full, golden_mode, rel_err
 from oracle import protocol, torch_ref
 
 TOL = 1e-5
@@ -19,6 +19,20 @@ def test_model_matches_reference_golden(case, golden):
         res = protocol.run_model_case(torch_ref, case)
     gold = golden("model_" + case)
     expected = {k for k in gold if k.split("/")[0] not in ("meta", "ref32_err", "refbf16_err")}
+    assert set(res) == expected
+    bad, worst = check_model_result(res, gold, TOL, TOL)
+    assert not bad, f"{len(bad)} keys off, first {bad[:5]}, worst {worst}"
+
+
+@pytest.mark.parametrize("mode", ["evalgrad", "train8"])
+@pytest.mark.parametrize("case", list(protocol.GRAD_CASES))
+def test_gradient_fixtures_match_reference_golden(case, mode, golden):
+    """The well-conditioned gradient fixtures (eval-mode BatchNorm; train mode at batch 8): the oracle restatement against
+    the real reference's fp64 values."""
+    with contextlib.redirect_stdout(io.StringIO()):
+        res = protocol.run_grad_case(torch_ref, case, mode)
+    gold = golden_mode(golden("grad_" + case), mode)
+    expected = {k for k in gold if k.split("/")[0] not in ("ref32_err", "refbf16_err")}
     assert set(res) == expected
     bad, worst = check_model_result(res, gold, TOL, TOL)
     assert not bad, f"{len(bad)} keys off, first {bad[:5]}, worst {worst}"
