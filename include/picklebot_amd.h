@@ -41,11 +41,12 @@ typedef enum {
  * result per workgroup (or work unit) in a "slot" of its own, and a consumer adds the slots in an order that depends
  * only on the shapes.
  *
- * Per-channel statistics buffers (`stats`, `sums` below) are PB_STAT_SLOTS slots of [2][C] fp32, layout
- * [slot][2][C], ZERO-FILLED by the caller.  Workgroup b of a producing launch adds its partial sums into slot b with
- * plain read-modify-writes (the launchers keep their grids <= PB_STAT_SLOTS); pb_bn_finalize / pb_bn_bwd_finalize
- * add the slots up in index order (in double). */
-#define PB_STAT_SLOTS 1024
+ * Per-channel statistics buffers (`stats`, `sums` below) are `slots` slots of [2][C] fp32, layout [slot][2][C],
+ * ZERO-FILLED by the caller; slots = PB_STAT_SLOTS unless the entry takes a slot count (the stem, whose launch wants
+ * more workgroups).  Workgroup b of a producing launch adds its partial sums into slot b with plain read-modify-writes
+ * (the launchers keep their grids <= slots); pb_bn_finalize / pb_bn_bwd_finalize add the slots up in a fixed order
+ * (in double). */
+#define PB_STAT_SLOTS 512
 int pb_abi_version(void);
 /* Last error message of the calling thread ("" if none). */
 const char* pb_last_error(void);
@@ -201,7 +202,7 @@ const char* pb_dwconv3d_kernel_name(const pb_dwconv_shape* s, pb_dtype dtype, in
  * The input is addressed through element strides, so both the NDHWC view train.py:106 produces and
  * a plain contiguous NCDHW tensor are read in place.  x_dtype: PB_F32 / PB_BF16 or 2 = uint8 (the
  * raw dataloader clip, scaled by x_scale = 1/255 on load: SURVEY.md 8f rank 2).
- * y [N,To,Ho,Wo,Cout] in `dtype`; Cout <= 32; stats as in pb_pwconv_fwd. */
+ * y [N,To,Ho,Wo,Cout] in `dtype`; Cout <= 32; stats [stat_slots][2][Cout] as in pb_pwconv_fwd (stat_slots >= 1). */
 typedef struct {
   int N, Cin, Cout;
   int Ti, Hi, Wi;
@@ -213,7 +214,7 @@ typedef struct {
 } pb_stem_shape;
 
 int pb_stem_conv3d_fwd(const void* x, int x_dtype, float x_scale, const float* w, const float* bias, void* y,
-                       const pb_stem_shape* s, pb_dtype dtype, float* stats, int device, void* stream);
+                       const pb_stem_shape* s, pb_dtype dtype, float* stats, int stat_slots, int device, void* stream);
 /* dw[Cout][Cin][kt][kh][kw] += ..., dbias[Cout] += sum dy (dbias may be NULL): per-workgroup partials in `ws`
  * (pb_stem_conv3d_bwd_weight_ws_bytes) added in a fixed order. */
 int64_t pb_stem_conv3d_bwd_weight_ws_bytes(const pb_stem_shape* s, int x_dtype, float x_scale, pb_dtype dtype);
@@ -233,7 +234,7 @@ int pb_chan_stats(const void* x, int64_t M, int C, pb_dtype dtype, float* stats,
  * Outputs scale = gamma*rstd, shift = beta - mean*scale, plus mean and rstd for backward.
  * gamma/beta NULL = affine-free BatchNorm (mobilevit.py:15).  num_batches_tracked (optional, device int64) is
  * incremented in training, like nn.BatchNorm does. */
-int pb_bn_finalize(const float* stats, double count, const float* gamma, const float* beta, float eps,
+int pb_bn_finalize(const float* stats, int slots, double count, const float* gamma, const float* beta, float eps,
                    float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked,
                    int use_running, float* scale, float* shift, float* mean, float* rstd, int C, int device,
                    void* stream);
@@ -255,7 +256,7 @@ int pb_act_bwd_reduce(const void* dy, const void* z, void* g_out, int64_t M, int
                       const float* mean, const float* rstd, float* sums, int device, void* stream);
 
 /* BatchNorm backward coefficients: dz = A*g + B*(z - mean) + Cc;  dgamma = sum g*xhat, dbeta = sum g. */
-int pb_bn_bwd_finalize(const float* sums, double count, const float* gamma, const float* mean, const float* rstd,
+int pb_bn_bwd_finalize(const float* sums, int slots, double count, const float* gamma, const float* mean, const float* rstd,
                        int training, float* coefA, float* coefB, float* coefC, float* dgamma, float* dbeta,
                        int C, int device, void* stream);
 

@@ -370,39 +370,52 @@ __global__ __launch_bounds__(256) void rowgroup_kernel(RgArgs a) {
   block_chan_reduce<CH, 1>(red, acc, lane_ok, mp.CVB, mp.P, blockIdx.y * CW, a.C, outs);
 }
 
-// Sum of the PB_STAT_SLOTS slots of one [slot][2][C] statistics buffer for the 32 channels of this workgroup:
-// thread (cl, sg) adds the slots sg, sg+8, ... in double, the eight groups are combined through LDS in index order.
-__device__ __forceinline__ void slot_sums(const float* stats, int C, int c0, double (*red)[2][32], double& s1, double& s2) {
+// Sum of the slots of one [slot][2][C] statistics buffer for the 32 channels of this workgroup (1024 threads):
+// thread (cl, sg) adds the slots sg, sg+32, ... with four independent chains (the loads of a chain step are in flight
+// together: 51 -> ~5 us per launch), the 32 groups are combined through LDS in index order - a fixed association.
+constexpr int FIN_T = 1024, FIN_G = FIN_T / 32;
+__device__ __forceinline__ void slot_sums(const float* stats, int slots, int C, int c0, double (*red)[2][32], double& s1, double& s2) {
   const int cl = threadIdx.x & 31, sg = threadIdx.x >> 5;
   const int c = c0 + cl;
-  double a1 = 0, a2 = 0;
+  double a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
   if (c < C) {
-    for (int r = sg; r < PB_STAT_SLOTS; r += 8) {
-      a1 += stats[(size_t)r * 2 * C + c];
-      a2 += stats[(size_t)r * 2 * C + C + c];
+    int r = sg;
+    for (; r + 3 * FIN_G < slots; r += 4 * FIN_G) {
+      float x1[4], x2[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        x1[u] = stats[(size_t)(r + u * FIN_G) * 2 * C + c];
+        x2[u] = stats[(size_t)(r + u * FIN_G) * 2 * C + C + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { a1[u] += x1[u]; a2[u] += x2[u]; }
+    }
+    for (; r < slots; r += FIN_G) {
+      a1[0] += stats[(size_t)r * 2 * C + c];
+      a2[0] += stats[(size_t)r * 2 * C + C + c];
     }
   }
-  red[sg][0][cl] = a1;
-  red[sg][1][cl] = a2;
+  red[sg][0][cl] = (a1[0] + a1[1]) + (a1[2] + a1[3]);
+  red[sg][1][cl] = (a2[0] + a2[1]) + (a2[2] + a2[3]);
   __syncthreads();
   s1 = s2 = 0;
   if (sg == 0) {
 #pragma unroll
-    for (int g = 0; g < 8; ++g) {
+    for (int g = 0; g < FIN_G; ++g) {
       s1 += red[g][0][cl];
       s2 += red[g][1][cl];
     }
   }
 }
 
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* stats, double count, const float* gamma, const float* beta,
+__global__ __launch_bounds__(FIN_T) void bn_finalize_kernel(const float* stats, int slots, double count, const float* gamma, const float* beta,
                                                           float eps, float momentum, float* running_mean, float* running_var,
                                                           int64_t* num_batches_tracked, int use_running, float* scale,
                                                           float* shift, float* mean_o, float* rstd_o, int C) {
-  __shared__ double red[8][2][32];
+  __shared__ double red[FIN_G][2][32];
   const int c = blockIdx.x * 32 + (threadIdx.x & 31);
   double s1 = 0, s2 = 0;
-  if (!use_running) slot_sums(stats, C, blockIdx.x * 32, red, s1, s2);
+  if (!use_running) slot_sums(stats, slots, C, blockIdx.x * 32, red, s1, s2);
   if (threadIdx.x >= 32 || c >= C) return;
   double mean, var;
   if (use_running) {
@@ -427,13 +440,13 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* stats, do
   if (rstd_o) rstd_o[c] = (float)rstd;
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* sums, double count, const float* gamma, const float* mean,
+__global__ __launch_bounds__(FIN_T) void bn_bwd_finalize_kernel(const float* sums, int slots, double count, const float* gamma, const float* mean,
                                                               const float* rstd, int training, float* cA, float* cB, float* cC,
                                                               float* dgamma, float* dbeta, int C) {
-  __shared__ double red[8][2][32];
+  __shared__ double red[FIN_G][2][32];
   const int c = blockIdx.x * 32 + (threadIdx.x & 31);
   double sg = 0, sgx = 0;
-  slot_sums(sums, C, blockIdx.x * 32, red, sg, sgx);
+  slot_sums(sums, slots, C, blockIdx.x * 32, red, sg, sgx);
   if (threadIdx.x >= 32 || c >= C) return;
   const double g = gamma ? gamma[c] : 1.0, r = rstd[c];
   if (training) {
@@ -478,16 +491,16 @@ extern "C" int pb_chan_stats(const void* x, int64_t M, int C, pb_dtype dtype, fl
   return 0;
 }
 
-extern "C" int pb_bn_finalize(const float* stats, double count, const float* gamma, const float* beta, float eps,
+extern "C" int pb_bn_finalize(const float* stats, int slots, double count, const float* gamma, const float* beta, float eps,
                               float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked,
                               int use_running, float* scale, float* shift, float* mean, float* rstd, int C, int device,
                               void* stream) {
   PB_CHECK_ARG(scale && shift && C > 0, "pb_bn_finalize: null output / bad C");
-  PB_CHECK_ARG(use_running ? (running_mean && running_var) : (stats && count > 0),
+  PB_CHECK_ARG(use_running ? (running_mean && running_var) : (stats && count > 0 && slots >= 1),
                "pb_bn_finalize: missing statistics (use_running=%d)", use_running);
   PB_ENTER(device);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)pb_cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, stats,
-                     count, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, use_running, scale,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)pb_cdiv(C, 32)), dim3(FIN_T), 0, (hipStream_t)stream, stats,
+                     slots, count, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, use_running, scale,
                      shift, mean, rstd, C);
   PB_LAUNCH_CHECK();
   return 0;
@@ -530,13 +543,13 @@ extern "C" int pb_act_bwd_reduce(const void* dy, const void* z, void* g_out, int
   return 0;
 }
 
-extern "C" int pb_bn_bwd_finalize(const float* sums, double count, const float* gamma, const float* mean,
+extern "C" int pb_bn_bwd_finalize(const float* sums, int slots, double count, const float* gamma, const float* mean,
                                   const float* rstd, int training, float* coefA, float* coefB, float* coefC,
                                   float* dgamma, float* dbeta, int C, int device, void* stream) {
-  PB_CHECK_ARG(sums && mean && rstd && coefA && coefB && coefC && C > 0 && count > 0, "pb_bn_bwd_finalize: bad args");
+  PB_CHECK_ARG(sums && slots >= 1 && mean && rstd && coefA && coefB && coefC && C > 0 && count > 0, "pb_bn_bwd_finalize: bad args");
   PB_ENTER(device);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)pb_cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream,
-                     sums, count, gamma, mean, rstd, training, coefA, coefB, coefC, dgamma, dbeta, C);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)pb_cdiv(C, 32)), dim3(FIN_T), 0, (hipStream_t)stream,
+                     sums, slots, count, gamma, mean, rstd, training, coefA, coefB, coefC, dgamma, dbeta, C);
   PB_LAUNCH_CHECK();
   return 0;
 }

@@ -738,9 +738,10 @@ int check_stem(const pb_stem_shape* s, int x_dtype, pb_dtype dtype, const char* 
   } while (0)
 
 extern "C" int pb_stem_conv3d_fwd(const void* x, int x_dtype, float x_scale, const float* w, const float* bias,
-                                  void* y, const pb_stem_shape* s, pb_dtype dtype, float* stats, int device,
-                                  void* stream) {
+                                  void* y, const pb_stem_shape* s, pb_dtype dtype, float* stats, int stat_slots,
+                                  int device, void* stream) {
   PB_CHECK_ARG(x && w && y, "pb_stem_conv3d_fwd: null pointer");
+  PB_CHECK_ARG(!stats || stat_slots >= 1, "pb_stem_conv3d_fwd: stat_slots must be >= 1");
   if (int rc = check_stem(s, x_dtype, dtype, "pb_stem_conv3d_fwd")) return rc;
   PB_ENTER(device);
   hipStream_t st = (hipStream_t)stream;
@@ -753,13 +754,14 @@ extern "C" int pb_stem_conv3d_fwd(const void* x, int x_dtype, float x_scale, con
     const int64_t items = (int64_t)s->N * s->To * s->Ho * pb_cdiv(s->Wo, SW_PIX);
     int64_t gx = pb_cdiv(items, 4);
     if (gx > 2048) gx = 2048;
-    if (stats && gx > PB_STAT_SLOTS) gx = PB_STAT_SLOTS;       // one statistics slot per workgroup
+    if (stats && gx > stat_slots) gx = stat_slots;             // one statistics slot per workgroup
     dim3 grid((unsigned)gx, (unsigned)pb_cdiv(s->Cout, OCB));
     if (stem3_ok(s, x_dtype, dtype) && x_scale == 1.f) hipLaunchKernelGGL(stem3_fwd_kernel, grid, dim3(256), 0, st, a);
     else PB_STEM_DISPATCH(stem_fwd_mfma_kernel, grid);
   } else {
     int64_t gx = pb_cdiv(a.npix, 256);
-    if (gx > PB_STAT_SLOTS) gx = PB_STAT_SLOTS;
+    if (gx > 2048) gx = 2048;
+    if (stats && gx > stat_slots) gx = stat_slots;
     dim3 grid((unsigned)gx, (unsigned)pb_cdiv(s->Cout, OCB));
     PB_STEM_DISPATCH(stem_fwd_kernel, grid);
   }

@@ -256,7 +256,7 @@ class _StemBnAct(torch.autograd.Function):
         kernel, stride, pad = cfg["kernel"], cfg["stride"], cfg["pad"]
         training, has_bn = cfg["training"], cfg["bn"] is not None
         Cout = w.shape[0]
-        stats = _zeros((K.REPL, 2, Cout), x) if (has_bn and training) else None
+        stats = _zeros((getattr(K, "STEM_REPL", K.REPL), 2, Cout), x) if (has_bn and training) else None
         z5 = K.stem_fwd(x, w, bias, kernel, stride, pad, cfg["dtype"], cfg["x_scale"], stats)
         z2 = z5.view(-1, Cout)
         bnc, scale, shift = None, None, None

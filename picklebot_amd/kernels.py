@@ -14,6 +14,7 @@ import torch
 from . import _C
 
 REPL = _C.STAT_SLOTS        # stats buffers are [REPL, 2, C]: one slot per producing workgroup (include/picklebot_amd.h)
+STEM_REPL = 2048            # the stem's statistics: its launch wants 2048 workgroups (16 channels: 256 KB)
 
 ACT = {"none": _C.ACT_NONE, "relu": _C.ACT_RELU, "leaky_relu": _C.ACT_LEAKY_RELU, "hardswish": _C.ACT_HSWISH,
        "hardsigmoid": _C.ACT_HSIGMOID, "silu": _C.ACT_SILU}
@@ -548,13 +549,15 @@ def stem_fwd(x, w, bias, kernel, stride, pad, out_dtype, x_scale=1.0, stats=None
     if x.dim() != 5 or x.dtype not in _XDT:
         raise ValueError(f"stem_fwd: bad input {tuple(x.shape)} {x.dtype}")
     cout = w.shape[0]
-    _f32(w, (cout, x.shape[1], *kernel), "w"); _f32(bias, (cout,), "bias"); _f32(stats, (REPL, 2, cout), "stats")
+    _f32(w, (cout, x.shape[1], *kernel), "w"); _f32(bias, (cout,), "bias")
+    if stats is not None:
+        _f32(stats, (stats.shape[0], 2, cout), "stats")
     out = dw_out_shape(tuple(x.shape[2:]), kernel, stride, pad)
     y = torch.empty((x.shape[0],) + out + (cout,), dtype=out_dtype, device=x.device)
     s = _stem_shape(x, cout, out, kernel, stride, pad)
     dev, st = _dev_stream(x)
     _launch(_stem_kernel_name("fwd", x, w.shape[0], kernel, stride, pad, out_dtype, x_scale), _nb(x, y, w), "pb_stem_conv3d_fwd", _p(x), _XDT[x.dtype], float(x_scale), _p(w), _p(bias), _p(y), ctypes.byref(s),
-            _dt(y), _p(stats), dev, st)
+            _dt(y), _p(stats), stats.shape[0] if stats is not None else 0, dev, st)
     return y
 
 
@@ -585,12 +588,14 @@ def bn_finalize(stats, count, gamma, beta, eps, momentum, running_mean, running_
     place when training."""
     if num_batches_tracked is not None and (num_batches_tracked.dtype != torch.int64 or num_batches_tracked.numel() != 1):
         raise TypeError("bn_finalize: num_batches_tracked must be a 1-element int64 tensor")
-    _f32(stats, (REPL, 2, C), "stats"); _f32(gamma, (C,), "gamma"); _f32(beta, (C,), "beta")
+    if stats is not None:
+        _f32(stats, (stats.shape[0], 2, C), "stats")
+    _f32(gamma, (C,), "gamma"); _f32(beta, (C,), "beta")
     _f32(running_mean, (C,), "running_mean"); _f32(running_var, (C,), "running_var")
     out = torch.empty((4, C), dtype=torch.float32, device=device)
     ref = stats if stats is not None else running_mean
     dev, st = _dev_stream(ref)
-    _launch("bn_finalize", _nb(out), "pb_bn_finalize", _p(stats), float(count), _p(gamma), _p(beta), float(eps), float(momentum),
+    _launch("bn_finalize", _nb(out), "pb_bn_finalize", _p(stats), stats.shape[0] if stats is not None else 0, float(count), _p(gamma), _p(beta), float(eps), float(momentum),
             _p(running_mean), _p(running_var), _p(None if use_running else num_batches_tracked), int(use_running), _p(out[0]),
             _p(out[1]), _p(out[2]), _p(out[3]), C, dev, st)
     return out[0], out[1], out[2], out[3]
@@ -644,10 +649,10 @@ def act_bwd_reduce(dy, z, *, scale=None, shift=None, act="none", slope=0.0, row_
 def bn_bwd_finalize(sums, count, gamma, mean, rstd, training, want_affine_grads):
     """-> (A, B, Cc, dgamma, dbeta); dz = A*g + B*z + Cc."""
     C = mean.shape[0]
-    _f32(sums, (REPL, 2, C), "sums"); _f32(gamma, (C,), "gamma"); _f32(mean, (C,), "mean"); _f32(rstd, (C,), "rstd")
+    _f32(sums, (sums.shape[0], 2, C), "sums"); _f32(gamma, (C,), "gamma"); _f32(mean, (C,), "mean"); _f32(rstd, (C,), "rstd")
     out = torch.empty((5, C), dtype=torch.float32, device=mean.device)
     dev, st = _dev_stream(mean)
-    _launch("bn_bwd_finalize", _nb(out), "pb_bn_bwd_finalize", _p(sums), float(count), _p(gamma), _p(mean), _p(rstd), int(training), _p(out[0]),
+    _launch("bn_bwd_finalize", _nb(out), "pb_bn_bwd_finalize", _p(sums), sums.shape[0], float(count), _p(gamma), _p(mean), _p(rstd), int(training), _p(out[0]),
             _p(out[1]), _p(out[2]), _p(out[3]) if want_affine_grads else None,
             _p(out[4]) if want_affine_grads else None, C, dev, st)
     return out[0], out[1], out[2], (out[3] if want_affine_grads else None), (out[4] if want_affine_grads else None)
