@@ -328,10 +328,11 @@ int pb_transpose_f32(const float* in, float* out, int R, int C, int device, void
  * THIS update (the caller increments it first; device memory so that a captured HIP graph advances).  inv_scale /
  * found_inf (both optional device floats): gradients are multiplied by *inv_scale, and the whole update is skipped
  * when *found_inf != 0 - torch.amp.GradScaler's unscale + skip (train.py:283-289).  pb_grad_check sets *found_inf = 1
- * when any gradient is inf/nan (the caller zeroes it). */
+ * when any gradient is inf/nan (the caller zeroes it).  lr_wd (optional device float[2] = {lr, weight_decay}) overrides
+ * the by-value pair: a step replayed from a HIP graph then follows the scheduler (train.py:215 CosineAnnealingLR). */
 int pb_adamw_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
-                  float weight_decay, const float* step, const float* inv_scale, const float* found_inf, int device,
-                  void* stream);
+                  float weight_decay, const float* step, const float* inv_scale, const float* found_inf,
+                  const float* lr_wd, int device, void* stream);
 int pb_grad_check(const float* g, int64_t n, float* found_inf, int device, void* stream);
 
 #ifdef __cplusplus

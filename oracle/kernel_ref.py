@@ -431,10 +431,13 @@ def attention_bwd(qkv, out, dout, lse, G, n, scale):
     return dqkv.to(qkv.dtype)
 
 
-def adamw_flat(p, g, m, v, step, lr, beta1, beta2, eps, weight_decay, inv_scale=None, found_inf=None):
-    """torch.optim.AdamW's single-tensor update (torch/optim/adamw.py) on flat buffers, in place."""
+def adamw_flat(p, g, m, v, step, lr, beta1, beta2, eps, weight_decay, inv_scale=None, found_inf=None, lr_wd=None):
+    """torch.optim.AdamW's single-tensor update (torch/optim/adamw.py) on flat buffers, in place.  lr_wd: the (lr,
+    weight_decay) pair as a tensor, which the product's kernel reads from device memory instead of the host values."""
     if found_inf is not None and float(found_inf) != 0.0:
         return
+    if lr_wd is not None:
+        lr, weight_decay = float(lr_wd[0]), float(lr_wd[1])
     t = float(step)
     gg = g * (float(inv_scale) if inv_scale is not None else 1.0)
     p.mul_(1 - lr * weight_decay)

@@ -70,7 +70,7 @@ SIGNATURES = {
     "pb_conv_weight_prep": [P, P, I, I, I, I, I, P],
     "pb_conv3d_fwd": [P, P, P, POINTER(ConvShape), I, P, P, I, F, P, I, P],
     "pb_conv3d_fwd_bf16w": [P, P, P, POINTER(ConvShape), P, P, P, I, F, P, I, P],
-    "pb_adamw_flat": [P, P, P, P, L, F, F, F, F, F, P, P, P, I, P],
+    "pb_adamw_flat": [P, P, P, P, L, F, F, F, F, F, P, P, P, P, I, P],
     "pb_grad_check": [P, L, P, I, P],
     "pb_conv3d_bwd_weight_ws": [P, P, P, POINTER(ConvShape), I, P, L, P, I, P],
 }

@@ -19,13 +19,16 @@ struct AdamArgs {
   const float* step;       // device scalar, already incremented for this step
   const float* inv_scale;  // optional
   const float* found_inf;  // optional
+  const float* lr_wd;      // optional device float[2] = {lr, weight_decay}: overrides the by-value pair, so that a step
+                           // replayed from a HIP graph follows a learning-rate schedule
 };
 
 __global__ __launch_bounds__(256) void adamw_flat_kernel(AdamArgs a) {
   if (a.found_inf && *a.found_inf != 0.f) return;
   const float t = *a.step;
+  const float lr = a.lr_wd ? a.lr_wd[0] : a.lr, wd = a.lr_wd ? a.lr_wd[1] : a.wd;
   const float bc1 = 1.f - powf(a.b1, t), bc2 = 1.f - powf(a.b2, t);
-  const float step_size = a.lr / bc1, inv_sqrt_bc2 = rsqrtf(bc2), decay = 1.f - a.lr * a.wd;
+  const float step_size = lr / bc1, inv_sqrt_bc2 = rsqrtf(bc2), decay = 1.f - lr * wd;
   const float gs = a.inv_scale ? *a.inv_scale : 1.f;
   const int64_t n4 = a.n >> 2;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
@@ -63,14 +66,14 @@ __global__ __launch_bounds__(256) void grad_check_kernel(const float* g, int64_t
 
 extern "C" int pb_adamw_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                              float eps, float weight_decay, const float* step, const float* inv_scale,
-                             const float* found_inf, int device, void* stream) {
+                             const float* found_inf, const float* lr_wd, int device, void* stream) {
   PB_CHECK_ARG(p && g && m && v && step, "pb_adamw_flat: null pointer");
   PB_CHECK_ARG(n >= 0, "pb_adamw_flat: bad size");
   PB_CHECK_ARG(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 && ((uintptr_t)v % 16) == 0,
                "pb_adamw_flat: buffers must be 16-byte aligned");
   if (n == 0) return 0;
   PB_ENTER(device);
-  AdamArgs a = {p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, inv_scale, found_inf};
+  AdamArgs a = {p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, inv_scale, found_inf, lr_wd};
   int64_t blocks = pb_cdiv(pb_cdiv(n, 4), 256);
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;

@@ -899,15 +899,16 @@ def attention_bwd(qkv, out, dout, lse, G, n, scale):
 
 
 # ------------------------------------------------------------------------------ optimizer step
-def adamw_flat(p, g, m, v, step, lr, beta1, beta2, eps, weight_decay, inv_scale=None, found_inf=None):
-    """In-place fused AdamW over flat fp32 buffers; `step`: device float tensor holding this update's step number."""
+def adamw_flat(p, g, m, v, step, lr, beta1, beta2, eps, weight_decay, inv_scale=None, found_inf=None, lr_wd=None):
+    """In-place fused AdamW over flat fp32 buffers; `step`: device float tensor holding this update's step number;
+    lr_wd: optional device float[2] = (lr, weight_decay) read by the kernel instead of the host values."""
     n = p.numel()
     for t, name in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
         _f32(t, (n,), name)
-    _f32(step, (), "step"); _f32(inv_scale, (), "inv_scale"); _f32(found_inf, (), "found_inf")
+    _f32(step, (), "step"); _f32(inv_scale, (), "inv_scale"); _f32(found_inf, (), "found_inf"); _f32(lr_wd, (2,), "lr_wd")
     dev, st = _dev_stream(p)
     _launch("adamw_flat", 7 * n * 4, "pb_adamw_flat", _p(p), _p(g), _p(m), _p(v), n, float(lr), float(beta1), float(beta2), float(eps),
-            float(weight_decay), _p(step), _p(inv_scale), _p(found_inf), dev, st)
+            float(weight_decay), _p(step), _p(inv_scale), _p(found_inf), _p(lr_wd), dev, st)
 
 
 def grad_check(g, found_inf):

@@ -13,8 +13,10 @@ rule.  State (exp_avg, exp_avg_sq) is fp32.
 
 Construct it after the model is on its device (parameters are re-pointed into the flat buffer; `state_dict` keys and values are
 unchanged).  With a `GradReducer` the reducer's buckets are adopted (its flat gradient buffers are what the all-reduce fills).
-Everything is stream-ordered and allocation-free after construction, so a whole step can be captured into a HIP graph
-(the step count lives on the device).
+Everything is stream-ordered and allocation-free after construction, so a whole step can be captured into a HIP graph:
+the step count AND the (lr, weight_decay) pair live on the device.  It IS a torch.optim.Optimizer (one param group), so
+the reference's `CosineAnnealingLR(optimizer, ...)` (train.py:215) drives it; `step()` uploads a changed lr before it
+launches, and a loop that replays a captured step calls `refresh_hyper()` before each replay for the same effect.
 """
 import torch
 
@@ -22,25 +24,23 @@ from . import kernels as K
 from .parallel import bucket_layout
 
 
-class FlatAdamW:
+class FlatAdamW(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
-        self.defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay)
-        self.param_groups = [dict(self.defaults)]          # (lr schedulers edit param_groups[0]["lr"])
         reducer = params if hasattr(params, "buckets") and hasattr(params, "flat") else None
         self._reducer = reducer
         if reducer is not None:
-            self.buckets = reducer.buckets
-            self.gflat = reducer.flat
-            self.gviews = reducer.views
+            buckets, gflat, gviews = reducer.buckets, reducer.flat, reducer.views
         else:
             plist = [p for p in params if p.requires_grad]
             if not plist:
                 raise ValueError("FlatAdamW: no parameters")
             offs, n = bucket_layout(plist)
-            self.buckets = [plist]
-            self.gflat = [torch.zeros(n, dtype=torch.float32, device=plist[0].device)]
-            self.gviews = [[self.gflat[0][o:o + p.numel()].view_as(p) for p, o in zip(plist, offs)]]
-        self.param_groups[0]["params"] = [p for b in self.buckets for p in b]
+            buckets = [plist]
+            gflat = [torch.zeros(n, dtype=torch.float32, device=plist[0].device)]
+            gviews = [[gflat[0][o:o + p.numel()].view_as(p) for p, o in zip(plist, offs)]]
+        # ONE param group (lr schedulers edit param_groups[0]["lr"]); torch.optim.Optimizer keeps the bookkeeping
+        super().__init__([p for b in buckets for p in b], dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
+        self.buckets, self.gflat, self.gviews = buckets, gflat, gviews
         self.pflat, self.exp_avg, self.exp_avg_sq = [], [], []
         for plist, g in zip(self.buckets, self.gflat):
             flat = torch.zeros_like(g)
@@ -57,7 +57,18 @@ class FlatAdamW:
         dev = self.pflat[0].device
         self.step_t = torch.zeros((), dtype=torch.float32, device=dev)
         self.found_inf = torch.zeros((), dtype=torch.float32, device=dev)
+        self.hyper = torch.tensor([lr, weight_decay], dtype=torch.float32, device=dev)   # what the kernel reads
+        self._hyper_host = (float(lr), float(weight_decay))
         self._packed = False
+
+    def refresh_hyper(self):
+        """Upload (lr, weight_decay) of param_groups[0] when a scheduler changed them.  step() calls this itself; a loop
+        that REPLAYS a captured step calls it before each replay (the kernel reads the pair from device memory)."""
+        g0 = self.param_groups[0]
+        cur = (float(g0["lr"]), float(g0["weight_decay"]))
+        if cur != self._hyper_host:
+            self.hyper.copy_(torch.tensor(cur, dtype=torch.float32), non_blocking=True)
+            self._hyper_host = cur
 
     # -- gradients ------------------------------------------------------------------------
     def detach_grads(self):
@@ -82,14 +93,20 @@ class FlatAdamW:
 
     # -- update ---------------------------------------------------------------------------
     @torch.no_grad()
-    def step(self, inv_scale=None, check_inf=False, packed=None):
+    def step(self, closure=None, inv_scale=None, check_inf=False, packed=None):
         """packed: the flat gradient buffers already hold this step's gradients (a reducer filled / reduced them);
         default: gather them now unless pack_grads() was called since the last zero_grad().
         inv_scale (device float tensor): GradScaler's 1/scale; check_inf: skip the update when a gradient is inf/nan."""
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
         if packed is None:
             packed = self._packed
         if not packed:
             self.pack_grads()
+        if not (self.hyper.is_cuda and torch.cuda.is_current_stream_capturing()):
+            self.refresh_hyper()                             # (during capture the values are whatever was uploaded last)
         g0 = self.param_groups[0]
         lr, (b1, b2), eps, wd = g0["lr"], g0["betas"], g0["eps"], g0["weight_decay"]
         found = None
@@ -102,8 +119,9 @@ class FlatAdamW:
         else:
             self.step_t += 1
         for p, g, m, v in zip(self.pflat, self.gflat, self.exp_avg, self.exp_avg_sq):
-            K.adamw_flat(p, g, m, v, self.step_t, lr, b1, b2, eps, wd, inv_scale=inv_scale, found_inf=found)
+            K.adamw_flat(p, g, m, v, self.step_t, lr, b1, b2, eps, wd, inv_scale=inv_scale, found_inf=found, lr_wd=self.hyper)
         self._packed = False
+        return loss
 
     # -- state ----------------------------------------------------------------------------
     def state_dict(self):
@@ -118,3 +136,4 @@ class FlatAdamW:
         for dst, src in zip(self.exp_avg_sq, sd["exp_avg_sq"]):
             dst.copy_(src)
         self.param_groups[0].update(sd["param_groups"][0])
+        self.refresh_hyper()

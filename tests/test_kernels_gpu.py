@@ -481,3 +481,38 @@ def test_adamw_flat_and_grad_check(K, n):
     before = p1.clone()
     K.adamw_flat(p1, dev(bad), m1, v1, step_d, 3e-3, 0.9, 0.99, 1e-8, 5e-2, found_inf=found)
     assert torch.equal(before, p1)
+
+
+def test_flat_adamw_lr_follows_scheduler_under_graph_replay(K):
+    """A step captured into a HIP graph reads (lr, weight_decay) from device memory: changing param_groups[0]["lr"] and
+    calling refresh_hyper() before a replay changes the update (the host float baked into the graph would not)."""
+    import picklebot_amd
+    torch.manual_seed(5)
+    n = 4096 + 3
+    p = torch.nn.Parameter(torch.randn(n, device=DEV))
+    opt = picklebot_amd.FlatAdamW([p], lr=1e-2, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-2)
+    assert isinstance(opt, torch.optim.Optimizer)
+    g = torch.randn(n, device=DEV)
+    opt.gflat[0][:n].copy_(g)
+    ref_p, ref_m, ref_v = p.detach().cpu().clone(), torch.zeros(n), torch.zeros(n)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        opt.step(packed=True)                                  # warm-up step (eager), counted below
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    R.adamw_flat(ref_p, g.cpu(), ref_m, ref_v, torch.tensor(1.0), 1e-2, 0.9, 0.99, 1e-8, 1e-2)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        opt.step(packed=True)
+    R.adamw_flat(ref_p, g.cpu(), ref_m, ref_v, torch.tensor(2.0), 1e-2, 0.9, 0.99, 1e-8, 1e-2)     # (capture ran the step once)
+    step = 2.0
+    for lr in (1e-2, 1e-3, 5e-2):
+        opt.param_groups[0]["lr"] = lr
+        opt.refresh_hyper()
+        graph.replay()
+        step += 1.0
+        R.adamw_flat(ref_p, g.cpu(), ref_m, ref_v, torch.tensor(step), lr, 0.9, 0.99, 1e-8, 1e-2)
+        torch.cuda.synchronize()
+        check(f"adamw_graph_lr{lr}", p.detach(), ref_p, torch.float32)
+    assert float(opt.step_t) == step
