@@ -180,6 +180,14 @@ int pb_dwconv3d_pool_slots(const pb_dwconv_shape* s, pb_dtype dtype);
 int pb_dwconv3d_fwd(const void* x, const float* w, void* y, const pb_dwconv_shape* s, pb_dtype dtype,
                     float* pool_part, int pool_slots, int device, void* stream);
 
+/* Streaming causal depthwise convolution (CausalConv3d with a stream buffer, movinet.py:7-39): the nhist frames that
+ * precede x in time are read from the caller-owned history `hist` [N][nhist][Hi][Wi][C] instead of being zero padding;
+ * s->pt = total front padding of the equivalent unchunked call (frames before the history are zeros).  The caller
+ * advances the history (last nhist frames of hist ++ x) between chunks.  Returns 3 when the shape is not one the
+ * (kt,3,3) kernels take (the caller then concatenates history and chunk and calls pb_dwconv3d_fwd). */
+int pb_dwconv3d_fwd_hist(const void* x, const void* hist, int nhist, const float* w, void* y, const pb_dwconv_shape* s,
+                         pb_dtype dtype, int device, void* stream);
+
 /* Backward.  The incoming gradient may carry the fused squeeze-excite backward:
  *   g[n,t,h,w,c] = dy[n,t,h,w,c] * g_scale[n,c] + g_shift[n,c]   (either may be NULL)
  * dx = conv_transpose(g, w);  dw[C][kt*kh*kw] += sum g * x: per-workgroup partial gradients go to `ws`

@@ -122,6 +122,13 @@ def dw_fwd(x, w, kernel, stride, pad_front, pad_back=None, pool=None):
     return y
 
 
+def dw_fwd_hist(x, hist, w, kernel, stride, pad_front, pad_back=None):
+    """Mirror of kernels.dw_fwd_hist: the history frames replace the last nhist frames of the front padding."""
+    nhist = hist.shape[1]
+    return dw_fwd(torch.cat([hist, x], 1), w, kernel, stride, (pad_front[0] - nhist, pad_front[1], pad_front[2]),
+                  pad_front if pad_back is None else pad_back)
+
+
 def _g(dy, g_scale, g_shift):
     g = dy.float()
     if g_scale is not None:

@@ -46,6 +46,7 @@ SIGNATURES = {
     "pb_pwconv_bwd_weight_ws": [P, P, P, L, I, I, I, P, P, I, F, P, L, P, L, POINTER(ReduceJob), I, P],
     "pb_dwconv3d_fwd": [P, P, P, POINTER(DwShape), I, P, I, I, P],
     "pb_dwconv3d_bwd_data": [P, P, P, POINTER(DwShape), I, P, P, I, P],
+    "pb_dwconv3d_fwd_hist": [P, P, I, P, P, POINTER(DwShape), I, I, P],
     "pb_dwconv3d_bwd_weight": [P, P, P, POINTER(DwShape), I, P, P, P, L, POINTER(ReduceJob), I, P],
     "pb_stem_conv3d_fwd": [P, I, F, P, P, P, POINTER(StemShape), I, P, I, I, P],
     "pb_stem_conv3d_bwd_weight": [P, P, I, F, P, P, POINTER(StemShape), I, P, L, I, P],
@@ -134,8 +135,11 @@ def load():
     return lib
 
 
-def call(name, *args):
+def call(name, *args, allow=()):
+    """Run an entry point; a status listed in `allow` is returned to the caller instead of raising."""
     lib = load()
     rc = getattr(lib, name)(*args)
+    if rc in allow:
+        return rc
     if rc != 0:
         raise RuntimeError(f"{name} failed (status {rc}): {lib.pb_last_error().decode()}")

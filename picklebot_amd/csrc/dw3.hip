@@ -19,6 +19,8 @@ struct Dw3Args {
   const float* g_scale;
   const float* g_shift;
   float* pool;
+  const void* hist;        // optional [N][nhist][Hs][Ws][C]: the nhist frames that precede src in time (stream buffer of a
+  int nhist;               // CausalConv3d, movinet.py:18-21,36): input frames -nhist .. -1 are read from it, not as zeros
   int N, C, Ts, Hs, Ws, Td, Hd, Wd, pt, ph, pw;
   int nseg, CP, nchunk, chunk;     // chunk = output frames per thread
 };
@@ -68,6 +70,8 @@ __global__ __launch_bounds__(256) void dw3_fwd_kernel(Dw3Args a) {
   if (a.g_scale) gs = *reinterpret_cast<const f32x2*>(a.g_scale + (int64_t)n * a.C + c0);
   if (a.g_shift) gh = *reinterpret_cast<const f32x2*>(a.g_shift + (int64_t)n * a.C + c0);
   const raw_t* src = (const raw_t*)a.src + ((int64_t)n * a.Ts * a.Hs * a.Ws * a.C + c0) / 2;
+  // history frames sit right "before" frame 0: hist_base + f*fstride is frame f of the history for f in [-nhist, 0)
+  const raw_t* hist_base = a.hist ? (const raw_t*)a.hist + ((int64_t)(n + 1) * a.nhist * a.Hs * a.Ws * a.C + c0) / 2 : nullptr;
   raw_t* dst = (raw_t*)a.dst + ((((int64_t)n * a.Td + t0) * a.Hd + ho) * a.Wd * a.C + c0) / 2 + (int64_t)w0 * ps;
   const int64_t fstride_s = (int64_t)a.Hs * a.Ws * ps, fstride_d = (int64_t)a.Hd * a.Wd * ps;
 
@@ -80,7 +84,8 @@ __global__ __launch_bounds__(256) void dw3_fwd_kernel(Dw3Args a) {
   constexpr bool DEEP = KT == 3 && S == 1;
   raw_t raw[3][IW], raw2[DEEP ? 3 : 1][DEEP ? IW : 1];
   auto load_into = [&](int f, auto& dst) {
-    const raw_t* base = src + (int64_t)min(max(f, 0), a.Ts - 1) * fstride_s;
+    const raw_t* base = (f < 0 && f >= -a.nhist) ? hist_base + (int64_t)f * fstride_s        // (nhist = 0 without a history)
+                                                 : src + (int64_t)min(max(f, 0), a.Ts - 1) * fstride_s;
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
@@ -98,7 +103,7 @@ __global__ __launch_bounds__(256) void dw3_fwd_kernel(Dw3Args a) {
       const int i = ik + r;
       if (i < nI) {
         const int f = f0 + i;
-        const bool fok = f >= 0 && f < a.Ts;
+        const bool fok = f >= -a.nhist && f < a.Ts;
         f32x2 xin[3][IW];
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh)
@@ -198,11 +203,12 @@ int pb_dw3_pool_slots(const pb_dwconv_shape* s) {
 }
 
 int pb_dw3_fwd(const void* src, const float* w, void* dst, const pb_dwconv_shape* s, pb_dtype dtype, int flip,
-               const float* g_scale, const float* g_shift, float* pool, hipStream_t st) {
+               const float* g_scale, const float* g_shift, float* pool, hipStream_t st, const void* hist, int nhist) {
   if (!dw3_ok(s)) return -1;
   PB_CHECK_ARG((int64_t)s->N * s->To * s->Ho * s->Wo * s->C < (1LL << 40), "dw3: tensor too large");
   Dw3Args a = {};
   a.src = src; a.dst = dst; a.w = w; a.g_scale = g_scale; a.g_shift = g_shift; a.pool = pool;
+  a.hist = hist; a.nhist = hist ? nhist : 0;
   a.N = s->N; a.C = s->C; a.Ts = s->Ti; a.Hs = s->Hi; a.Ws = s->Wi; a.Td = s->To; a.Hd = s->Ho; a.Wd = s->Wo;
   a.pt = s->pt; a.ph = s->ph; a.pw = s->pw;
   const int KT = s->kt, S = s->sh;

@@ -59,4 +59,5 @@ PB_HIDDEN int pb_dw_rows_wgrad(const void* dy, const void* x, float* part, const
 PB_HIDDEN bool pb_dw3_eligible(const pb_dwconv_shape* s);
 PB_HIDDEN int pb_dw3_pool_slots(const pb_dwconv_shape* s);
 PB_HIDDEN int pb_dw3_fwd(const void* src, const float* w, void* dst, const pb_dwconv_shape* s, pb_dtype dtype, int flip,
-                         const float* g_scale, const float* g_shift, float* pool, hipStream_t st);
+                         const float* g_scale, const float* g_shift, float* pool, hipStream_t st,
+                         const void* hist = nullptr, int nhist = 0);

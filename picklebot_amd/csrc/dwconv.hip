@@ -953,6 +953,25 @@ extern "C" int pb_dwconv3d_fwd(const void* x, const float* w, void* y, const pb_
   return 0;
 }
 
+// Streaming (stateful) causal depthwise convolution: the `nhist` frames that precede x in time come from the
+// caller-owned history buffer `hist` [N][nhist][Hi][Wi][C] (same dtype), not from zero padding - the chunked evaluation
+// of a CausalConv3d (movinet.py:7-39) never re-reads history from a concatenated tensor.  s->pt = the total front
+// padding of the equivalent unchunked call (>= nhist: frames before the history are zeros, as the conv's own padding).
+// Only the (kt,3,3) kernels implement it: returns 3 ("shape not taken") otherwise and the caller concatenates.
+extern "C" int pb_dwconv3d_fwd_hist(const void* x, const void* hist, int nhist, const float* w, void* y,
+                                    const pb_dwconv_shape* s, pb_dtype dtype, int device, void* stream) {
+  PB_CHECK_ARG(x && hist && w && y, "pb_dwconv3d_fwd_hist: null pointer");
+  if (int rc = check_shape(s, "pb_dwconv3d_fwd_hist")) return rc;
+  PB_CHECK_ARG(dtype == PB_F32 || dtype == PB_BF16, "pb_dwconv3d_fwd_hist: bad dtype");
+  PB_CHECK_ARG(nhist >= 1 && nhist <= s->pt, "pb_dwconv3d_fwd_hist: nhist=%d must be in [1, pt=%d]", nhist, s->pt);
+  if (!pb_dw3_eligible(s)) { pb_set_error("pb_dwconv3d_fwd_hist: shape not taken by the (kt,3,3) kernels"); return 3; }
+  PB_ENTER(device);
+  const int rc = pb_dw3_fwd(x, w, y, s, dtype, 0, nullptr, nullptr, nullptr, (hipStream_t)stream, hist, nhist);
+  if (rc) return rc < 0 ? 3 : rc;
+  PB_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int pb_dwconv3d_bwd_data(const void* dy, const float* w, void* dx, const pb_dwconv_shape* s,
                                     pb_dtype dtype, const float* g_scale, const float* g_shift, int device,
                                     void* stream) {

@@ -487,6 +487,27 @@ def dw_fwd(x, w, kernel, stride, pad_front, pad_back=None, pool=None):
     return y
 
 
+def dw_fwd_hist(x, hist, w, kernel, stride, pad_front, pad_back=None):
+    """Causal depthwise conv of the chunk x [N,T,H,W,C] whose preceding frames are hist [N,nhist,H,W,C] (a CausalConv3d
+    stream buffer): pad_front[0] = the unchunked call's total front padding on T (>= nhist; the rest is zeros).
+    Returns y, or None when no history-aware kernel takes the shape (the caller concatenates)."""
+    _ndhwc(x, "x"); _ndhwc(hist, "hist")
+    N, T, H, W, C = x.shape
+    nhist = hist.shape[1]
+    if tuple(hist.shape) != (N, nhist, H, W, C) or hist.dtype != x.dtype or nhist < 1 or nhist > pad_front[0]:
+        raise ValueError(f"dw_fwd_hist: history {tuple(hist.shape)} does not fit x {tuple(x.shape)} / pad_front {pad_front}")
+    taps = kernel[0] * kernel[1] * kernel[2]
+    _f32(w, (C, taps), "w")
+    out = dw_out_shape((T, H, W), kernel, stride, pad_front, pad_back)
+    if min(out) <= 0:
+        raise ValueError(f"dw_fwd_hist: empty output {out}")
+    y = torch.empty((N,) + out + (C,), dtype=x.dtype, device=x.device)
+    s = _dw_shape(N, C, (T, H, W), out, kernel, stride, pad_front)
+    dev, st = _dev_stream(x)
+    rc = _C.call("pb_dwconv3d_fwd_hist", _p(x), _p(hist), nhist, _p(w), _p(y), ctypes.byref(s), _dt(x), dev, st, allow=(3,))
+    return y if rc is None or rc == 0 else None
+
+
 def dw_bwd_data(dy, w, in_thw, kernel, stride, pad_front, g_scale=None, g_shift=None):
     _ndhwc(dy, "dy")
     N, To, Ho, Wo, C = dy.shape

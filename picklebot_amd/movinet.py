@@ -17,9 +17,16 @@ def _triple(v):
 
 
 class CausalConv3d(nn.Module):
-    """Left-pad T by (k_t - 1) frames, then a plain Conv3d (movinet.py:7-39).  `conv3d` carries the
-    parameters (key `conv3d.weight`).  Depthwise (groups == channels) and dense filters both run in HIP;
-    a non-zero `stream_buffer` pad value is not supported (no reference model uses CausalConv3d at all)."""
+    """Left-pad T by (k_t - 1) frames of `stream_buffer` (a constant; 0 by default), then a plain Conv3d
+    (movinet.py:7-39).  `conv3d` carries the parameters (key `conv3d.weight`).  Depthwise (groups == channels) and
+    dense filters both run in HIP.
+
+    Streaming (the reference's "stream buffer" idea, which its own forward only ever fills with a constant): the causal
+    left pad is exactly the (k_t - 1) frames that preceded the chunk, so `forward_stream(chunk, state)` evaluates a clip
+    chunk by chunk and equals `forward(clip)` on the whole clip (SURVEY 8a-5 known answer).  The depthwise (kt,3,3)
+    kernels read the history from the caller-owned state buffer directly (pb_dwconv3d_fwd_hist); other shapes
+    concatenate history and chunk.  No reference MODEL uses CausalConv3d, and whole-model streaming is undefined there
+    (squeeze-excite pools over all of T), so this stays a layer-level API."""
 
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, dilation=1, stream_buffer=None, **kwargs):
         super().__init__()
@@ -31,24 +38,68 @@ class CausalConv3d(nn.Module):
         self.p_left_causal, self.p_right_causal = left + right, 0
         self.conv3d = nn.Conv3d(in_channels, out_channels, ks, stride=stride, dilation=dl, **kwargs)
 
+    def _check(self):
+        c = self.conv3d
+        if c.dilation != (1, 1, 1) or isinstance(c.padding, str):
+            raise NotImplementedError("picklebot_amd.CausalConv3d: dilation / string padding")
+        if not (c.groups == c.in_channels == c.out_channels or c.groups == 1):
+            raise NotImplementedError("picklebot_amd.CausalConv3d: grouped (non-depthwise) convolution")
+        return c
+
+    def _conv(self, x5, hist5):
+        """x5 NDHWC chunk; hist5: None (zero causal pad) or the p_left_causal frames that precede it."""
+        c = self.conv3d
+        pt, ph, pw = c.padding
+        pad_front, pad_back = (pt + self.p_left_causal, ph, pw), (pt, ph, pw)
+        depthwise = c.groups == c.in_channels == c.out_channels
+        if hist5 is not None and self.p_left_causal > 0:
+            if depthwise and c.bias is None and not torch.is_grad_enabled():
+                y5 = PF.K.dw_fwd_hist(x5, hist5, c.weight.view(c.out_channels, -1), c.kernel_size, c.stride, pad_front, pad_back)
+                if y5 is not None:
+                    return y5
+            # any other shape (and training): history and chunk as one tensor, the conv's own zero padding in front of it
+            x5 = torch.cat([hist5, x5], 1)
+            pad_front = (pt, ph, pw)
+        if depthwise:
+            return PF.depthwise(x5, c.weight, c.bias, c.kernel_size, c.stride, pad_front, pad_back)
+        return PF.conv3d_dense(x5, c.weight, c.bias, c.stride, pad_front, pad_back)
+
     @torch.compiler.disable
     @PF.scoped
     def forward(self, x):
-        c = self.conv3d
-        if self.stream_buffer != 0:
-            raise NotImplementedError("picklebot_amd.CausalConv3d: non-zero stream_buffer pad value")
-        if c.dilation != (1, 1, 1) or isinstance(c.padding, str):
-            raise NotImplementedError("picklebot_amd.CausalConv3d: dilation / string padding")
+        self._check()
         x5 = to_ndhwc(x, compute_dtype(x))
-        pt, ph, pw = c.padding
-        pad_front, pad_back = (pt + self.p_left_causal, ph, pw), (pt, ph, pw)
-        if c.groups == c.in_channels == c.out_channels:
-            y5 = PF.depthwise(x5, c.weight, c.bias, c.kernel_size, c.stride, pad_front, pad_back)
-        elif c.groups == 1:
-            y5 = PF.conv3d_dense(x5, c.weight, c.bias, c.stride, pad_front, pad_back)
-        else:
-            raise NotImplementedError("picklebot_amd.CausalConv3d: grouped (non-depthwise) convolution")
-        return from_ndhwc(y5)
+        hist5 = None
+        if self.stream_buffer != 0 and self.p_left_causal > 0:        # F.pad(..., "constant", stream_buffer), movinet.py:36
+            N, _, H, W, C = x5.shape
+            hist5 = torch.full((N, self.p_left_causal, H, W, C), float(self.stream_buffer), dtype=x5.dtype, device=x5.device)
+        return from_ndhwc(self._conv(x5, hist5))
+
+    @torch.compiler.disable
+    @PF.scoped
+    def forward_stream(self, x, state=None):
+        """One chunk of a clip: x (N,C,t,H,W) -> (y (N,C',t',H',W'), state).  `state` is the history buffer
+        [N, k_t-1, H, W, C] (NDHWC, caller-owned; None for the first chunk = the `stream_buffer` constant) and is
+        advanced in place to the last k_t-1 frames seen.  Temporal stride 1 only (every reference use)."""
+        c = self._check()
+        if c.stride[0] != 1:
+            raise NotImplementedError("picklebot_amd.CausalConv3d.forward_stream: temporal stride must be 1")
+        x5 = to_ndhwc(x, compute_dtype(x))
+        nh = self.p_left_causal
+        if nh == 0:
+            return from_ndhwc(self._conv(x5, None)), state
+        N, t, H, W, C = x5.shape
+        if state is None:
+            state = torch.full((N, nh, H, W, C), float(self.stream_buffer), dtype=x5.dtype, device=x5.device)
+        elif tuple(state.shape) != (N, nh, H, W, C) or state.dtype != x5.dtype:
+            raise ValueError(f"CausalConv3d.forward_stream: state {tuple(state.shape)} {state.dtype} does not fit the chunk")
+        y5 = self._conv(x5, state)
+        with torch.no_grad():                                         # advance the history (memory plumbing)
+            if t >= nh:
+                state.copy_(x5[:, t - nh:])
+            else:
+                state.copy_(torch.cat([state[:, t:], x5], 1))
+        return from_ndhwc(y5), state
 
 
 class MoviNetBottleneck(nn.Module):

@@ -51,3 +51,29 @@ def test_eval_fold_equals_train_path(cpu_kernels):
         y_fold = blk(x)
     y_full = blk(x.clone().requires_grad_(True))
     assert torch.allclose(y_fold, y_full, atol=1e-5, rtol=1e-5)
+
+
+def _causal_pair(case, stream_buffer=None):
+    """(oracle layer, picklebot_amd layer) with the same formula weights."""
+    from oracle import formula, torch_ref
+    _, kwargs, shape = protocol.BLOCK_CASES[case]
+    kw = dict(kwargs, stream_buffer=stream_buffer)
+    ref, ours = torch_ref.CausalConv3d(**kw), picklebot_amd.CausalConv3d(**kw)
+    formula.fill_state_dict(ref); formula.fill_state_dict(ours)
+    return ref.eval(), ours.eval(), formula.tensor("x:" + case, shape)
+
+
+@pytest.mark.parametrize("case", ["causal_dw_533", "causal_333"])
+def test_causal_stream_buffer_value_and_chunked_streaming(case, cpu_kernels):
+    """CausalConv3d (movinet.py:7-39): a non-zero stream_buffer pad value equals F.pad(..., value) + Conv3d, and
+    forward_stream over chunks (history carried in the caller-owned state) equals the full clip."""
+    ref, ours, x = _causal_pair(case, stream_buffer=0.75)
+    with torch.no_grad():
+        want = ref(x)
+        assert torch.allclose(ours(x), want, atol=1e-5, rtol=1e-5)
+        for chunk in (1, 3, 4):
+            state, pieces = None, []
+            for t0 in range(0, x.shape[2], chunk):
+                y, state = ours.forward_stream(x[:, :, t0:t0 + chunk], state)
+                pieces.append(y)
+            assert torch.allclose(torch.cat(pieces, 2), want, atol=1e-5, rtol=1e-5), chunk

@@ -505,8 +505,7 @@ def test_flat_adamw_lr_follows_scheduler_under_graph_replay(K):
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
         opt.step(packed=True)
-    R.adamw_flat(ref_p, g.cpu(), ref_m, ref_v, torch.tensor(2.0), 1e-2, 0.9, 0.99, 1e-8, 1e-2)     # (capture ran the step once)
-    step = 2.0
+    step = 1.0                                                 # (capture records the step, it does not run it)
     for lr in (1e-2, 1e-3, 5e-2):
         opt.param_groups[0]["lr"] = lr
         opt.refresh_hyper()

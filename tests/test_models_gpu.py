@@ -265,3 +265,63 @@ def test_training_reduces_loss_on_a_fixed_batch(name):
         losses.append(float(loss))
     assert all(v == v for v in losses), losses
     assert min(losses[-5:]) < 0.6 * losses[0], losses
+
+
+# ------------------------------------------------------------------------------ CausalConv3d streaming
+@pytest.mark.parametrize("case", ["causal_dw_533", "causal_333"])
+def test_causal_streaming_known_answer_on_hip(case, golden):
+    """chunked evaluation with (k_t - 1) frames of carried history == the full clip, on the HIP path, against the
+    reference's own values (blocks.npz: stream_<case>/full)."""
+    with contextlib.redirect_stdout(io.StringIO()):
+        res = protocol.run_causal_stream_case(picklebot_amd, case, device=DEV)
+    g = golden("blocks")
+    assert rel_err(res["full"], g[f"stream_{case}/full"]) <= 1e-5
+    assert rel_err(res["stream"], g[f"stream_{case}/full"]) <= 1e-5
+
+
+def _torch_causal(w, b, x, value, pad):
+    """The reference's CausalConv3d.forward in stock torch ops on the CPU (movinet.py:33-39)."""
+    kt = w.shape[2]
+    xp = torch.nn.functional.pad(x, (0, 0, 0, 0, kt - 1, 0), "constant", value)
+    return torch.nn.functional.conv3d(xp, w, b, padding=pad, groups=x.shape[1] if w.shape[1] == 1 else 1)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C,kt,thw,value", [(40, 3, (11, 22, 22), 0.0), (40, 3, (11, 22, 22), 0.5), (96, 5, (9, 11, 11), -0.25),
+                                            (16, 5, (7, 6, 6), 0.0)])
+def test_causal_depthwise_stateful_stream(C, kt, thw, value, dtype):
+    """The stateful entry (pb_dwconv3d_fwd_hist: (kt,3,3) depthwise kernels reading a caller-owned history buffer):
+    forward(clip) with a stream_buffer pad VALUE == F.pad(value) + conv3d, and forward_stream over chunks of 1, 2, 4
+    frames == forward(clip) (fp32: 1e-5; bf16: the same kernel arithmetic per output, so also tight)."""
+    torch.manual_seed(C + kt)
+    layer = picklebot_amd.CausalConv3d(C, C, (kt, 3, 3), padding=(0, 1, 1), groups=C, bias=False, stream_buffer=value).to(DEV).eval()
+    x = torch.randn(2, C, *thw)
+    want = _torch_causal(layer.conv3d.weight.detach().cpu(), None, x, value, (0, 1, 1))
+    xd = x.to(DEV).to(dtype)
+    tol = 1e-5 if dtype == torch.float32 else 1.5e-2
+    with torch.no_grad():
+        full = layer(xd)
+        assert rel_err(full.float().cpu().numpy(), want.numpy()) <= tol
+        for chunk in (1, 2, 4):
+            state, pieces = None, []
+            for t0 in range(0, thw[0], chunk):
+                y, state = layer.forward_stream(xd[:, :, t0:t0 + chunk], state)
+                pieces.append(y)
+            got = torch.cat(pieces, 2)
+            assert rel_err(got.float().cpu().numpy(), full.float().cpu().numpy()) <= (1e-6 if dtype == torch.float32 else 1e-6), chunk
+
+
+def test_causal_dense_stream_buffer_value():
+    """Dense CausalConv3d with a non-zero stream_buffer value (constant history frames, concatenated in front)."""
+    torch.manual_seed(2)
+    layer = picklebot_amd.CausalConv3d(8, 16, (3, 3, 3), padding=(0, 1, 1), stream_buffer=0.3).to(DEV).eval()
+    x = torch.randn(1, 8, 6, 9, 9)
+    want = _torch_causal(layer.conv3d.weight.detach().cpu(), layer.conv3d.bias.detach().cpu(), x, 0.3, (0, 1, 1))
+    with torch.no_grad():
+        got = layer(x.to(DEV))
+        assert rel_err(got.cpu().numpy(), want.numpy()) <= 1e-4
+        state, pieces = None, []
+        for t0 in range(0, 6, 2):
+            y, state = layer.forward_stream(x.to(DEV)[:, :, t0:t0 + 2], state)
+            pieces.append(y)
+        assert rel_err(torch.cat(pieces, 2).cpu().numpy(), got.cpu().numpy()) <= 1e-5
