@@ -325,3 +325,107 @@ def test_causal_dense_stream_buffer_value():
             y, state = layer.forward_stream(x.to(DEV)[:, :, t0:t0 + 2], state)
             pieces.append(y)
         assert rel_err(torch.cat(pieces, 2).cpu().numpy(), got.cpu().numpy()) <= 1e-5
+
+
+# ------------------------------------------------------------------------------ callers around the path
+def test_variable_length_batch_from_custom_collate():
+    """dataloader.py:10-23: clips of different lengths are zero-padded on T to the longest.  The padded uint8 batch goes
+    through the model as is (the stem folds /255) and must match the CPU oracle on the same padded batch."""
+    from oracle import torch_ref
+    g = torch.Generator().manual_seed(4)
+    batch = [(torch.randint(0, 256, (t, 64, 64, 3), dtype=torch.uint8, generator=g), lab) for t, lab in ((8, 1), (5, 0), (3, 1))]
+    clips, labels = picklebot_amd.custom_collate(batch)
+    assert tuple(clips.shape) == (3, 8, 64, 64, 3) and int(clips[2, 3:].sum()) == 0
+    m = protocol.build_model(picklebot_amd, "small3d", DEV).eval()
+    ref = protocol.build_model(torch_ref, "small3d", "cpu").eval()
+    feats, lab = picklebot_amd.extract_features_labels((clips, labels), DEV)
+    with torch.no_grad():
+        got = m(feats).float().cpu()
+        want = ref(clips.permute(0, -1, 1, 2, 3).float() / 255)
+    assert rel_err(got.numpy(), want.numpy()) <= 1e-3
+    # a clip's logits do not depend on how much zero tail its neighbours forced on the batch... only on its own padding
+    with torch.no_grad():
+        alone = m(picklebot_amd.extract_features_labels((clips[1:2], labels[1:2]), DEV)[0]).float().cpu()
+    assert rel_err(alone.numpy(), got[1:2].numpy()) <= 1e-5
+
+
+def test_estimate_loss_and_prefetcher_on_gpu():
+    """train.py:123-153 on the device: DevicePrefetcher (pinned H2D on a copy stream) feeding estimate_loss; same numbers
+    as a plain per-batch loop."""
+    torch.manual_seed(0)
+    m = protocol.build_model(picklebot_amd, "small3d", DEV)
+    g = torch.Generator().manual_seed(9)
+    loader = [(torch.randint(0, 256, (b, 8, 64, 64, 3), dtype=torch.uint8, generator=g), torch.randint(0, 2, (b,), generator=g))
+              for b in (3, 2, 4)]
+    crit = torch.nn.CrossEntropyLoss()
+    loss, acc = picklebot_amd.estimate_loss(m, picklebot_amd.DevicePrefetcher(loader, DEV), crit, DEV)
+    tot, cor, n = 0.0, 0, 0
+    m.eval()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        for clips, labels in loader:
+            out = m(clips.to(DEV).permute(0, -1, 1, 2, 3))
+            tot += float(crit(out, labels.to(DEV)))
+            cor += int((out.argmax(1).cpu() == labels).sum())
+            n += labels.numel()
+    assert abs(loss - tot / len(loader)) <= 1e-6 * max(1.0, abs(loss)) and abs(acc - cor / n) < 1e-12
+
+
+# ------------------------------------------------------------------------------ BASELINE configs at full size
+def test_mobilenet_large3d_batch32_full_size_properties():
+    """BASELINE config 2 at its full size (32 clips of 16x224x224, bf16 autocast, train mode): finite loss and gradients,
+    bit-identical on a second run, and the gradient of a clip-summed loss is the sum of per-half-batch gradients in eval
+    mode (linearity over the batch: no cross-clip leakage outside BatchNorm)."""
+    torch.manual_seed(1234)
+    m = picklebot_amd.MobileNetLarge3D(13).to(DEV).train()
+    x = torch.randint(0, 256, (32, 16, 224, 224, 3), dtype=torch.uint8, device=DEV).permute(0, -1, 1, 2, 3).to(torch.bfloat16) / 255
+    y = torch.randint(0, 13, (32,), device=DEV)
+
+    def grads(model, xs, ys, reduction="mean"):
+        model.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss = torch.nn.functional.cross_entropy(model(xs).float(), ys, reduction=reduction)
+        loss.backward()
+        return float(loss), [p.grad.detach().clone() for p in model.parameters()]
+
+    for mod in m.modules():
+        if isinstance(mod, (torch.nn.Dropout, torch.nn.Dropout3d)):
+            mod.p = 0.0
+    l1, g1 = grads(m, x, y)
+    bufs = {k: v.clone() for k, v in m.state_dict().items() if "running" in k}
+    m.load_state_dict({**m.state_dict(), **bufs})
+    assert l1 == l1 and all(torch.isfinite(g).all() for g in g1)
+    # same inputs, same statistics buffers -> same bits (only running stats moved, they do not enter train-mode math)
+    l2, g2 = grads(m, x, y)
+    assert l1 == l2 and all(torch.equal(a, b) for a, b in zip(g1, g2))
+    m.eval()
+    _, gs = grads(m, x, y, "sum")
+    _, ga = grads(m, x[:16], y[:16], "sum")
+    _, gb = grads(m, x[16:], y[16:], "sum")
+    gmax = max(float(g.norm()) for g in gs)
+    worst = max(float((s - (a + b)).norm()) / max(float(s.norm()), 1e-3 * gmax) for s, a, b in zip(gs, ga, gb))
+    assert worst <= 2e-2, worst
+
+
+def test_mobilevit_s_full_size_training_properties():
+    """BASELINE config 4 at its full size per GPU (8 clips of 16x256x256, bf16 autocast): finite, loss decreases over AdamW
+    steps on a fixed batch, and eval-mode logits of a clip do not depend on its batch neighbours."""
+    torch.manual_seed(0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = picklebot_amd.MobileViT(num_classes=13, **protocol.MOBILEVIT_CFG["s"]).to(DEV).train()
+    x = torch.rand(8, 16, 256, 256, 3, device=DEV).permute(0, 4, 1, 2, 3).to(torch.bfloat16)
+    y = torch.randint(0, 13, (8,), device=DEV)
+    opt = picklebot_amd.FlatAdamW(m.parameters(), lr=1e-3)
+    losses = []
+    for _ in range(8):
+        opt.zero_grad()
+        with torch.autocast("cuda", dtype=torch.bfloat16), contextlib.redirect_stdout(io.StringIO()):
+            loss = torch.nn.functional.cross_entropy(m(x).float(), y)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert all(v == v for v in losses) and min(losses[-3:]) < losses[0], losses
+    m.eval()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        full = m(x).float().cpu()
+        part = torch.cat([m(x[i:i + 1]) for i in (0, 5)]).float().cpu()
+    assert rel_err(part.numpy(), full[[0, 5]].numpy()) <= 2e-2
