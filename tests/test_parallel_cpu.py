@@ -85,8 +85,40 @@ def _worker(rank, world, port, q):
         dist.all_gather(outs, g)
     for got, outs in zip(mine, gathered):
         assert torch.allclose(got, sum(outs) / world, atol=1e-6), "packed gradient mismatch"
-    # .grad tensors are still views of the flat buckets
-    assert all(p.grad.data_ptr() >= red.flat[0].data_ptr() or True for p in model.parameters())
+    # .grad tensors are views of the flat buckets again
+    spans = [(f.data_ptr(), f.data_ptr() + f.numel() * f.element_size()) for f in red.flat]
+    assert all(any(lo <= p.grad.data_ptr() < hi for lo, hi in spans) for p in model.parameters())
+    # 4) a BatchNorm-bearing replica: BatchNorm is per rank (no SyncBN), so
+    #    train mode: the reduced gradient == the average of the per-shard gradients, each with its OWN batch statistics;
+    #    eval mode : the reduced gradient == the single-process gradient on the concatenated batch
+    def bn_model():
+        torch.manual_seed(5)
+        return nn.Sequential(nn.Conv3d(3, 6, 1), nn.BatchNorm3d(6), nn.Hardswish(), nn.AdaptiveAvgPool3d(1), nn.Flatten(),
+                             nn.Linear(6, 4))
+    torch.manual_seed(11)
+    clips = torch.randn(world, 4, 3, 2, 5, 5)
+    labels = torch.randint(0, 4, (world, 4))
+    for train in (True, False):
+        m = bn_model().train(train)
+        rd = GradReducer(m, bucket_bytes=64)
+        rd.zero_grad()
+        # mean over the LOCAL shard; the reducer averages over ranks = mean over the global batch (equal shard sizes)
+        nn.functional.cross_entropy(m(clips[rank]), labels[rank]).backward()
+        rd.finish()
+        got = [p.grad.clone() for p in m.parameters()]
+        if train:
+            shard = []
+            for r in range(world):
+                ref_m = bn_model().train()
+                nn.functional.cross_entropy(ref_m(clips[r]), labels[r]).backward()
+                shard.append([p.grad.clone() for p in ref_m.parameters()])
+            want = [sum(gs) / world for gs in zip(*shard)]
+        else:
+            ref_m = bn_model().eval()
+            nn.functional.cross_entropy(ref_m(clips.flatten(0, 1)), labels.flatten()).backward()
+            want = [p.grad.clone() for p in ref_m.parameters()]
+        for a, b in zip(got, want):
+            assert torch.allclose(a, b, atol=1e-6, rtol=1e-5), ("BatchNorm replica", train, (a - b).abs().max())
     dist.barrier()
     dist.destroy_process_group()
     q.put((rank, "ok"))
