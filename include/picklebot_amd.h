@@ -299,6 +299,23 @@ int pb_se_fc_bwd(const float* dscale, const float* pool, float inv_count, const 
                  const float* w1, const float* w2, float* g_shift, float* dw1, float* db1, float* dw2, float* db2,
                  float* work, int G, int C, int Cm, int device, void* stream);
 
+/* The same two steps fused, reading the squeeze partial sums directly (one launch forward, two backward instead of
+ * four + six): pool_part / dscale_part are fp32 [slots][G][C] (pb_dwconv3d_fwd's pool_part; pb_rowgroup_partials);
+ * pool [G][C] is written forward (the slot sum) and read backward.  Optional wproj (fp32 [N][C]) + wbs (bf16 [G][N][C]):
+ * the projection conv's weights scaled per clip, wbs[g][n][c] = wproj[n][c] * scale[g][c], which pb_pwconv_fwd_bf16w
+ * takes as per-group weights (C % 8 == 0). */
+int pb_se_fused_fwd(const float* pool_part, int slots, float inv_count, const float* w1, const float* b1, const float* w2,
+                    const float* b2, float* pool, float* scale, float* hidden, const float* wproj, void* wbs_bf16, int N,
+                    int G, int C, int Cm, int device, void* stream);
+int pb_se_fused_bwd(const float* dscale_part, int slots, const float* pool, float inv_count, const float* scale,
+                    const float* hidden, const float* w1, const float* w2, float* g_shift, float* dw1, float* db1,
+                    float* dw2, float* db2, float* work, int G, int C, int Cm, int device, void* stream);
+/* Row-group partial sums only (the first half of pb_rowgroup_reduce): part fp32 [slots][G][C] with
+ * slots = pb_rowgroup_slots(...) for a consumer that adds the slots itself (pb_se_fused_bwd / pb_se_fused_fwd). */
+int pb_rowgroup_slots(int64_t G, int64_t rows_per_group, int C, pb_dtype dtype);
+int pb_rowgroup_partials(const void* a, const void* b, float* part, int64_t G, int64_t rows_per_group, int C,
+                         pb_dtype dtype, int device, void* stream);
+
 /* ---------------------------------------------------------------- MobileViT token-side helpers
  * pb_unfold_fold: einops 'b d (t pt)(h ph)(w pw) -> b (pt ph pw)(t h w) d' and its inverse incl. the
  *   zero padding to patch multiples / the crop (mobilevit.py:129-137).  Voxels [B,T,H,W,D] (unpadded),

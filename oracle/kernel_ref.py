@@ -77,7 +77,8 @@ def _prologue(x, in_scale, in_shift, in_act, in_slope, row_scale, rows_per_group
 
 
 def pw_fwd(x, w, *, w_transposed=False, in_scale=None, in_shift=None, in_act="none", in_slope=0.0, row_scale=None,
-           rows_per_group=0, out_scale=None, out_shift=None, out_act="none", out_slope=0.0, stats=None, residual=None):
+           rows_per_group=0, out_scale=None, out_shift=None, out_act="none", out_slope=0.0, stats=None, residual=None,
+           scaled_weights=None):
     xf = _prologue(x, in_scale, in_shift, in_act, in_slope, row_scale, rows_per_group)
     wl = (w.t() if w_transposed else w).to(x.dtype).float()
     acc = xf @ wl.t()
@@ -120,6 +121,13 @@ def dw_fwd(x, w, kernel, stride, pad_front, pad_back=None, pool=None):
     if pool is not None:
         pool.copy_(y.float().sum((1, 2, 3)))
     return y
+
+
+def dw_fwd_pool(x, w, kernel, stride, pad_front, pad_back=None):
+    """Mirror of kernels.dw_fwd_pool: one slot holding the whole sum."""
+    pool = torch.zeros(x.shape[0], x.shape[4])
+    y = dw_fwd(x, w, kernel, stride, pad_front, pad_back, pool=pool)
+    return y, pool.unsqueeze(0)
 
 
 def dw_fwd_hist(x, hist, w, kernel, stride, pad_front, pad_back=None):
@@ -313,6 +321,20 @@ def se_fc_fwd(pool, inv_count, w1, b1, w2, b2):
     if b2 is not None:
         pre = pre + b2
     return torch.clamp(pre / 6 + 0.5, 0, 1), h
+
+
+def se_fused_fwd(pool_part, inv_count, w1, b1, w2, b2, wproj=None, want_scaled=False):
+    pool = pool_part.sum(0)
+    scale, hidden = se_fc_fwd(pool, inv_count, w1, b1, w2, b2)
+    return pool, scale, hidden, None
+
+
+def rowgroup_partials(a, b, G):
+    return rowgroup_reduce(a, b, G).unsqueeze(0)
+
+
+def se_fused_bwd(dscale_part, pool, inv_count, scale, hidden, w1, w2, want_bias=True):
+    return se_fc_bwd(dscale_part.sum(0), pool, inv_count, scale, hidden, w1, w2, want_bias)
 
 
 def se_fc_bwd(dscale, pool, inv_count, scale, hidden, w1, w2, want_bias=True):

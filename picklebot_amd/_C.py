@@ -59,6 +59,9 @@ SIGNATURES = {
     "pb_rowgroup_reduce": [P, P, P, L, L, I, I, P, L, I, P],
     "pb_se_fc_fwd": [P, F, P, P, P, P, P, P, I, I, I, I, P],
     "pb_se_fc_bwd": [P, P, F, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P],
+    "pb_se_fused_fwd": [P, I, F, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P],
+    "pb_se_fused_bwd": [P, I, P, F, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P],
+    "pb_rowgroup_partials": [P, P, P, L, L, I, I, I, P],
     "pb_transpose_f32": [P, P, I, I, I, P],
     "pb_pw_weight_prep": [P, I, I, I, P, I, P, I, P],
     "pb_pw_weight_prep_batch": [P, I, I, P],
@@ -96,6 +99,7 @@ SIZE_SIGNATURES = {
 # entry points returning a plain int count
 COUNT_SIGNATURES = {
     "pb_dwconv3d_pool_slots": [POINTER(DwShape), I],
+    "pb_rowgroup_slots": [L, L, I, I],
 }
 
 

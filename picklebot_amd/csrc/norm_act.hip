@@ -591,6 +591,35 @@ int64_t rowgroup_gx(int64_t G, int64_t rows_per_group, int C, pb_dtype dtype, Ro
 }
 }  // namespace
 
+extern "C" int pb_rowgroup_slots(int64_t G, int64_t rows_per_group, int C, pb_dtype dtype) {
+  if (G <= 0 || rows_per_group <= 0 || C <= 0) return 0;
+  return (int)rowgroup_gx(G, rows_per_group, C, dtype, nullptr);
+}
+
+extern "C" int pb_rowgroup_partials(const void* a_, const void* b_, float* part, int64_t G, int64_t rows_per_group, int C,
+                                    pb_dtype dtype, int device, void* stream) {
+  PB_CHECK_ARG(a_ && part, "pb_rowgroup_partials: null pointer");
+  PB_CHECK_ARG(G > 0 && G <= 65535 && rows_per_group > 0 && C > 0, "pb_rowgroup_partials: bad sizes");
+  PB_CHECK_ARG(dtype == PB_F32 || dtype == PB_BF16, "pb_rowgroup_partials: bad dtype");
+  PB_ENTER(device);
+  RgArgs a;
+  a.a = a_; a.b = b_; a.R = rows_per_group; a.C = C; a.out = part;
+  const int vec = dtype == PB_BF16 ? 8 : 4;
+  const bool v = (C % vec) == 0;
+  const int64_t gx = rowgroup_gx(G, rows_per_group, C, dtype, &a.map);
+  dim3 grid((unsigned)gx, (unsigned)a.map.chunks, (unsigned)G);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == PB_BF16) {
+    if (v) hipLaunchKernelGGL((rowgroup_kernel<bf16_t, 8>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((rowgroup_kernel<bf16_t, 1>), grid, dim3(256), 0, st, a);
+  } else {
+    if (v) hipLaunchKernelGGL((rowgroup_kernel<float, 4>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((rowgroup_kernel<float, 1>), grid, dim3(256), 0, st, a);
+  }
+  PB_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int64_t pb_rowgroup_reduce_ws_bytes(int64_t G, int64_t rows_per_group, int C, pb_dtype dtype) {
   if (G <= 0 || rows_per_group <= 0 || C <= 0) return 0;
   const int64_t gx = rowgroup_gx(G, rows_per_group, C, dtype, nullptr);

@@ -161,17 +161,22 @@ class _Bottleneck(torch.autograd.Function):
         e2 = K.pw_fwd(x2, w1.view(E, Cin))
         e5 = e2.view(N, T, H, W, E)
         training_bn = has_bn and training
-        pool, stats = _zeros_many(x5, (N, E) if has_se else (0,), (K.REPL, 2, Cout) if training_bn else (0,))
-        pool = pool if has_se else None
-        stats = stats if training_bn else None
-        d5 = K.dw_fwd(e5, wdw.view(E, -1), kernel, stride, pad, pool=pool)
+        stats = _zeros((K.REPL, 2, Cout), x5) if training_bn else None
+        pool = se_scale = hidden = wbs = None
+        if has_se:
+            # squeeze partial sums ride on the depthwise kernel; ONE launch turns them into pool / hidden / scale and the
+            # per-clip scaled bf16 projection weights (the squeeze-excite scale is folded into the GEMM's weights)
+            d5, pool_part = K.dw_fwd_pool(e5, wdw.view(E, -1), kernel, stride, pad)
+        else:
+            d5 = K.dw_fwd(e5, wdw.view(E, -1), kernel, stride, pad)
         To, Ho, Wo = d5.shape[1:4]
         R2 = To * Ho * Wo
         d2 = d5.view(-1, E)
-        se_scale = hidden = None
         if has_se:
             Cm = se_w1.shape[0]
-            se_scale, hidden = K.se_fc_fwd(pool, 1.0 / R2, se_w1.view(Cm, E), se_b1, se_w2.view(E, Cm), se_b2)
+            want_scaled = d2.dtype == torch.bfloat16 and R2 >= 128
+            pool, se_scale, hidden, wbs = K.se_fused_fwd(pool_part, 1.0 / R2, se_w1.view(Cm, E), se_b1, se_w2.view(E, Cm), se_b2,
+                                                         wproj=w2.view(Cout, E), want_scaled=want_scaled)
         need_grad = cfg["need_grad"]
         bnc = None
         if has_bn and not training and not need_grad:
@@ -179,9 +184,9 @@ class _Bottleneck(torch.autograd.Function):
             eps, momentum = cfg["bn"]
             scale, shift, _, _ = _bn_forward(d2, None, 1, gamma, beta, rmean, rvar, eps, momentum, False)
             y2 = K.pw_fwd(d2, w2.view(Cout, E), row_scale=se_scale, rows_per_group=R2, out_scale=scale,
-                          out_shift=shift, out_act=act, out_slope=slope)
+                          out_shift=shift, out_act=act, out_slope=slope, scaled_weights=wbs)
             return y2.view(N, To, Ho, Wo, Cout)
-        z2 = K.pw_fwd(d2, w2.view(Cout, E), row_scale=se_scale, rows_per_group=R2, stats=stats)
+        z2 = K.pw_fwd(d2, w2.view(Cout, E), row_scale=se_scale, rows_per_group=R2, stats=stats, scaled_weights=wbs)
         scale = shift = None
         if has_bn:
             eps, momentum = cfg["bn"]
@@ -220,9 +225,9 @@ class _Bottleneck(torch.autograd.Function):
             dS2 = K.pw_fwd(dz, w2.view(Cout, E), w_transposed=True)
             if has_se:
                 Cm = se_w1.shape[0]
-                dscale = K.rowgroup_reduce(dS2, d2, N)
-                g_shift, dse_w1, dse_b1, dse_w2, dse_b2 = K.se_fc_bwd(dscale, pool, 1.0 / R2, se_scale, hidden,
-                                                                      se_w1.view(Cm, E), se_w2.view(E, Cm))
+                dpart = K.rowgroup_partials(dS2, d2, N)
+                g_shift, dse_w1, dse_b1, dse_w2, dse_b2 = K.se_fused_bwd(dpart, pool, 1.0 / R2, se_scale, hidden,
+                                                                         se_w1.view(Cm, E), se_w2.view(E, Cm))
                 g_scale = se_scale
                 dse_w1, dse_w2 = dse_w1.view_as(se_w1), dse_w2.view_as(se_w2)
             dS5 = dS2.view(N, To, Ho, Wo, E)

@@ -326,9 +326,11 @@ class WeightSet:
 
 
 def pw_fwd(x, w, *, w_transposed=False, in_scale=None, in_shift=None, in_act="none", in_slope=0.0, row_scale=None,
-           rows_per_group=0, out_scale=None, out_shift=None, out_act="none", out_slope=0.0, stats=None, residual=None):
+           rows_per_group=0, out_scale=None, out_shift=None, out_act="none", out_slope=0.0, stats=None, residual=None,
+           scaled_weights=None):
     """y[M,N] = P(x)[M,K] @ Wl[N,K]^T with fused prologue/epilogue (see pb_pwconv_fwd).
-    w: fp32 [N,K], or [K,N] with w_transposed (backward-data)."""
+    w: fp32 [N,K], or [K,N] with w_transposed (backward-data).  scaled_weights: bf16 [groups,N,K] = w * row_scale per
+    clip, already made by se_fused_fwd (saves the weight-preparation launch of the row_scale path)."""
     _rows(x, "x")
     M, K = x.shape
     _f32(w, name="w")
@@ -370,9 +372,12 @@ def pw_fwd(x, w, *, w_transposed=False, in_scale=None, in_shift=None, in_act="no
         groups = 1
         if row_scale is not None:
             groups = M // rows_per_group
-            wbs = torch.empty((groups, N, K), dtype=torch.bfloat16, device=x.device)
-            _launch("pw_weight_prep_kernel", _nb(w, row_scale, wbs), "pb_pw_weight_prep", _p(w), N, K, 0, _p(row_scale), groups,
-                    _p(wbs), dev, st)
+            if scaled_weights is not None and tuple(scaled_weights.shape) == (groups, N, K) and not w_transposed:
+                wbs = scaled_weights
+            else:
+                wbs = torch.empty((groups, N, K), dtype=torch.bfloat16, device=x.device)
+                _launch("pw_weight_prep_kernel", _nb(w, row_scale, wbs), "pb_pw_weight_prep", _p(w), N, K, 0, _p(row_scale), groups,
+                        _p(wbs), dev, st)
             wb = wbs
         _launch("pw_gemm_dma_kernel", _nb(x, y) + N * K * 2, "pb_pwconv_fwd_bf16w", _p(x), _p(wb), _p(y), M, K, N, groups,
                 int(rows_per_group) if groups > 1 else 0, _p(out_scale), _p(out_shift), ACT[out_act], float(out_slope),
@@ -485,6 +490,26 @@ def dw_fwd(x, w, kernel, stride, pad_front, pad_back=None, pool=None):
     if pool is not None and slots > 1:
         partials_reduce([(part, pool, N * C, N * C, slots, 0)], x.device)
     return y
+
+
+def dw_fwd_pool(x, w, kernel, stride, pad_front, pad_back=None):
+    """Depthwise conv with the fused squeeze: -> (y, pool_part fp32 [slots, N, C]); the per-work-unit partial sums of y over
+    (To,Ho,Wo) are consumed by se_fused_fwd (which adds the slots in a fixed order)."""
+    _ndhwc(x, "x")
+    N, T, H, W, C = x.shape
+    taps = kernel[0] * kernel[1] * kernel[2]
+    _f32(w, (C, taps), "w")
+    out = dw_out_shape((T, H, W), kernel, stride, pad_front, pad_back)
+    if min(out) <= 0:
+        raise ValueError(f"dw_fwd_pool: empty output {out}")
+    y = torch.empty((N,) + out + (C,), dtype=x.dtype, device=x.device)
+    s = _dw_shape(N, C, (T, H, W), out, kernel, stride, pad_front)
+    dev, st = _dev_stream(x)
+    slots = int(_C.load().pb_dwconv3d_pool_slots(ctypes.byref(s), _dt(x)))
+    part = torch.empty((slots, N, C), dtype=torch.float32, device=x.device)
+    _launch(_dw_kernel_name(0, s, _dt(x)), _nb(x, y, w), "pb_dwconv3d_fwd", _p(x), _p(w), _p(y), ctypes.byref(s), _dt(x), _p(part), slots,
+            dev, st, detail=f"C{C} {T}x{H}x{W}->{out[0]}x{out[1]}x{out[2]} k{kernel} s{stride}")
+    return y, part
 
 
 def dw_fwd_hist(x, hist, w, kernel, stride, pad_front, pad_back=None):
@@ -754,6 +779,68 @@ def se_fc_bwd(dscale, pool, inv_count, scale, hidden, w1, w2, want_bias=True):
     _launch("se_fc_bwd", _nb(pool, w1, w2, dw1, dw2), "pb_se_fc_bwd", _p(dscale), _p(pool), float(inv_count), _p(scale), _p(hidden), _p(w1), _p(w2),
             _p(g_shift), _p(dw1), _p(db1) if want_bias else None, _p(dw2), _p(db2) if want_bias else None, _p(work),
             G, C, Cm, dev, st)
+    return g_shift, dw1, (db1 if want_bias else None), dw2, (db2 if want_bias else None)
+
+
+def se_fused_fwd(pool_part, inv_count, w1, b1, w2, b2, wproj=None, want_scaled=False):
+    """pool_part fp32 [slots,G,C] -> (pool [G,C], scale [G,C], hidden [G,Cm], wbs): ONE launch.  wbs (want_scaled and
+    wproj fp32 [N,C] given, C and N multiples of 8): bf16 [G,N,C] = wproj * scale per clip for pw_fwd(scaled_weights=)."""
+    if pool_part.dim() != 3:
+        raise ValueError("se_fused_fwd: pool_part must be [slots, G, C]")
+    slots, G, C = pool_part.shape
+    Cm = w1.shape[0]
+    _f32(pool_part, name="pool_part"); _f32(w1, (Cm, C), "w1"); _f32(w2, (C, Cm), "w2"); _f32(b1, (Cm,), "b1"); _f32(b2, (C,), "b2")
+    dev_t = pool_part.device
+    pool = torch.empty((G, C), dtype=torch.float32, device=dev_t)
+    scale = torch.empty((G, C), dtype=torch.float32, device=dev_t)
+    hidden = torch.empty((G, Cm), dtype=torch.float32, device=dev_t)
+    wbs, N = None, 0
+    if want_scaled and wproj is not None and C % 8 == 0 and wproj.shape[0] % 8 == 0 and wproj.data_ptr() % 16 == 0:
+        _f32(wproj, (wproj.shape[0], C), "wproj")
+        N = wproj.shape[0]
+        wbs = torch.empty((G, N, C), dtype=torch.bfloat16, device=dev_t)
+    dev, st = _dev_stream(pool_part)
+    _launch("se_fused_fwd", _nb(pool_part, w1, w2, scale, wbs), "pb_se_fused_fwd", _p(pool_part), slots, float(inv_count), _p(w1), _p(b1),
+            _p(w2), _p(b2), _p(pool), _p(scale), _p(hidden), _p(wproj if wbs is not None else None), _p(wbs), N, G, C, Cm, dev, st)
+    return pool, scale, hidden, wbs
+
+
+def rowgroup_partials(a, b, G):
+    """Per-workgroup partial sums [slots,G,C] of rowgroup_reduce (for se_fused_bwd, which adds the slots itself)."""
+    _rows(a, "a")
+    M, C = a.shape
+    if M % G:
+        raise ValueError("rowgroup_partials: G must divide M")
+    if b is not None:
+        _rows(b, "b")
+        if b.shape != a.shape or b.dtype != a.dtype:
+            raise ValueError("rowgroup_partials: a/b mismatch")
+    slots = int(_C.load().pb_rowgroup_slots(G, M // G, C, _dt(a)))
+    part = torch.empty((slots, G, C), dtype=torch.float32, device=a.device)
+    dev, st = _dev_stream(a)
+    _launch("rowgroup_kernel", _nb(a, b, part), "pb_rowgroup_partials", _p(a), _p(b), _p(part), G, M // G, C, _dt(a), dev, st,
+            detail=f"M{M} C{C} G{G}")
+    return part
+
+
+def se_fused_bwd(dscale_part, pool, inv_count, scale, hidden, w1, w2, want_bias=True):
+    """dscale_part fp32 [slots,G,C] -> (g_shift [G,C], dw1, db1, dw2, db2): two launches (per-clip vectors; weight grads)."""
+    slots, G, C = dscale_part.shape
+    Cm = w1.shape[0]
+    for t, shp, n in ((pool, (G, C), "pool"), (scale, (G, C), "scale"), (hidden, (G, Cm), "hidden"), (w1, (Cm, C), "w1"),
+                      (w2, (C, Cm), "w2")):
+        _f32(t, shp, n)
+    _f32(dscale_part, name="dscale_part")
+    dev_t = pool.device
+    g_shift = torch.empty((G, C), dtype=torch.float32, device=dev_t)
+    flat = zeros(2 * C * Cm + C + Cm, dev_t)
+    dw1, dw2 = flat[:C * Cm].view(Cm, C), flat[C * Cm:2 * C * Cm].view(C, Cm)
+    db1, db2 = flat[2 * C * Cm:2 * C * Cm + Cm], flat[2 * C * Cm + Cm:]
+    work = torch.empty(G * (C + Cm), dtype=torch.float32, device=dev_t)
+    dev, st = _dev_stream(pool)
+    _launch("se_fused_bwd", _nb(dscale_part, w1, w2, dw1, dw2), "pb_se_fused_bwd", _p(dscale_part), slots, _p(pool), float(inv_count),
+            _p(scale), _p(hidden), _p(w1), _p(w2), _p(g_shift), _p(dw1), _p(db1) if want_bias else None, _p(dw2),
+            _p(db2) if want_bias else None, _p(work), G, C, Cm, dev, st)
     return g_shift, dw1, (db1 if want_bias else None), dw2, (db2 if want_bias else None)
 
 

@@ -515,3 +515,38 @@ def test_flat_adamw_lr_follows_scheduler_under_graph_replay(K):
         torch.cuda.synchronize()
         check(f"adamw_graph_lr{lr}", p.detach(), ref_p, torch.float32)
     assert float(opt.step_t) == step
+
+
+@pytest.mark.parametrize("G,C,Cm,N,slots", [(3, 72, 18, 24, 5), (2, 960, 240, 160, 19), (4, 120, 30, 40, 40), (1, 16, 4, 8, 1),
+                                            (2, 576, 144, 96, 33)])
+def test_se_fused_forward_backward(K, G, C, Cm, N, slots):
+    """The one-launch squeeze-excite gate (slot sum + two GEMVs + per-clip scaled bf16 projection weights) and the fused
+    backward against the mirrors."""
+    part = rnd((slots, G, C), seed=40) * 3
+    w1, b1, w2, b2 = rnd((Cm, C), seed=41) * C ** -0.5, rnd((Cm,), seed=42) * 0.1, rnd((C, Cm), seed=43) * Cm ** -0.5, rnd((C,), seed=44) * 0.1
+    wproj = rnd((N, C), seed=45)
+    pool_r, scale_r, hid_r, _ = R.se_fused_fwd(part, 1 / 50, w1, b1, w2, b2)
+    pool, scale, hid, wbs = K.se_fused_fwd(dev(part), 1 / 50, dev(w1), dev(b1), dev(w2), dev(b2), wproj=dev(wproj), want_scaled=True)
+    check("se_pool", pool, pool_r, torch.float32); check("se_scale", scale, scale_r, torch.float32)
+    check("se_hidden", hid, hid_r, torch.float32)
+    assert wbs is not None and wbs.dtype == torch.bfloat16
+    check("se_wbs", wbs, (wproj[None] * scale_r[:, None, :]), torch.bfloat16)
+    dpart = rnd((slots, G, C), seed=46)
+    out_r = R.se_fused_bwd(dpart, pool_r, 1 / 50, scale_r, hid_r, w1, w2)
+    out = K.se_fused_bwd(dev(dpart), dev(pool_r), 1 / 50, dev(scale_r), dev(hid_r), dev(w1), dev(w2))
+    for a, b, name in zip(out, out_r, ("g_shift", "dw1", "db1", "dw2", "db2")):
+        check("se_fused_bwd_" + name, a, b, torch.float32, 2.0)
+    # bit-reproducible
+    again = K.se_fused_bwd(dev(dpart), dev(pool_r), 1 / 50, dev(scale_r), dev(hid_r), dev(w1), dev(w2))
+    assert all(torch.equal(a, b) for a, b in zip(out, again))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_pool_and_rowgroup_partials_sum_to_the_totals(K, dtype):
+    x = rnd((2, 5, 14, 14, 72), dtype, 50)
+    w = rnd((72, 9), seed=51)
+    y, part = K.dw_fwd_pool(dev(x), dev(w), (1, 3, 3), (1, 1, 1), (1, 1, 1))
+    y_ref, part_ref = R.dw_fwd_pool(x, w, (1, 3, 3), (1, 1, 1), (1, 1, 1))
+    check("dw_fwd_pool_y", y, y_ref, dtype); check("dw_fwd_pool_sum", part.sum(0), part_ref.sum(0), dtype)
+    a, b = rnd((6 * 70, 40), dtype, 52), rnd((6 * 70, 40), dtype, 53)
+    check("rowgroup_partials", K.rowgroup_partials(dev(a), dev(b), 6).sum(0), R.rowgroup_reduce(a, b, 6), dtype)
