@@ -114,12 +114,11 @@ __global__ __launch_bounds__(256) void se_fc_bwd_w_kernel(const float* work, con
 
 
 // ---------------------------------------------------------------------------------------------- fused forms
-// One launch per squeeze-excite block and direction (the training step used to spend 4 + 6 launches on each of its
-// 8 blocks).  One workgroup (1024 threads) per clip; every sum is added in a fixed order.
-constexpr int SEF_T = 1024, SEF_W = SEF_T / 64;
-
+// Two launches forward (was 4: slot reduction, two GEMVs, weight scaling) and three backward (was 6), every one with
+// hundreds of workgroups: a single workgroup per clip was tried first and is latency-bound (116 us for C = 960).
+// Every sum is added in a fixed order.
 struct SeFwdArgs {
-  const float* part;      // pool partial sums [slots][G][C] (pb_dwconv3d_fwd / pb_rowgroup partials)
+  const float* part;      // pool partial sums [slots][G][C] (pb_dwconv3d_fwd / pb_rowgroup_partials)
   int slots;
   float inv_count;
   const float* w1; const float* b1; const float* w2; const float* b2;
@@ -131,73 +130,98 @@ struct SeFwdArgs {
   int G, C, Cm, N;
 };
 
-__global__ __launch_bounds__(SEF_T) void se_fused_fwd_kernel(SeFwdArgs a) {
-  extern __shared__ float sm[];                 // [SEF_W][C] slot-group partials, then pool[C] | hidden[Cm] | scale[C]
-  const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int C = a.C, Cm = a.Cm;
-  // phase A: pool[c] = sum over slots; wave w adds the slots w, w+16, ... (lanes along c: coalesced), then the 16
-  // wave partials are added in wave order
-  for (int c = lane; c < C; c += 64) {
-    float s0 = 0.f, s1 = 0.f;
-    int sl = wave;
-    for (; sl + SEF_W < a.slots; sl += 2 * SEF_W) {
-      s0 += a.part[((int64_t)sl * a.G + g) * C + c];
-      s1 += a.part[((int64_t)(sl + SEF_W) * a.G + g) * C + c];
-    }
-    if (sl < a.slots) s0 += a.part[((int64_t)sl * a.G + g) * C + c];
-    sm[wave * C + c] = s0 + s1;
-  }
-  __syncthreads();
-  float* pool = sm + SEF_W * C;
-  float* hid = pool + C;
-  float* scl = hid + Cm;
-  for (int c = tid; c < C; c += SEF_T) {
-    float s = 0.f;
+// sum over the slots of part[.][g][c] for c = tid, tid + nthreads, ... -> dst (LDS).  Eight loads in flight per thread:
+// with 4 the loop was a chain of ~50 memory round trips (20 us per launch).
+__device__ __forceinline__ void slot_sum_to_lds(const float* part, int slots, int G, int g, int C, float* dst, int nthreads) {
+  for (int c = threadIdx.x; c < C; c += nthreads) {
+    const float* p = part + (int64_t)g * C + c;
+    const int64_t st = (int64_t)G * C;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int sl = 0;
+    for (; sl + 8 <= slots; sl += 8) {
+      float v[8];
 #pragma unroll
-    for (int w = 0; w < SEF_W; ++w) s += sm[w * C + c];
-    pool[c] = s;
-    a.pool[(int64_t)g * C + c] = s;
-  }
-  __syncthreads();
-  // phase B: hidden[j] = relu(b1[j] + inv_count * W1[j,:] . pool): one wavefront per output, lanes over c
-  for (int j = wave; j < Cm; j += SEF_W) {
-    const float* wr = a.w1 + (int64_t)j * C;
-    float s = 0.f;
-    for (int c = lane; c < C; c += 64) s += wr[c] * pool[c];
-    s = wave_sum(s) * a.inv_count + (a.b1 ? a.b1[j] : 0.f);
-    s = s > 0.f ? s : 0.f;
-    if (lane == 0) {
-      hid[j] = s;
-      a.hidden[(int64_t)g * Cm + j] = s;
+      for (int u = 0; u < 8; ++u) v[u] = p[(sl + u) * st];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc[u] += v[u];
     }
+    for (; sl < slots; ++sl) acc[0] += p[sl * st];
+    dst[c] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
   }
+}
+
+constexpr int SE_HT = 1024;   // threads of se_hidden_kernel
+constexpr int SE_JB = 64;     // hidden outputs per workgroup (16 waves x 4, computed together)
+
+// hidden[g][j] = relu(b1[j] + inv_count * W1[j,:] . pool[g,:]), pool = slot sum.  grid (ceil(Cm/64), G), 1024 threads.
+__global__ __launch_bounds__(SE_HT) void se_hidden_kernel(SeFwdArgs a) {
+  extern __shared__ float sm[];                 // pool[C]
+  const int g = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int C = a.C;
+  slot_sum_to_lds(a.part, a.slots, a.G, g, C, sm, SE_HT);
   __syncthreads();
-  // phase C: scale[c] = hardsigmoid(b2[c] + W2[c,:] . hidden): one wavefront per output, lanes over j
-  for (int c = wave; c < C; c += SEF_W) {
-    const float* wr = a.w2 + (int64_t)c * Cm;
-    float s = 0.f;
-    for (int j = lane; j < Cm; j += 64) s += wr[j] * hid[j];
-    s = wave_sum(s) + (a.b2 ? a.b2[c] : 0.f);
-    s = fminf(fmaxf(s * (1.f / 6.f) + 0.5f, 0.f), 1.f);
-    if (lane == 0) {
-      scl[c] = s;
-      a.scale[(int64_t)g * C + c] = s;
+  if (blockIdx.x == 0)
+    for (int c = threadIdx.x; c < C; c += SE_HT) a.pool[(int64_t)g * C + c] = sm[c];
+  const int j0 = blockIdx.x * SE_JB + wave * 4;
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int c = lane; c < C; c += 64) {
+    const float p = sm[c];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (j0 + q < a.Cm) s[q] += a.w1[(int64_t)(j0 + q) * C + c] * p;
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float v = wave_sum(s[q]) * a.inv_count + ((a.b1 && j0 + q < a.Cm) ? a.b1[j0 + q] : 0.f);
+    if (lane == 0 && j0 + q < a.Cm) a.hidden[(int64_t)g * a.Cm + j0 + q] = v > 0.f ? v : 0.f;
+  }
+}
+
+// scale[g][c] = hardsigmoid(b2[c] + W2[c,:] . hidden[g,:]) for a block of 64 channels, then the block's columns of the
+// per-clip scaled bf16 projection weights.  grid (ceil(C/64), G), 256 threads.
+__global__ __launch_bounds__(256) void se_scale_kernel(SeFwdArgs a) {
+  extern __shared__ float sm[];                 // hidden[Cm] | scale block[64]
+  const int g = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int C = a.C, Cm = a.Cm;
+  float* hid = sm;
+  float* scl = sm + Cm;
+  for (int j = tid; j < Cm; j += 256) hid[j] = a.hidden[(int64_t)g * Cm + j];
+  __syncthreads();
+  const int cb = blockIdx.x * 64;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {                 // 16 channels per wave, 4 at a time
+    const int c0 = cb + wave * 16 + r * 4;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int j = lane; j < Cm; j += 64) {
+      const float h = hid[j];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (c0 + q < C) s[q] += a.w2[(int64_t)(c0 + q) * Cm + j] * h;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float v = wave_sum(s[q]) + ((a.b2 && c0 + q < C) ? a.b2[c0 + q] : 0.f);
+      v = fminf(fmaxf(v * (1.f / 6.f) + 0.5f, 0.f), 1.f);
+      if (lane == 0) {
+        scl[wave * 16 + r * 4 + q] = v;
+        if (c0 + q < C) a.scale[(int64_t)g * C + c0 + q] = v;
+      }
     }
   }
   if (!a.wbs) return;
   __syncthreads();
-  // phase D: this clip's scaled bf16 copy of the projection weights ((X * s) W^T = X (W * s)^T): 8 elements per thread
-  const int64_t total8 = (int64_t)a.N * C / 8;
+  // this clip's scaled bf16 copy of the projection weights, columns cb .. cb+63 ((X * s) W^T = X (W * s)^T)
+  const int chunks = min(64, C - cb) / 8;       // C % 8 == 0
   bf16_t* out = a.wbs + (int64_t)g * a.N * C;
-  for (int64_t i = tid; i < total8; i += SEF_T) {
-    const int64_t e = i * 8;
-    const int c0 = (int)(e % C);
+  for (int i = tid; i < a.N * chunks; i += 256) {
+    const int n = i / chunks, ch = i - n * chunks;
+    const int64_t e = (int64_t)n * C + cb + ch * 8;
     const f32x4 w0 = *reinterpret_cast<const f32x4*>(a.wproj + e), w1v = *reinterpret_cast<const f32x4*>(a.wproj + e + 4);
     bf16x8 o;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      o[q] = (bf16_t)(w0[q] * scl[c0 + q]);
-      o[4 + q] = (bf16_t)(w1v[q] * scl[c0 + 4 + q]);
+      o[q] = (bf16_t)(w0[q] * scl[ch * 8 + q]);
+      o[4 + q] = (bf16_t)(w1v[q] * scl[ch * 8 + 4 + q]);
     }
     *reinterpret_cast<bf16x8*>(out + e) = o;
   }
@@ -213,78 +237,76 @@ struct SeBwdArgs {
   int G, C, Cm;
 };
 
-__global__ __launch_bounds__(SEF_T) void se_fused_bwd_kernel(SeBwdArgs a) {
-  extern __shared__ float sm[];                 // [SEF_W][max(C, 64)] partials, then dpre2[C] | dh[Cm]
-  const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+constexpr int SEB_T = 1024, SEB_W = SEB_T / 64;
+
+// dpre2[g][c] = hardsigmoid'(.) * (slot sum of dscale); dh[g][j] = [hidden > 0] * sum_c W2[c][j] * dpre2[c] for a block of
+// 64 outputs j: lanes over j (W2 rows are contiguous in j), the 16 waves split c.  grid (ceil(Cm/64), G), 1024 threads.
+__global__ __launch_bounds__(SEB_T) void se_bwd_dh_kernel(SeBwdArgs a) {
+  extern __shared__ float sm[];                 // dpre2[C] | partials [16][64]
+  const int g = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int C = a.C, Cm = a.Cm;
-  const int LD = C > 64 ? C : 64;
-  for (int c = lane; c < C; c += 64) {
-    float s0 = 0.f, s1 = 0.f;
-    int sl = wave;
-    for (; sl + SEF_W < a.slots; sl += 2 * SEF_W) {
-      s0 += a.dpart[((int64_t)sl * a.G + g) * C + c];
-      s1 += a.dpart[((int64_t)(sl + SEF_W) * a.G + g) * C + c];
-    }
-    if (sl < a.slots) s0 += a.dpart[((int64_t)sl * a.G + g) * C + c];
-    sm[wave * LD + c] = s0 + s1;
-  }
+  float* dpre2 = sm;
+  float* red = sm + C;
+  slot_sum_to_lds(a.dpart, a.slots, a.G, g, C, dpre2, SEB_T);
   __syncthreads();
-  float* dpre2 = sm + SEF_W * LD;
-  float* dh = dpre2 + C;
-  for (int c = tid; c < C; c += SEF_T) {
-    float s = 0.f;
-#pragma unroll
-    for (int w = 0; w < SEF_W; ++w) s += sm[w * LD + c];
+  for (int c = tid; c < C; c += SEB_T) {
     const float sc = a.scale[(int64_t)g * C + c];
-    const float d = (sc > 0.f && sc < 1.f) ? s * (1.f / 6.f) : 0.f;       // hardsigmoid'
+    const float d = (sc > 0.f && sc < 1.f) ? dpre2[c] * (1.f / 6.f) : 0.f;
     dpre2[c] = d;
-    a.work[(int64_t)g * (C + Cm) + c] = d;
+    if (blockIdx.x == 0) a.work[(int64_t)g * (C + Cm) + c] = d;
   }
   __syncthreads();
-  // dh[j] = [hidden[j] > 0] * sum_c W2[c][j] * dpre2[c]: lanes over j (W2 rows are contiguous in j), the 16 waves split c
-  for (int j0 = 0; j0 < Cm; j0 += 64) {
-    const int j = j0 + lane;
-    const int cq = (C + SEF_W - 1) / SEF_W, c0 = wave * cq, c1 = min(C, c0 + cq);
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    if (j < Cm) {
-      int c = c0;
-      for (; c + 4 <= c1; c += 4) {
-        s0 += a.w2[(int64_t)c * Cm + j] * dpre2[c];
-        s1 += a.w2[(int64_t)(c + 1) * Cm + j] * dpre2[c + 1];
-        s2 += a.w2[(int64_t)(c + 2) * Cm + j] * dpre2[c + 2];
-        s3 += a.w2[(int64_t)(c + 3) * Cm + j] * dpre2[c + 3];
-      }
-      for (; c < c1; ++c) s0 += a.w2[(int64_t)c * Cm + j] * dpre2[c];
+  const int j = blockIdx.x * 64 + lane;
+  const int cq = (C + SEB_W - 1) / SEB_W, c0 = wave * cq, c1 = min(C, c0 + cq);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (j < Cm) {
+    int c = c0;
+    for (; c + 4 <= c1; c += 4) {
+      s0 += a.w2[(int64_t)c * Cm + j] * dpre2[c];
+      s1 += a.w2[(int64_t)(c + 1) * Cm + j] * dpre2[c + 1];
+      s2 += a.w2[(int64_t)(c + 2) * Cm + j] * dpre2[c + 2];
+      s3 += a.w2[(int64_t)(c + 3) * Cm + j] * dpre2[c + 3];
     }
-    __syncthreads();                              // (sm is free: the dscale partials were consumed above)
-    sm[wave * 64 + lane] = (s0 + s1) + (s2 + s3);
-    __syncthreads();
-    if (wave == 0 && j < Cm) {
-      float s = 0.f;
-#pragma unroll
-      for (int w = 0; w < SEF_W; ++w) s += sm[w * 64 + lane];
-      if (!(a.hidden[(int64_t)g * Cm + j] > 0.f)) s = 0.f;
-      dh[j] = s;
-      a.work[(int64_t)g * (C + Cm) + C + j] = s;
-    }
+    for (; c < c1; ++c) s0 += a.w2[(int64_t)c * Cm + j] * dpre2[c];
   }
+  red[wave * 64 + lane] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  // g_shift[c] = inv_count * sum_j W1[j][c] * dh[j]: lanes over c, the 16 waves split j
-  for (int cb = 0; cb < C; cb += 64) {
-    const int c = cb + lane;
-    const int jq = (Cm + SEF_W - 1) / SEF_W, j0 = wave * jq, j1 = min(Cm, j0 + jq);
+  if (wave == 0 && j < Cm) {
     float s = 0.f;
-    if (c < C)
-      for (int j = j0; j < j1; ++j) s += a.w1[(int64_t)j * C + c] * dh[j];
-    __syncthreads();
-    sm[wave * 64 + lane] = s;
-    __syncthreads();
-    if (wave == 0 && c < C) {
-      float t = 0.f;
 #pragma unroll
-      for (int w = 0; w < SEF_W; ++w) t += sm[w * 64 + lane];
-      a.g_shift[(int64_t)g * C + c] = t * a.inv_count;
+    for (int w = 0; w < SEB_W; ++w) s += red[w * 64 + lane];
+    if (!(a.hidden[(int64_t)g * Cm + j] > 0.f)) s = 0.f;
+    a.work[(int64_t)g * (C + Cm) + C + j] = s;
+  }
+}
+
+// g_shift[g][c] = inv_count * sum_j W1[j][c] * dh[g][j] for a block of 64 channels: lanes over c, the 16 waves split j.
+__global__ __launch_bounds__(SEB_T) void se_bwd_gshift_kernel(SeBwdArgs a) {
+  extern __shared__ float sm[];                 // dh[Cm] | partials [16][64]
+  const int g = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int C = a.C, Cm = a.Cm;
+  float* dh = sm;
+  float* red = sm + Cm;
+  for (int j = tid; j < Cm; j += SEB_T) dh[j] = a.work[(int64_t)g * (C + Cm) + C + j];
+  __syncthreads();
+  const int c = blockIdx.x * 64 + lane;
+  const int jq = (Cm + SEB_W - 1) / SEB_W, j0 = wave * jq, j1 = min(Cm, j0 + jq);
+  float s0 = 0.f, s1 = 0.f;
+  if (c < C) {
+    int j = j0;
+    for (; j + 2 <= j1; j += 2) {
+      s0 += a.w1[(int64_t)j * C + c] * dh[j];
+      s1 += a.w1[(int64_t)(j + 1) * C + c] * dh[j + 1];
     }
+    if (j < j1) s0 += a.w1[(int64_t)j * C + c] * dh[j];
+  }
+  red[wave * 64 + lane] = s0 + s1;
+  __syncthreads();
+  if (wave == 0 && c < C) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < SEB_W; ++w) t += red[w * 64 + lane];
+    a.g_shift[(int64_t)g * C + c] = t * a.inv_count;
   }
 }
 
@@ -329,47 +351,38 @@ extern "C" int pb_se_fc_bwd(const float* dscale, const float* pool, float inv_co
 
 // Fused squeeze-excite gate: pool partial sums -> pool, hidden, scale (and, optionally, the per-clip scaled bf16
 // projection weights the LDS-DMA GEMM reads) in ONE launch.  pool_part: fp32 [slots][G][C].
+// Fused squeeze-excite gate: pool partial sums -> pool, hidden, scale (and, optionally, the per-clip scaled bf16
+// projection weights the LDS-DMA GEMM reads) in two launches.  pool_part: fp32 [slots][G][C].
 extern "C" int pb_se_fused_fwd(const float* pool_part, int slots, float inv_count, const float* w1, const float* b1,
                                const float* w2, const float* b2, float* pool, float* scale, float* hidden,
                                const float* wproj, void* wbs_bf16, int N, int G, int C, int Cm, int device, void* stream) {
   PB_CHECK_ARG(pool_part && w1 && w2 && pool && scale && hidden && slots >= 1, "pb_se_fused_fwd: null pointer / bad slots");
-  PB_CHECK_ARG(G > 0 && C > 0 && Cm > 0 && C <= 4096 && Cm <= 2048, "pb_se_fused_fwd: bad sizes C=%d Cm=%d", C, Cm);
+  PB_CHECK_ARG(G > 0 && G <= 65535 && C > 0 && Cm > 0 && C <= 8192 && Cm <= 8192, "pb_se_fused_fwd: bad sizes G=%d C=%d Cm=%d", G, C, Cm);
   PB_CHECK_ARG((wproj == nullptr) == (wbs_bf16 == nullptr), "pb_se_fused_fwd: wproj and wbs go together");
   PB_CHECK_ARG(!wproj || (N > 0 && C % 8 == 0 && ((uintptr_t)wproj % 16) == 0 && ((uintptr_t)wbs_bf16 % 16) == 0),
                "pb_se_fused_fwd: scaled weights need C %% 8 == 0 and 16-byte aligned pointers");
   PB_ENTER(device);
+  hipStream_t st = (hipStream_t)stream;
   SeFwdArgs a = {pool_part, slots, inv_count, w1, b1, w2, b2, pool, scale, hidden, wproj, (bf16_t*)wbs_bf16, G, C, Cm, N};
-  const size_t lds = ((size_t)SEF_W * C + 2 * (size_t)C + Cm) * sizeof(float);
-  static bool attr_done[16] = {false};
-  if (lds > 64 * 1024 && !attr_done[device & 15]) {
-    PB_HIP(hipFuncSetAttribute((const void*)se_fused_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done[device & 15] = true;
-  }
-  PB_CHECK_ARG(lds <= 160 * 1024, "pb_se_fused_fwd: C=%d needs %zu bytes of LDS", C, lds);
-  hipLaunchKernelGGL(se_fused_fwd_kernel, dim3((unsigned)G), dim3(SEF_T), lds, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(se_hidden_kernel, dim3((unsigned)pb_cdiv(Cm, SE_JB), (unsigned)G), dim3(SE_HT), (size_t)C * 4, st, a);
+  hipLaunchKernelGGL(se_scale_kernel, dim3((unsigned)pb_cdiv(C, 64), (unsigned)G), dim3(256), ((size_t)Cm + 64) * 4, st, a);
   PB_LAUNCH_CHECK();
   return 0;
 }
 
-// Fused backward: dscale partial sums [slots][G][C] -> g_shift, then the weight gradients (2 launches).
+// Fused backward: dscale partial sums [slots][G][C] -> dh, g_shift, then the weight gradients (3 launches).
 extern "C" int pb_se_fused_bwd(const float* dscale_part, int slots, const float* pool, float inv_count, const float* scale,
                                const float* hidden, const float* w1, const float* w2, float* g_shift, float* dw1,
                                float* db1, float* dw2, float* db2, float* work, int G, int C, int Cm, int device,
                                void* stream) {
   PB_CHECK_ARG(dscale_part && pool && scale && hidden && w1 && w2 && g_shift && dw1 && dw2 && work && slots >= 1,
                "pb_se_fused_bwd: null pointer / bad slots");
-  PB_CHECK_ARG(G > 0 && C > 0 && Cm > 0 && C <= 4096 && Cm <= 2048, "pb_se_fused_bwd: bad sizes C=%d Cm=%d", C, Cm);
+  PB_CHECK_ARG(G > 0 && G <= 65535 && C > 0 && Cm > 0 && C <= 8192 && Cm <= 8192, "pb_se_fused_bwd: bad sizes G=%d C=%d Cm=%d", G, C, Cm);
   PB_ENTER(device);
   hipStream_t st = (hipStream_t)stream;
   SeBwdArgs a = {dscale_part, slots, inv_count, scale, hidden, w1, w2, g_shift, work, G, C, Cm};
-  const size_t lds = ((size_t)SEF_W * (C > 64 ? C : 64) + C + Cm) * sizeof(float);
-  static bool attr_done[16] = {false};
-  if (lds > 64 * 1024 && !attr_done[device & 15]) {
-    PB_HIP(hipFuncSetAttribute((const void*)se_fused_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done[device & 15] = true;
-  }
-  PB_CHECK_ARG(lds <= 160 * 1024, "pb_se_fused_bwd: C=%d needs %zu bytes of LDS", C, lds);
-  hipLaunchKernelGGL(se_fused_bwd_kernel, dim3((unsigned)G), dim3(SEF_T), lds, st, a);
+  hipLaunchKernelGGL(se_bwd_dh_kernel, dim3((unsigned)pb_cdiv(Cm, 64), (unsigned)G), dim3(SEB_T), ((size_t)C + SEB_T) * 4, st, a);
+  hipLaunchKernelGGL(se_bwd_gshift_kernel, dim3((unsigned)pb_cdiv(C, 64), (unsigned)G), dim3(SEB_T), ((size_t)Cm + SEB_T) * 4, st, a);
   const int64_t total = 2LL * C * Cm + C + Cm;
   hipLaunchKernelGGL(se_fc_bwd_w_kernel, dim3((unsigned)pb_cdiv(total, 256)), dim3(256), 0, st, (const float*)work, pool,
                      inv_count, hidden, dw1, db1, dw2, db2, G, C, Cm);

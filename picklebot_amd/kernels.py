@@ -782,11 +782,23 @@ def se_fc_bwd(dscale, pool, inv_count, scale, hidden, w1, w2, want_bias=True):
     return g_shift, dw1, (db1 if want_bias else None), dw2, (db2 if want_bias else None)
 
 
+def _few_slots(part, limit=64):
+    """The fused squeeze-excite kernels re-add the slots in several workgroups per clip: beyond `limit` slots (MoViNet's
+    large frames) one fixed-order reduction launch folds them first."""
+    if part.shape[0] <= limit:
+        return part
+    out = torch.empty((1,) + tuple(part.shape[1:]), dtype=torch.float32, device=part.device)
+    n = out.numel()
+    partials_reduce([(part, out, n, n, part.shape[0], 0)], part.device)
+    return out
+
+
 def se_fused_fwd(pool_part, inv_count, w1, b1, w2, b2, wproj=None, want_scaled=False):
     """pool_part fp32 [slots,G,C] -> (pool [G,C], scale [G,C], hidden [G,Cm], wbs): ONE launch.  wbs (want_scaled and
     wproj fp32 [N,C] given, C and N multiples of 8): bf16 [G,N,C] = wproj * scale per clip for pw_fwd(scaled_weights=)."""
     if pool_part.dim() != 3:
         raise ValueError("se_fused_fwd: pool_part must be [slots, G, C]")
+    pool_part = _few_slots(pool_part)
     slots, G, C = pool_part.shape
     Cm = w1.shape[0]
     _f32(pool_part, name="pool_part"); _f32(w1, (Cm, C), "w1"); _f32(w2, (C, Cm), "w2"); _f32(b1, (Cm,), "b1"); _f32(b2, (C,), "b2")
@@ -825,6 +837,7 @@ def rowgroup_partials(a, b, G):
 
 def se_fused_bwd(dscale_part, pool, inv_count, scale, hidden, w1, w2, want_bias=True):
     """dscale_part fp32 [slots,G,C] -> (g_shift [G,C], dw1, db1, dw2, db2): two launches (per-clip vectors; weight grads)."""
+    dscale_part = _few_slots(dscale_part)
     slots, G, C = dscale_part.shape
     Cm = w1.shape[0]
     for t, shp, n in ((pool, (G, C), "pool"), (scale, (G, C), "scale"), (hidden, (G, Cm), "hidden"), (w1, (Cm, C), "w1"),
