@@ -340,6 +340,11 @@ int pb_copy_cols(const void* src, int64_t src_ld, int src_off, void* dst, int64_
  * delta [R][8] fp32 is scratch (rowsum(dO*O)), dqkv [R][384] is fully written. */
 int pb_attention_fwd(const void* qkv, void* out, float* lse, int64_t G, int n, float scale, pb_dtype dtype, int device,
                      void* stream);
+/* The same forward with fp8 (OCP e4m3) MFMA operands - K and V quantised per (group, head) with one scale each, Q per
+ * 16-query tile, the probabilities as p*256 - and fp32 softmax statistics; qkv / out bf16.  BASELINE config 5; the
+ * reference has no fp8 path, so beyond the bf16 goldens its parity is unpinned (tests state the measured tolerance).
+ * n <= 1024.  Inference only. */
+int pb_attention_fwd_fp8(const void* qkv, void* out, float* lse, int64_t G, int n, float scale, int device, void* stream);
 int pb_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
                      int64_t G, int n, float scale, pb_dtype dtype, int device, void* stream);
 

@@ -433,7 +433,7 @@ def _split_heads(qkv, G, n):
     return q, k, v
 
 
-def attention_fwd(qkv, G, n, scale):
+def attention_fwd(qkv, G, n, scale, fp8=False):
     q, k, v = _split_heads(qkv, G, n)
     s = torch.matmul(q, k.transpose(-1, -2)) * scale
     lse = torch.logsumexp(s, -1)

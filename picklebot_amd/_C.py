@@ -70,6 +70,7 @@ SIGNATURES = {
     "pb_layernorm": [P, P, P, P, L, I, F, I, I, I, P],
     "pb_copy_cols": [P, L, I, P, L, I, L, I, I, I, I, P],
     "pb_attention_fwd": [P, P, P, L, I, F, I, I, P],
+    "pb_attention_fwd_fp8": [P, P, P, L, I, F, I, P],
     "pb_attention_bwd": [P, P, P, P, P, P, L, I, F, I, I, P],
     "pb_conv_weight_prep": [P, P, I, I, I, I, I, P],
     "pb_conv3d_fwd": [P, P, P, POINTER(ConvShape), I, P, P, I, F, P, I, P],

@@ -16,6 +16,7 @@
 // contractions use all 32: slot (g,j) <-> index 4g+j (j<4) / 16+4g+(j-4) of a 32-wide pair of tiles).
 // fp32 (parity path): exact-f32 v_mfma_f32_16x16x4_f32, slot g of step r <-> index 4g+r of a tile.
 #include "pb_common.h"
+#include <stdlib.h>
 #include <type_traits>
 
 namespace {
@@ -185,6 +186,191 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) op[r] = from_f32<T>(o[r]);
       if (g == 0) a.lse[((int64_t)grp * n + q) * NH + h] = m * 0.69314718055994530942f + __logf(l);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ forward, one pass
+// bf16 activations, ONE pass over the keys with an online softmax (the two-pass kernel above computed every score and
+// every exp twice: 153 us at n = 768, batch 8 - 3-5 % of the dense MFMA peak).  Per wave: a tile of 16 queries; per
+// step a PAIR of 16-key tiles: two S^T = K Q^T MFMAs, the running max is raised (two shuffles across the four lane
+// groups that share a query column), the accumulators are rescaled, and the eight probabilities a lane holds ARE its
+// slots of the B operand of O^T += V^T P^T (slot (g, r) <-> key 4g + r of the first tile, (g, 4 + r) <-> the second).
+// P never leaves registers.  FP8 (BASELINE config 5, "CDNA4 fp8 MFMA attn"): the operands of both products are OCP
+// e4m3 - K and V quantised per (group, head) with one scale each (amax over the head slice, found while staging), Q
+// per query tile, P as p * 256 - fed to v_mfma_f32_16x16x32_fp8_fp8; softmax statistics stay fp32.
+typedef long fp8x8_t;
+
+__device__ __forceinline__ fp8x8_t pack_fp8x8(const float (&v)[8]) {
+  int lo = 0, hi = 0;
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], lo, false);
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], lo, true);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], hi, false);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6], v[7], hi, true);
+  return (fp8x8_t)(((unsigned long)(unsigned)hi << 32) | (unsigned)lo);
+}
+
+__device__ __forceinline__ float block_max(float v, float* red) {       // max over the workgroup (order-independent)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  if ((threadIdx.x & 63) == 0) red[wave] = v;
+  __syncthreads();
+  float m = red[0];
+  for (int w = 1; w < nw; ++w) m = fmaxf(m, red[w]);
+  __syncthreads();
+  return m;
+}
+
+template <bool FP8>
+__global__ __launch_bounds__(512) void attn_fwd_onepass_kernel(AttnArgs a) {
+  typedef bf16_t T;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int n = a.n, npad = a.npad;
+  const int gh = blockIdx.x / a.split, sp = blockIdx.x - gh * a.split, nwv = blockDim.x >> 6;
+  const int grp = gh / NH, h = gh - grp * NH;
+  const T* base = (const T*)a.qkv + (int64_t)grp * n * QKV_LD + h * HD;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  // LDS: bf16: K [npad][16] (32 B rows) | V^T [16][npad + 8];  fp8: K [npad][16] (16 B rows) | V^T [16][npad + 16] | 8 floats
+  const int ldt = FP8 ? npad + 16 : npad + 8;
+  T* Ks = (T*)smem;
+  T* Vs = Ks + npad * HD;
+  unsigned char* K8 = smem;
+  unsigned char* V8 = smem + (size_t)npad * HD;
+  float inv_sk = 1.f, inv_sv = 1.f;
+  if constexpr (!FP8) {
+    stage_head<T>(base + NH * HD, QKV_LD, n, npad, Ks, nullptr, 0);
+    stage_head<T>(base + 2 * NH * HD, QKV_LD, n, npad, nullptr, Vs, ldt);
+    __syncthreads();
+  } else {
+    // K and V head slices: registers -> amax -> one scale each -> e4m3 in LDS (rows >= n are zeros)
+    constexpr int MAXC = 4;                                    // 16-byte chunks per thread and tensor: npad * 2 <= 2048
+    float* red = (float*)(smem + (size_t)npad * HD + (size_t)HD * ldt);
+    bf16x8 kc[MAXC], vc[MAXC];
+    float ak = 0.f, av = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      const int i = threadIdx.x + c * 512;
+      const int r = i >> 1, hf = i & 1;
+      const bool ok = i < npad * 2 && r < n;
+      bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+      kc[c] = ok ? *reinterpret_cast<const bf16x8*>(base + NH * HD + (int64_t)r * QKV_LD + hf * 8) : z;
+      vc[c] = ok ? *reinterpret_cast<const bf16x8*>(base + 2 * NH * HD + (int64_t)r * QKV_LD + hf * 8) : z;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        ak = fmaxf(ak, fabsf((float)kc[c][e]));
+        av = fmaxf(av, fabsf((float)vc[c][e]));
+      }
+    }
+    ak = block_max(ak, red);
+    av = block_max(av, red);
+    const float sk = ak > 0.f ? 448.f / ak : 1.f, sv = av > 0.f ? 448.f / av : 1.f;
+    inv_sk = 1.f / sk; inv_sv = 1.f / sv;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      const int i = threadIdx.x + c * 512;
+      if (i < npad * 2) {
+        const int r = i >> 1, hf = i & 1;
+        float kf[8], vf[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { kf[e] = (float)kc[c][e] * sk; vf[e] = (float)vc[c][e] * sv; }
+        *reinterpret_cast<fp8x8_t*>(K8 + (size_t)r * HD + hf * 8) = pack_fp8x8(kf);
+        const fp8x8_t vq = pack_fp8x8(vf);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) V8[(size_t)(hf * 8 + e) * ldt + r] = (unsigned char)((unsigned long)vq >> (8 * e));
+      }
+    }
+    __syncthreads();
+  }
+  const float NEG = -3.0e38f;
+  const int npairs = npad >> 5, pfull = n >> 5;               // key-tile pairs; pairs without padding keys
+  for (int qt = sp * nwv + wave; qt * 16 < n; qt += nwv * a.split) {
+    const int q = qt * 16 + li;
+    const bool qok = q < n;
+    // B operand of the score products: lane (query = li, g) holds Q[q][8g .. 8g+7] for g < 2, zeros above (d = 16)
+    bf16x8 qv = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (qok && g < 2) qv = *reinterpret_cast<const bf16x8*>(base + (int64_t)q * QKV_LD + 8 * g);
+    fp8x8_t q8 = 0;
+    float sl = a.scale * 1.44269504088896340736f;             // scores in the log2 domain
+    if constexpr (FP8) {
+      float aq = 0.f, qf[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) aq = fmaxf(aq, fabsf((float)qv[e]));
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) aq = fmaxf(aq, __shfl_xor(aq, o, 64));
+      const float sq = aq > 0.f ? 448.f / aq : 1.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qf[e] = (float)qv[e] * sq;
+      q8 = pack_fp8x8(qf);
+      sl *= inv_sk / sq;
+    }
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    float m = NEG, l = 0.f;                                    // l: this lane's share (its 8 keys per pair) of the row sum
+    auto step = [&](int kp, auto masked) {
+      f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = sa;
+      if constexpr (FP8) {
+        const fp8x8_t ka = g < 2 ? *reinterpret_cast<const fp8x8_t*>(K8 + (size_t)(kp * 32 + li) * HD + 8 * g) : 0;
+        const fp8x8_t kb = g < 2 ? *reinterpret_cast<const fp8x8_t*>(K8 + (size_t)(kp * 32 + 16 + li) * HD + 8 * g) : 0;
+        sa = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(ka, q8, sa, 0, 0, 0);
+        sb = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(kb, q8, sb, 0, 0, 0);
+      } else {
+        bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        const bf16x8 ka = g < 2 ? *reinterpret_cast<const bf16x8*>(Ks + (kp * 32 + li) * HD + 8 * g) : z;
+        const bf16x8 kb = g < 2 ? *reinterpret_cast<const bf16x8*>(Ks + (kp * 32 + 16 + li) * HD + 8 * g) : z;
+        sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qv, sa, 0, 0, 0);
+        sb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kb, qv, sb, 0, 0, 0);
+      }
+      float sv8[8], mx = NEG;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        sv8[r] = (!decltype(masked)::value || kp * 32 + 4 * g + r < n) ? sa[r] * sl : NEG;
+        sv8[4 + r] = (!decltype(masked)::value || kp * 32 + 16 + 4 * g + r < n) ? sb[r] * sl : NEG;
+      }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) mx = fmaxf(mx, sv8[r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));                  // the four lane groups of a query column
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mn = fmaxf(m, mx);
+      const float alpha = __builtin_amdgcn_exp2f(m - mn);
+      m = mn;
+      float p[8], ps = 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        p[r] = __builtin_amdgcn_exp2f(sv8[r] - mn);
+        ps += p[r];
+      }
+      l = l * alpha + ps;
+      o *= alpha;
+      if constexpr (FP8) {
+        float p8[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) p8[r] = p[r] * 256.f;
+        const fp8x8_t pb = pack_fp8x8(p8);
+        const unsigned v0 = *reinterpret_cast<const unsigned*>(V8 + (size_t)li * ldt + kp * 32 + 4 * g);
+        const unsigned v1 = *reinterpret_cast<const unsigned*>(V8 + (size_t)li * ldt + kp * 32 + 16 + 4 * g);
+        const fp8x8_t va = (fp8x8_t)(((unsigned long)v1 << 32) | v0);
+        o = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(va, pb, o, 0, 0, 0);
+      } else {
+        bf16x8 pb;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) pb[r] = (bf16_t)p[r];
+        const bf16x4 v0 = *reinterpret_cast<const bf16x4*>(Vs + li * ldt + kp * 32 + 4 * g);
+        const bf16x4 v1 = *reinterpret_cast<const bf16x4*>(Vs + li * ldt + kp * 32 + 16 + 4 * g);
+        const bf16x8 va = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, pb, o, 0, 0, 0);
+      }
+    };
+    for (int kp = 0; kp < pfull; ++kp) step(kp, std::false_type{});
+    for (int kp = pfull; kp < npairs; ++kp) step(kp, std::true_type{});
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = (FP8 ? inv_sv * (1.f / 256.f) : 1.f) / l;
+    if (qok) {
+      // O^T tile: column = q (this lane), rows d = 4g + r: 8 bytes per lane
+      const bf16x4 ov = {(bf16_t)(o[0] * inv), (bf16_t)(o[1] * inv), (bf16_t)(o[2] * inv), (bf16_t)(o[3] * inv)};
+      *reinterpret_cast<bf16x4*>((T*)a.out + ((int64_t)grp * n + q) * OUT_LD + h * HD + 4 * g) = ov;
+      if (g == 0) a.lse[((int64_t)grp * n + q) * NH + h] = (m + __log2f(l)) * 0.69314718055994530942f;
     }
   }
 }
@@ -408,13 +594,35 @@ extern "C" int pb_attention_fwd(const void* qkv, void* out, float* lse, int64_t 
   const size_t es = dtype == PB_BF16 ? 2 : 4;
   const size_t lds = (size_t)a.npad * HD * es + (dtype == PB_BF16 ? (size_t)HD * (a.npad + 8) * es : (size_t)a.npad * HD * es);
   dim3 grid((unsigned)(G * NH * a.split));
-  if (dtype == PB_BF16) {
+  static const bool onepass = !(getenv("PB_ATTN_ONEPASS") && atoi(getenv("PB_ATTN_ONEPASS")) == 0);
+  if (dtype == PB_BF16 && onepass) {
+    if (int rc = set_lds(attn_fwd_onepass_kernel<false>, lds)) return rc;
+    hipLaunchKernelGGL(attn_fwd_onepass_kernel<false>, grid, dim3(ATT_THREADS), lds, (hipStream_t)stream, a);
+  } else if (dtype == PB_BF16) {
     if (int rc = set_lds(attn_fwd_kernel<bf16_t>, lds)) return rc;
     hipLaunchKernelGGL(attn_fwd_kernel<bf16_t>, grid, dim3(ATT_THREADS), lds, (hipStream_t)stream, a);
   } else {
     if (int rc = set_lds(attn_fwd_kernel<float>, lds)) return rc;
     hipLaunchKernelGGL(attn_fwd_kernel<float>, grid, dim3(ATT_THREADS), lds, (hipStream_t)stream, a);
   }
+  PB_LAUNCH_CHECK();
+  return 0;
+}
+
+// bf16 in / out, fp8 (OCP e4m3) operands in both MFMA products, fp32 softmax statistics: the forward of BASELINE's
+// config 5 ("MobileViT-XXS fp8 forward ... CDNA4 fp8 MFMA attn").  Inference only (no backward form).
+extern "C" int pb_attention_fwd_fp8(const void* qkv, void* out, float* lse, int64_t G, int n, float scale, int device,
+                                    void* stream) {
+  PB_CHECK_ARG(qkv && out && lse, "pb_attention_fwd_fp8: null pointer");
+  if (int rc = check_attn(G, n, PB_BF16, "pb_attention_fwd_fp8")) return rc;
+  PB_CHECK_ARG(n <= 1024, "pb_attention_fwd_fp8: n=%d exceeds the staged maximum of 1024 tokens", n);
+  PB_ENTER(device);
+  AttnArgs a = {};
+  a.qkv = qkv; a.out = out; a.lse = lse; a.n = n; a.npad = (n + 31) / 32 * 32; a.scale = scale;
+  a.split = attn_split(G, n);
+  const size_t lds = (size_t)a.npad * HD + (size_t)HD * (a.npad + 16) + 64;
+  if (int rc = set_lds(attn_fwd_onepass_kernel<true>, lds)) return rc;
+  hipLaunchKernelGGL(attn_fwd_onepass_kernel<true>, dim3((unsigned)(G * NH * a.split)), dim3(ATT_THREADS), lds, (hipStream_t)stream, a);
   PB_LAUNCH_CHECK();
   return 0;
 }

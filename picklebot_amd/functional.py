@@ -684,8 +684,31 @@ class _FFBlock(torch.autograd.Function):
         return dx, dw1, dw2
 
 
+_fp8_attention = False
+
+
+class fp8_attention:
+    """Context manager: inside it, INFERENCE forwards (torch.no_grad, bf16 activations) run the patch attention with fp8
+    (e4m3) MFMA operands - BASELINE config 5.  Training forwards are unaffected (there is no fp8 backward)."""
+
+    def __enter__(self):
+        global _fp8_attention
+        self.prev, _fp8_attention = _fp8_attention, True
+        return self
+
+    def __exit__(self, *exc):
+        global _fp8_attention
+        _fp8_attention = self.prev
+        return False
+
+
 def attn_block(rows, w_qkv, w_out, G, n, scale, eps):
-    return _AttnBlock.apply(rows if rows.is_contiguous() else rows.contiguous(), w_qkv, w_out, G, n, scale, eps)
+    rows = rows if rows.is_contiguous() else rows.contiguous()
+    if _fp8_attention and not torch.is_grad_enabled() and rows.dtype == torch.bfloat16 and n <= 1024:
+        xn, _ = K.layernorm_fwd(rows, eps)
+        o, _ = K.attention_fwd(K.pw_fwd(xn, w_qkv), G, n, scale, fp8=True)
+        return K.pw_fwd(o, w_out, residual=rows)
+    return _AttnBlock.apply(rows, w_qkv, w_out, G, n, scale, eps)
 
 
 def ff_block(rows, w1, w2):

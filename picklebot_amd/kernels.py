@@ -993,14 +993,21 @@ def copy_cols(src, src_off, dst, dst_off, C, accumulate=False):
     return dst
 
 
-def attention_fwd(qkv, G, n, scale):
-    """qkv [G*n, 384] -> (out [G*n, 128], lse fp32 [G*n, 8]); 8 heads of 16 (mobilevit.py:116)."""
+def attention_fwd(qkv, G, n, scale, fp8=False):
+    """qkv [G*n, 384] -> (out [G*n, 128], lse fp32 [G*n, 8]); 8 heads of 16 (mobilevit.py:116).
+    fp8: bf16 tensors, fp8 (e4m3) MFMA operands in both products (inference; BASELINE config 5)."""
     _rows(qkv, "qkv")
     if qkv.shape != (G * n, 384):
         raise ValueError(f"attention_fwd: qkv shape {tuple(qkv.shape)} != ({G * n}, 384)")
     out = torch.empty((G * n, 128), dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty((G * n, 8), dtype=torch.float32, device=qkv.device)
     dev, st = _dev_stream(qkv)
+    if fp8:
+        if qkv.dtype != torch.bfloat16:
+            raise TypeError("attention_fwd(fp8=True): bfloat16 activations only")
+        _launch("attention_fwd_fp8", _nb(qkv, out), "pb_attention_fwd_fp8", _p(qkv), _p(out), _p(lse), G, n, float(scale), dev, st,
+                detail=f"G{G} n{n}")
+        return out, lse
     _launch("attention_fwd", _nb(qkv, out), "pb_attention_fwd", _p(qkv), _p(out), _p(lse), G, n, float(scale), _dt(qkv), dev, st,
             detail=f"G{G} n{n}")
     return out, lse

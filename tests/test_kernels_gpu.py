@@ -550,3 +550,18 @@ def test_pool_and_rowgroup_partials_sum_to_the_totals(K, dtype):
     check("dw_fwd_pool_y", y, y_ref, dtype); check("dw_fwd_pool_sum", part.sum(0), part_ref.sum(0), dtype)
     a, b = rnd((6 * 70, 40), dtype, 52), rnd((6 * 70, 40), dtype, 53)
     check("rowgroup_partials", K.rowgroup_partials(dev(a), dev(b), 6).sum(0), R.rowgroup_reduce(a, b, 6), dtype)
+
+
+@pytest.mark.parametrize("G,n", [(2, 32), (3, 147), (2, 768), (1, 784), (5, 16), (1, 1000)])
+def test_attention_fp8_forward(K, G, n):
+    """fp8 (e4m3) MFMA operands, fp32 softmax statistics (BASELINE config 5).  The reference has no fp8 path: parity
+    unpinned beyond the bf16 mirror.  Measured on MI355X against the fp32-arithmetic mirror on the same bf16 inputs:
+    <= 6e-2 relative per output tensor (e4m3 carries 3 mantissa bits: 6 % per element, averaged over the keys)."""
+    qkv = rnd((G * n, 384), torch.bfloat16, 60)
+    want, lse_ref = R.attention_fwd(qkv, G, n, 0.25)
+    got, lse = K.attention_fwd(dev(qkv), G, n, 0.25, fp8=True)
+    e = rel_err(got.float().cpu().numpy(), want.float().numpy())
+    assert e <= 6e-2, e
+    assert rel_err(lse.cpu().numpy(), lse_ref.numpy()) <= 2e-2
+    bf, _ = K.attention_fwd(dev(qkv), G, n, 0.25)
+    assert rel_err(bf.float().cpu().numpy(), want.float().numpy()) <= 1.2e-2

@@ -429,3 +429,24 @@ def test_mobilevit_s_full_size_training_properties():
         full = m(x).float().cpu()
         part = torch.cat([m(x[i:i + 1]) for i in (0, 5)]).float().cpu()
     assert rel_err(part.numpy(), full[[0, 5]].numpy()) <= 2e-2
+
+
+def test_mobilevit_xxs_fp8_attention_forward(golden):
+    """BASELINE config 5: MobileViT-XXS inference with fp8 MFMA attention (picklebot_amd.fp8_attention()).  Checked against
+    the reference's fp64 logits (model_mobilevit_xxs.npz): the fp8 forward must stay within 3 x the reference's own
+    bf16-autocast deviation or 5e-2, and the bf16 forward of the same build is reported beside it."""
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = protocol.build_model(picklebot_amd, "mobilevit_xxs", DEV).eval()
+    shape = protocol.MODEL_CASES["mobilevit_xxs"][2]
+    x = formula.clip_features(*shape).to(DEV)
+    gold = golden("model_mobilevit_xxs")
+    want = np.asarray(gold["logits_eval"], np.float64)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16), contextlib.redirect_stdout(io.StringIO()):
+        bf = m(x).float().cpu().numpy()
+        with picklebot_amd.fp8_attention():
+            f8 = m(x).float().cpu().numpy()
+    e_bf, e_f8 = rel_err(bf, want), rel_err(f8, want)
+    ref_bf = float(gold["refbf16_err/logits_eval"][0]) if "refbf16_err/logits_eval" in gold else 0.0
+    print(f"mobilevit_xxs eval logits vs fp64 reference: bf16 {e_bf:.2e}, fp8-attention {e_f8:.2e} (reference's own bf16 {ref_bf:.2e})")
+    assert e_f8 <= max(5e-2, 3 * ref_bf), (e_f8, ref_bf)
+    assert not np.array_equal(bf, f8)            # the fp8 kernel really ran
