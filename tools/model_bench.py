@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--detail", default=None)
     ap.add_argument("--fp32", action="store_true")
     ap.add_argument("--graph", action="store_true", help="also time the step replayed from one HIP graph (as bench.py does)")
+    ap.add_argument("--fp8", action="store_true", help="inference: patch attention with fp8 MFMA operands (BASELINE config 5)")
     args = ap.parse_args()
 
     import picklebot_amd as pb
@@ -73,6 +74,9 @@ def main():
             opt.step()
             return loss
         with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=not args.fp32):
+            if args.fp8:
+                with pb.fp8_attention():
+                    return model(x)
             return model(x)
 
     for _ in range(3):
@@ -121,6 +125,18 @@ def main():
     for name, d in sorted(prof.items(), key=lambda kv: -kv[1]["ms"]):
         print("  %-34s n=%4d  %8.3f ms/step  %7.1f GB/s  %5.1f%%" % (
             name, d["launches"] // args.steps, d["ms"] / args.steps, d["bytes"] / 1e6 / max(d["ms"], 1e-9), 100 * d["ms"] / tot))
+    # patch attention against the dense MFMA peak (MI355X_MICROARCH.md: 2.5 PFLOP/s bf16, 5 PFLOP/s fp8): algorithmic
+    # flops = 4 * n^2 * d per (group, head) forward (QK^T and PV), 2.5x that backward
+    import re
+    for k, d in sorted(detail.items(), key=lambda kv: -kv[1]["ms"]):
+        mm = re.match(r"(attention_fwd_fp8|attention_fwd|attention_bwd) \| G(\d+) n(\d+)", k)
+        if mm:
+            kind, G, n = mm.group(1), int(mm.group(2)), int(mm.group(3))
+            flops = 4.0 * n * n * 16 * 8 * G * (2.5 if kind == "attention_bwd" else 1.0)
+            us = d["ms"] / d["launches"] * 1e3
+            peak = 5.0e15 if kind.endswith("fp8") else 2.5e15
+            print("  %-18s G%-5d n%-4d %8.1f us/launch  %7.1f TFLOP/s  = %.3f of the dense %s MFMA peak" % (
+                kind, G, n, us, flops / us / 1e6, flops / (us * 1e-6) / peak, "fp8" if kind.endswith("fp8") else "bf16"))
     if args.detail:
         with open(args.detail, "w") as f:
             for k, d in sorted(detail.items(), key=lambda kv: -kv[1]["ms"]):
