@@ -165,34 +165,63 @@ def main():
             K.reset_zero_arena()
             step = eager_step
     elif dp_path and not args.no_graph:
-        # data parallel: forward + backward (gradients accumulate into the reducer's flat buckets, exchange hooks off)
-        # replayed from a HIP graph; then the 3 bucket all-reduces over RCCL and the fused optimiser, eagerly.  The
-        # exchange no longer overlaps backward (16.8 MB: a few hundred microseconds over xGMI), in return the ranks
-        # are not bound by 8 ms of Python launch overhead each.
-        try:
-            def fwd_bwd():
-                reducer.detach_grads()                        # backward hands its gradient tensors over as they are ...
-                with reducer.no_sync():
-                    with torch.autocast("cuda", dtype=torch.bfloat16):
-                        loss = torch.nn.functional.cross_entropy(model(x).float(), y)
-                    loss.backward()
-                reducer.pack_grads()                          # ... and one concatenation per bucket gathers them
-                return loss
-            step()                                            # creates the RCCL communicator outside any capture
-            graph, graph_loss = capture(fwd_bwd)
-            reducer.attach_grads()                            # the optimiser reads the (reduced) buckets from now on
+        # data parallel.  First choice: the WHOLE step in one HIP graph, the exchange included - backward hands its gradients
+        # over as they are, the hook of a bucket's last gradient packs the bucket and issues its RCCL all-reduce on RCCL's
+        # stream (a fork inside the capture), so bucket k travels over xGMI while the rest of backward replays; the
+        # optimizer joins behind the last reduction.  Second choice (capture of the collective refused): forward +
+        # backward from a graph, then the bucket all-reduces and the optimizer eagerly (no overlap).  Third: eager.
+        def overlapped_step():
+            reducer.adopt_grads()
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                loss = torch.nn.functional.cross_entropy(model(x).float(), y)
+            loss.backward()
+            reducer.finish()
+            opt_step_reduced()
+            return loss
 
-            def step():  # noqa: F811
-                graph.replay()
-                reducer.reduce_now()
-                opt_step_reduced()
-                return graph_loss
-            launch_mode = "hipgraph(fwd+bwd) + eager all-reduce/optimizer"
-        except Exception as e:
-            print(f"[bench] HIP graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
-            torch.cuda.synchronize()
-            K.reset_zero_arena()
-            step = eager_step
+        def fwd_bwd():
+            reducer.detach_grads()                        # backward hands its gradient tensors over as they are ...
+            with reducer.no_sync():
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    loss = torch.nn.functional.cross_entropy(model(x).float(), y)
+                loss.backward()
+            reducer.pack_grads()                          # ... and one concatenation per bucket gathers them
+            return loss
+
+        step()                                            # creates the RCCL communicator outside any capture
+        sync()
+        captured = False
+        if flat_opt and not os.environ.get("PB_BENCH_NO_OVERLAP_GRAPH"):
+            try:
+                graph, graph_loss = capture(overlapped_step)
+
+                def step():  # noqa: F811
+                    graph.replay()
+                    return graph_loss
+                launch_mode = "hipgraph(whole step; RCCL all-reduce per bucket on a forked stream, overlapped with backward)"
+                captured = True
+                eager_step = overlapped_step
+            except Exception as e:
+                print(f"[bench] capture with in-graph all-reduce failed ({type(e).__name__}: {e}); trying fwd+bwd only", file=sys.stderr)
+                torch.cuda.synchronize()
+                K.reset_zero_arena()
+                reducer.adopt_grads(False)
+        if not captured:
+            try:
+                graph, graph_loss = capture(fwd_bwd)
+                reducer.attach_grads()                    # the optimiser reads the (reduced) buckets from now on
+
+                def step():  # noqa: F811
+                    graph.replay()
+                    reducer.reduce_now()
+                    opt_step_reduced()
+                    return graph_loss
+                launch_mode = "hipgraph(fwd+bwd) + eager all-reduce/optimizer"
+            except Exception as e:
+                print(f"[bench] HIP graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+                torch.cuda.synchronize()
+                K.reset_zero_arena()
+                step = eager_step
     for _ in range(args.warmup):
         step()
     sync()
@@ -214,6 +243,9 @@ def main():
     if rank == 0:
         prof_step = eager_step                                              # HIP events need eager launches
         if dp_path:
+            reducer.adopt_grads(False)
+            reducer.attach_grads()
+
             def prof_step():      # rank 0 profiles alone: no collective may be issued here (the other ranks are waiting)
                 reducer.zero_grad()
                 with reducer.no_sync():

@@ -223,7 +223,7 @@ __device__ __forceinline__ float block_max(float v, float* red) {       // max o
 }
 
 template <bool FP8>
-__global__ __launch_bounds__(512) void attn_fwd_onepass_kernel(AttnArgs a) {
+__global__ __launch_bounds__(1024) void attn_fwd_onepass_kernel(AttnArgs a) {
   typedef bf16_t T;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int n = a.n, npad = a.npad;
@@ -245,13 +245,13 @@ __global__ __launch_bounds__(512) void attn_fwd_onepass_kernel(AttnArgs a) {
     __syncthreads();
   } else {
     // K and V head slices: registers -> amax -> one scale each -> e4m3 in LDS (rows >= n are zeros)
-    constexpr int MAXC = 4;                                    // 16-byte chunks per thread and tensor: npad * 2 <= 2048
+    constexpr int MAXC = 4;                                    // 16-byte chunks per thread and tensor: npad * 2 <= 4 * 512
     float* red = (float*)(smem + (size_t)npad * HD + (size_t)HD * ldt);
     bf16x8 kc[MAXC], vc[MAXC];
     float ak = 0.f, av = 0.f;
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {
-      const int i = threadIdx.x + c * 512;
+      const int i = threadIdx.x + c * (int)blockDim.x;
       const int r = i >> 1, hf = i & 1;
       const bool ok = i < npad * 2 && r < n;
       bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(512) void attn_fwd_onepass_kernel(AttnArgs a) {
     inv_sk = 1.f / sk; inv_sv = 1.f / sv;
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {
-      const int i = threadIdx.x + c * 512;
+      const int i = threadIdx.x + c * (int)blockDim.x;
       if (i < npad * 2) {
         const int r = i >> 1, hf = i & 1;
         float kf[8], vf[8];
@@ -292,7 +292,14 @@ __global__ __launch_bounds__(512) void attn_fwd_onepass_kernel(AttnArgs a) {
     bf16x8 qv = {0, 0, 0, 0, 0, 0, 0, 0};
     if (qok && g < 2) qv = *reinterpret_cast<const bf16x8*>(base + (int64_t)q * QKV_LD + 8 * g);
     fp8x8_t q8 = 0;
-    float sl = a.scale * 1.44269504088896340736f;             // scores in the log2 domain
+    // scores in the log2 domain: the multiplier scale * log2(e) is folded into Q once per query tile (bf16: Q is
+    // re-rounded after the multiplication, the same 2^-9 relative error as the unscaled operand; fp8: into Q's scale)
+    const float sl0 = a.scale * 1.44269504088896340736f;
+    if constexpr (!FP8) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qv[e] = (bf16_t)((float)qv[e] * sl0);
+    }
+    float sl = 1.f;                                            // fp8: de-quantisation factor of the scores; bf16: already in Q
     if constexpr (FP8) {
       float aq = 0.f, qf[8];
 #pragma unroll
@@ -303,7 +310,7 @@ __global__ __launch_bounds__(512) void attn_fwd_onepass_kernel(AttnArgs a) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) qf[e] = (float)qv[e] * sq;
       q8 = pack_fp8x8(qf);
-      sl *= inv_sk / sq;
+      sl = sl0 * inv_sk / sq;
     }
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
     float m = NEG, l = 0.f;                                    // l: this lane's share (its 8 keys per pair) of the row sum
@@ -324,24 +331,30 @@ __global__ __launch_bounds__(512) void attn_fwd_onepass_kernel(AttnArgs a) {
       float sv8[8], mx = NEG;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        sv8[r] = (!decltype(masked)::value || kp * 32 + 4 * g + r < n) ? sa[r] * sl : NEG;
-        sv8[4 + r] = (!decltype(masked)::value || kp * 32 + 16 + 4 * g + r < n) ? sb[r] * sl : NEG;
+        const float xa = FP8 ? sa[r] * sl : sa[r], xb = FP8 ? sb[r] * sl : sb[r];
+        sv8[r] = (!decltype(masked)::value || kp * 32 + 4 * g + r < n) ? xa : NEG;
+        sv8[4 + r] = (!decltype(masked)::value || kp * 32 + 16 + 4 * g + r < n) ? xb : NEG;
       }
 #pragma unroll
       for (int r = 0; r < 8; ++r) mx = fmaxf(mx, sv8[r]);
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));                  // the four lane groups of a query column
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float mn = fmaxf(m, mx);
-      const float alpha = __builtin_amdgcn_exp2f(m - mn);
-      m = mn;
+      // after the first few key tiles the running maximum rarely moves: the rescale (one more exp and five multiplies
+      // per lane) runs only when some lane of the wave raised its maximum
+      if (__any(mx > m)) {
+        const float mn = fmaxf(m, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m - mn);
+        m = mn;
+        l *= alpha;
+        o *= alpha;
+      }
       float p[8], ps = 0.f;
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
-        p[r] = __builtin_amdgcn_exp2f(sv8[r] - mn);
+        p[r] = __builtin_amdgcn_exp2f(sv8[r] - m);
         ps += p[r];
       }
-      l = l * alpha + ps;
-      o *= alpha;
+      l += ps;
       if constexpr (FP8) {
         float p8[8];
 #pragma unroll
@@ -575,6 +588,12 @@ int attn_split(int64_t G, int n, int threads = ATT_THREADS) {
   return sp < 1 ? 1 : (int)sp;
 }
 
+int onepass_threads(int n) {
+  static const int forced = getenv("PB_ATTN_THREADS") ? atoi(getenv("PB_ATTN_THREADS")) : 0;
+  if (forced == 256 || forced == 512 || forced == 1024) return forced;
+  return n >= 512 ? 1024 : 512;
+}
+
 int check_attn(int64_t G, int n, pb_dtype dtype, const char* who) {
   PB_CHECK_ARG(G > 0 && n > 0 && G * NH * 64 < 0x7fffffffLL, "%s: bad sizes G=%lld n=%d", who, (long long)G, n);
   PB_CHECK_ARG(dtype == PB_F32 || dtype == PB_BF16, "%s: bad dtype", who);
@@ -596,8 +615,12 @@ extern "C" int pb_attention_fwd(const void* qkv, void* out, float* lse, int64_t 
   dim3 grid((unsigned)(G * NH * a.split));
   static const bool onepass = !(getenv("PB_ATTN_ONEPASS") && atoi(getenv("PB_ATTN_ONEPASS")) == 0);
   if (dtype == PB_BF16 && onepass) {
+    // long sequences: 16 waves per workgroup, one workgroup per (group, head) - the K/V slices are staged once and every
+    // round of workgroups fills the chip (512-thread workgroups at 3 per CU left a third of the second round empty)
+    const int threads = onepass_threads(n);
+    a.split = attn_split(G, n, threads);
     if (int rc = set_lds(attn_fwd_onepass_kernel<false>, lds)) return rc;
-    hipLaunchKernelGGL(attn_fwd_onepass_kernel<false>, grid, dim3(ATT_THREADS), lds, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(attn_fwd_onepass_kernel<false>, dim3((unsigned)(G * NH * a.split)), dim3(threads), lds, (hipStream_t)stream, a);
   } else if (dtype == PB_BF16) {
     if (int rc = set_lds(attn_fwd_kernel<bf16_t>, lds)) return rc;
     hipLaunchKernelGGL(attn_fwd_kernel<bf16_t>, grid, dim3(ATT_THREADS), lds, (hipStream_t)stream, a);
@@ -619,10 +642,11 @@ extern "C" int pb_attention_fwd_fp8(const void* qkv, void* out, float* lse, int6
   PB_ENTER(device);
   AttnArgs a = {};
   a.qkv = qkv; a.out = out; a.lse = lse; a.n = n; a.npad = (n + 31) / 32 * 32; a.scale = scale;
-  a.split = attn_split(G, n);
+  const int threads = onepass_threads(n);
+  a.split = attn_split(G, n, threads);
   const size_t lds = (size_t)a.npad * HD + (size_t)HD * (a.npad + 16) + 64;
   if (int rc = set_lds(attn_fwd_onepass_kernel<true>, lds)) return rc;
-  hipLaunchKernelGGL(attn_fwd_onepass_kernel<true>, dim3((unsigned)(G * NH * a.split)), dim3(ATT_THREADS), lds, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(attn_fwd_onepass_kernel<true>, dim3((unsigned)(G * NH * a.split)), dim3(threads), lds, (hipStream_t)stream, a);
   PB_LAUNCH_CHECK();
   return 0;
 }

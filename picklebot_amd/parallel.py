@@ -14,7 +14,12 @@ The reference's only parallelism is pure data parallel: every rank holds a full 
     event on the compute stream, so the exchange overlaps the rest of backward;
   * `finish()` makes the compute stream wait for the outstanding reductions (no host sync);
   * `no_sync()` skips the exchange on gradient-accumulation micro-steps (the reference reduces
-    on every micro-batch, train.py:269 vs :283; skipping them does not change the result).
+    on every micro-batch, train.py:269 vs :283; skipping them does not change the result);
+  * `adopt_grads()` mode: backward hands its gradient tensors over as they are (`.grad = None` beforehand: no
+    accumulate kernels); when the last gradient of a bucket has arrived that bucket is packed by ONE multi-tensor
+    copy and its all-reduce goes out at once - still during backward.  Everything is stream-ordered (no host
+    sync, no allocation by this class), so the WHOLE step - forward, backward with the overlapped exchange on
+    RCCL's stream (a fork/join inside the capture), optimizer - can be captured into one HIP graph.
 
 Works with any backend (`gloo` on CPU is what the unit tests use).
 """
@@ -44,6 +49,7 @@ class GradReducer:
         self.world = dist.get_world_size(process_group)
         self.average = average
         self._enabled = True
+        self._adopt = False
         self._pending = []
         params = [p for p in module.parameters() if p.requires_grad]
         if broadcast_from is not None:           # DDP ctor: replicas start identical
@@ -83,8 +89,14 @@ class GradReducer:
                 return
             self._ready[bi] += 1
             if self._ready[bi] == self._need[bi]:
+                if self._adopt:
+                    self._pack_bucket(bi)
                 self._launch(bi)
         return hook
+
+    def _pack_bucket(self, bi):
+        srcs = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.buckets[bi]]
+        torch._foreach_copy_(self.views[bi], srcs)
 
     def _launch(self, bi):
         op = dist.ReduceOp.SUM
@@ -106,6 +118,8 @@ class GradReducer:
         launched = {bi for bi, _ in self._pending}
         for bi in range(len(self.buckets)):
             if bi not in launched:
+                if self._adopt:
+                    self._pack_bucket(bi)
                 self._launch(bi)
         for bi, work in self._pending:
             work.wait()
@@ -113,6 +127,14 @@ class GradReducer:
                 self.flat[bi].mul_(1.0 / self.world)
         self._pending = []
         self._ready = [0] * len(self.buckets)
+
+    def adopt_grads(self, on=True):
+        """Overlapped exchange without accumulate kernels: call before every backward (it clears .grad); the hooks
+        pack and reduce each bucket as soon as it is complete; finish() afterwards; the optimiser then reads the
+        flat buckets (FlatAdamW.step(packed=True))."""
+        self._adopt = bool(on)
+        if on:
+            self.detach_grads()
 
     def detach_grads(self):
         """Set every .grad to None: the next backward then hands its gradient tensors over as they are (autograd

@@ -88,6 +88,21 @@ def _worker(rank, world, port, q):
     # .grad tensors are views of the flat buckets again
     spans = [(f.data_ptr(), f.data_ptr() + f.numel() * f.element_size()) for f in red.flat]
     assert all(any(lo <= p.grad.data_ptr() < hi for lo, hi in spans) for p in model.parameters())
+    # 3b) adopt mode: .grad = None before backward, every bucket packed + reduced from the hook of its last gradient
+    red.adopt_grads()
+    nn.functional.mse_loss(model(data[rank, 2]), target[rank, 2]).backward()
+    red.finish()
+    want = local_grads([2])
+    gathered = [[torch.zeros_like(g) for _ in range(world)] for g in want]
+    for g, outs in zip(want, gathered):
+        dist.all_gather(outs, g)
+    flat_views = [v for views in red.views for v in views]
+    params_in_order = [p for plist in red.buckets for p in plist]
+    by_param = {id(p): v for p, v in zip(params_in_order, flat_views)}
+    for p, outs in zip(model.parameters(), gathered):
+        assert torch.allclose(by_param[id(p)], sum(outs) / world, atol=1e-6), "adopt-mode bucket mismatch"
+    red.adopt_grads(False)
+    red.attach_grads()
     # 4) a BatchNorm-bearing replica: BatchNorm is per rank (no SyncBN), so
     #    train mode: the reduced gradient == the average of the per-shard gradients, each with its OWN batch statistics;
     #    eval mode : the reduced gradient == the single-process gradient on the concatenated batch
