@@ -274,14 +274,18 @@ def main():
         dom = next(iter(families))
         d = prof[dom]
         ach = d["bytes"] / 1e9 / (d["ms"] / 1e3)
-        # HBM bytes per launch from the committed PMC summary (rocprofv3 FETCH_SIZE/WRITE_SIZE passes of this
-        # same command, corrected as MI355X_MICROARCH.md prescribes; tools/pmc_summary.py) - null if absent
+        # HBM bytes per launch of the dominant kernel from the PMC summary (rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this
+        # same command, corrected as MI355X_MICROARCH.md prescribes; tools/profile_round.sh + tools/pmc_summary.py).  Only a
+        # summary collected from THIS kernel code counts (its csrc digest must match): otherwise null, never a stale number.
         traffic = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
-            key = dom.split("<")[0]
-            if key in pmc:
-                traffic = pmc[key]["hbm_bytes_per_launch"]
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from pmc_summary import csrc_digest
+            pmc = json.load(open(os.environ.get("PB_PMC_TRAFFIC", os.path.join(ROOT, "profiles", "r02_pmc_traffic.json"))))
+            if pmc.get("meta", {}).get("csrc_digest") == csrc_digest():
+                key = dom.split("<")[0]
+                if key in pmc["kernels"]:
+                    traffic = pmc["kernels"][key]["hbm_bytes_per_launch"]
         except Exception:
             traffic = None
         roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -10,9 +10,24 @@ WRITE_SIZE is exact for 16 B/lane stores and float atomics.  Kernel template ins
 base name (the launch mix of the bench is fixed, so per-launch averages are comparable run to run)."""
 import collections
 import csv
+import hashlib
 import json
+import os
 import re
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def csrc_digest():
+    """sha256 over the kernel sources and the C-ABI header: bench.py reports `roofline.traffic` from a PMC summary only
+    when it was collected from THIS code (otherwise null)."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "picklebot_amd", "csrc")
+    for f in sorted(os.listdir(d)) + ["../../include/picklebot_amd.h"]:
+        if f.endswith((".hip", ".h")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def base_name(n):
@@ -43,7 +58,8 @@ def main():
         wr = (wa[k][1] / wa[k][0] * 1024.0) if k in wa and wa[k][0] else 0.0
         res[k] = {"launches": n, "read_bytes_per_launch": round(rd), "write_bytes_per_launch": round(wr),
                   "hbm_bytes_per_launch": round(rd + wr)}
-    meta = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of bench.py --steps 3 --warmup 1",
+    meta = {"csrc_digest": csrc_digest(),
+            "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of bench.py --steps 3 --warmup 1",
             "correction": "reads = 2 x FETCH_SIZE (gfx950 wide-read undercount), KB -> bytes"}
     json.dump({"meta": meta, "kernels": dict(sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"]))},
               open(out, "w"), indent=1)

@@ -14,7 +14,9 @@ echo "fetch done"
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -o write -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph > $O/write.log 2>&1 || { echo write failed; tail -5 $O/write.log; exit 1; }
 echo "write done"
 cd $R
-timeout -k 10 600 python bench.py > $O/bench.jsonl 2> $O/bench.err || { echo bench failed; tail -5 $O/bench.err; exit 1; }
+python3 tools/pmc_summary.py $(find $O/fetch -name "*counter_collection.csv" | head -1) $(find $O/write -name "*counter_collection.csv" | head -1) $O/pmc_traffic.json > $O/pmc_summary.txt || { echo pmc summary failed; exit 1; }
+cp $(find $O/trace -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
+PB_PMC_TRAFFIC=$O/pmc_traffic.json PB_BENCH_DETAIL=$O/per_shape.txt timeout -k 10 600 python bench.py > $O/bench.jsonl 2> $O/bench.err || { echo bench failed; tail -5 $O/bench.err; exit 1; }
 tail -c 600 $O/bench.jsonl
 find $O -name "*.csv" | head -20
 du -sh $O
