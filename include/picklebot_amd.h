@@ -94,7 +94,8 @@ int pb_pw_weight_prep(const float* w, int N, int K, int transpose, const float* 
 
 /* The same conversion for many weight matrices in ONE launch (a model's forward prepares all of its pointwise
  * weights, both orientations, at once).  desc: device array of `count` records of four int64:
- * {fp32 source pointer, bf16 destination pointer, (N << 32) | K, transpose}; no scaling. */
+ * {fp32 source pointer, bf16 destination pointer, (N << 32) | K, mode}; mode 0: [N][K], 1: transposed [K][N],
+ * 2 / 3: blockdiag(B,B,B,B) of the mode-0 / mode-1 matrix B (the 4-rows-per-line form of K = 16 layers); no scaling. */
 int pb_pw_weight_prep_batch(const int64_t* desc, int count, int device, void* stream);
 
 /* Y[M,N] = X[M,K] * Wb[g(m)][N,K]^T, bf16, both operands streamed by LDS-DMA rings (pw_gemm_dma.hip); same

@@ -406,24 +406,31 @@ __global__ __launch_bounds__(256) void pw_weight_prep_kernel(PrepArgs a) {
   }
 }
 
-// the same conversion for a whole model in one launch: desc[t] = {w, out, N << 32 | K, transpose} (device array)
+// the same conversion for a whole model in one launch: desc[t] = {w, out, N << 32 | K, mode} (device array)
+//   mode 0: out[N][K] = w;  1: out[K][N] = w^T;  2 / 3: blockdiag(B, B, B, B) [4R][4C] of the mode-0 / mode-1 matrix B [R][C]
+//   (the 4-rows-per-line form of the K = 16 layers: [M,16] x W^T == [M/4,64] x blockdiag(W,W,W,W)^T)
 __global__ __launch_bounds__(256) void pw_weight_prep_batch_kernel(const int64_t* desc) {
   const int64_t* d = desc + 4 * blockIdx.y;
-  PrepArgs a;
-  a.w = (const float*)d[0]; a.out = (bf16_t*)d[1]; a.scale = nullptr;
-  a.N = (int)(d[2] >> 32); a.K = (int)(d[2] & 0xffffffffLL); a.G = 1; a.transpose = (int)d[3];
-  const int R = a.transpose ? a.K : a.N, C = a.transpose ? a.N : a.K;
-  const int64_t total8 = (int64_t)R * C / 8;
+  const float* w = (const float*)d[0];
+  bf16_t* out = (bf16_t*)d[1];
+  const int N = (int)(d[2] >> 32), K = (int)(d[2] & 0xffffffffLL), mode = (int)d[3];
+  const bool transpose = mode & 1, fold = mode >= 2;
+  const int R = transpose ? K : N, C = transpose ? N : K;           // the base matrix B
+  const int RO = fold ? 4 * R : R, CO = fold ? 4 * C : C;
+  const int64_t total8 = (int64_t)RO * CO / 8;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total8; i += (int64_t)gridDim.x * 256) {
     const int64_t e = i * 8;
-    const int r = (int)(e / C), c0 = (int)(e - (int64_t)r * C);
+    const int ro = (int)(e / CO), co0 = (int)(e - (int64_t)ro * CO);
     bf16x8 o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int c = c0 + j;
-      o[j] = (bf16_t)(a.transpose ? a.w[(int64_t)c * a.K + r] : a.w[(int64_t)r * a.K + c]);
+      const int co = co0 + j;
+      const int r = fold ? ro % R : ro, c = fold ? co % C : co;
+      float v = transpose ? w[(int64_t)c * K + r] : w[(int64_t)r * K + c];
+      if (fold && ro / R != co / C) v = 0.f;
+      o[j] = (bf16_t)v;
     }
-    *reinterpret_cast<bf16x8*>(a.out + e) = o;
+    *reinterpret_cast<bf16x8*>(out + e) = o;
   }
 }
 

@@ -312,17 +312,30 @@ class WeightSet:
                 N, K = w.shape
                 o0 = torch.empty((N, K), dtype=torch.bfloat16, device=w.device)
                 o1 = torch.empty((K, N), dtype=torch.bfloat16, device=w.device)
-                outs.append((o0, o1))
                 rows.append([w.data_ptr(), o0.data_ptr(), (N << 32) | K, 0])
                 rows.append([w.data_ptr(), o1.data_ptr(), (N << 32) | K, 1])
+                f0 = f1 = None
+                # the K = 16 GEMMs run as K = 64 GEMMs on blockdiag(W,W,W,W) (pw_fwd): forward when this layer reads 16
+                # channels (K == 16, 4N <= 96), backward-data when it writes 16 (N == 16, 4K <= 96)
+                if _K16_FOLD and K == 16 and 4 * N <= 96:
+                    f0 = torch.empty((4 * N, 4 * K), dtype=torch.bfloat16, device=w.device)
+                    rows.append([w.data_ptr(), f0.data_ptr(), (N << 32) | K, 2])
+                if _K16_FOLD and N == 16 and 4 * K <= 96:
+                    f1 = torch.empty((4 * K, 4 * N), dtype=torch.bfloat16, device=w.device)
+                    rows.append([w.data_ptr(), f1.data_ptr(), (N << 32) | K, 3])
+                outs.append((o0, o1, f0, f1))
             self.desc = torch.tensor(rows, dtype=torch.int64, device=weights[0].device)
             self.ptrs, self.outs = ptrs, outs
         dev, st = _dev_stream(weights[0])
         _launch("pw_weight_prep_batch_kernel", sum(w.numel() * 8 for w in weights), "pb_pw_weight_prep_batch", _p(self.desc),
                 self.desc.shape[0], dev, st)
-        for w, (o0, o1) in zip(weights, self.outs):
+        for w, (o0, o1, f0, f1) in zip(weights, self.outs):
             _wcache[(w.data_ptr(), w.numel(), False)] = (_wgen, o0)      # forward: GEMM weights [N,K] = w
             _wcache[(w.data_ptr(), w.numel(), True)] = (_wgen, o1)       # backward-data: GEMM weights [K,N] = w^T
+            if f0 is not None:
+                _wcache[(w.data_ptr(), w.numel(), False, "fold4")] = (_wgen, f0)
+            if f1 is not None:
+                _wcache[(w.data_ptr(), w.numel(), True, "fold4")] = (_wgen, f1)
 
 
 def pw_fwd(x, w, *, w_transposed=False, in_scale=None, in_shift=None, in_act="none", in_slope=0.0, row_scale=None,

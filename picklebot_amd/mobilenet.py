@@ -71,12 +71,27 @@ class _MaskPool:
     masks of n*c <= 5k elements; drawing each one separately cost 3 tiny launches per block."""
     SIZE = 1 << 20
 
+    CAPTURE_SIZE = 1 << 16           # masks drawn per (forward, p) while a HIP graph is being captured
+
     def __init__(self):
         self._pools = {}             # (device, p) -> [flat mask tensor, offset]
+        self._cap = {}               # (device, p) -> [forward generation, flat mask tensor, offset]
 
     def take(self, p, numel, device):
-        if numel > self.SIZE // 4 or torch.cuda.is_current_stream_capturing():
-            # (under HIP-graph capture a pooled slice would replay the same mask for ever: draw in-graph)
+        capturing = torch.cuda.is_current_stream_capturing()
+        if capturing and numel <= self.CAPTURE_SIZE // 4:
+            # under HIP-graph capture a pooled slice would replay the same mask for ever: the masks of ONE forward are
+            # drawn in-graph by one Bernoulli launch (each replay redraws them), not three tiny launches per block
+            gen = getattr(PF.K, "_wgen", 0)
+            ent = self._cap.get((device, p))
+            if ent is None or ent[0] != gen or ent[2] + numel > self.CAPTURE_SIZE:
+                keep = torch.full((self.CAPTURE_SIZE,), 1.0 - p, dtype=torch.float32, device=device)
+                ent = [gen, torch.bernoulli(keep).mul_(1.0 / (1.0 - p)), 0]
+                self._cap[(device, p)] = ent
+            off = ent[2]
+            ent[2] = off + (numel + 3) // 4 * 4
+            return ent[1][off:off + numel]
+        if numel > self.SIZE // 4 or capturing:
             keep = torch.full((numel,), 1.0 - p, dtype=torch.float32, device=device)
             return torch.bernoulli(keep) * (1.0 / (1.0 - p))
         ent = self._pools.get((device, p))
