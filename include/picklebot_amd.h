@@ -34,7 +34,7 @@ typedef enum {
   PB_ACT_HSIGMOID = 4, PB_ACT_SILU = 5
 } pb_act;
 
-#define PB_ABI_VERSION 12
+#define PB_ABI_VERSION 13
 
 /* Determinism.  Nothing in this library accumulates with floating-point atomics: two runs of the same binary on the
  * same inputs give bit-identical outputs and gradients.  Every reduction that spans workgroups stores one partial
@@ -348,6 +348,17 @@ int pb_attention_fwd(const void* qkv, void* out, float* lse, int64_t G, int n, f
 int pb_attention_fwd_fp8(const void* qkv, void* out, float* lse, int64_t G, int n, float scale, int device, void* stream);
 int pb_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
                      int64_t G, int n, float scale, pb_dtype dtype, int device, void* stream);
+
+/* ---------------------------------------------------------------- MobileViT-V2 separable attention on 3-D patch tokens
+ * The part of LinearSelfAttention.forward between qkv_proj and out_proj (mobilevitv2.py:37-52), on the token rows of the
+ * 3-D unfold: G = batch * pixels-in-patch groups of n patches.  qkv [G*n][1+2D] keeps qkv_proj's column order
+ * (q | k | v, :37); scores fp32 [G*n] = softmax over the n patches (:41); ctx fp32 [G][D] = sum_i scores*k (:46-48);
+ * out [G*n][D] = relu(v)*ctx (:52).  Backward: dctx fp32 [G][D] and dscore fp32 [G*n] are scratch, dqkv is fully written.
+ * D <= 256.  The reference module is 2-D and unregistered: same arithmetic, 3-D patches. */
+int pb_linattn_fwd(const void* qkv, float* scores, float* ctx, void* out, int G, int n, int D, pb_dtype dtype, int device,
+                   void* stream);
+int pb_linattn_bwd(const void* qkv, const float* scores, const float* ctx, const void* dout, float* dctx, float* dscore,
+                   void* dqkv, int G, int n, int D, pb_dtype dtype, int device, void* stream);
 
 /* ---------------------------------------------------------------- misc
  * fp32 [R][C] -> [C][R] (depthwise weight [C][taps] -> [taps][C] staging). */

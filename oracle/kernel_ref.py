@@ -460,6 +460,30 @@ def attention_bwd(qkv, out, dout, lse, G, n, scale):
     return dqkv.to(qkv.dtype)
 
 
+def linattn_fwd(qkv, G, n):
+    """mobilevitv2.py:37-52 on token rows [G*n, 1+2D] (q | k | v)."""
+    D = (qkv.shape[1] - 1) // 2
+    x = qkv.float().view(G, n, 1 + 2 * D)
+    scores = torch.softmax(x[..., 0], dim=-1)                       # over the n patches (:41)
+    ctx = (x[..., 1:1 + D] * scores[..., None]).sum(1)              # [G, D] (:46-48)
+    out = torch.relu(x[..., 1 + D:]) * ctx[:, None, :]              # (:52)
+    return out.reshape(G * n, D).to(qkv.dtype), scores.reshape(G * n).contiguous(), ctx.contiguous()
+
+
+def linattn_bwd(qkv, scores, ctx, dout, G, n):
+    D = (qkv.shape[1] - 1) // 2
+    x = qkv.float().view(G, n, 1 + 2 * D)
+    k, v = x[..., 1:1 + D], x[..., 1 + D:]
+    do = dout.float().view(G, n, D)
+    a = scores.view(G, n)
+    dctx = (do * torch.relu(v)).sum(1)                              # [G, D]
+    dv = do * ctx[:, None, :] * (v > 0)
+    dk = a[..., None] * dctx[:, None, :]
+    da = (k * dctx[:, None, :]).sum(-1)                             # [G, n]
+    dq = a * (da - (a * da).sum(-1, keepdim=True))
+    return torch.cat([dq[..., None], dk, dv], -1).reshape(G * n, 1 + 2 * D).to(qkv.dtype)
+
+
 def adamw_flat(p, g, m, v, step, lr, beta1, beta2, eps, weight_decay, inv_scale=None, found_inf=None, lr_wd=None):
     """torch.optim.AdamW's single-tensor update (torch/optim/adamw.py) on flat buffers, in place.  lr_wd: the (lr,
     weight_decay) pair as a tensor, which the product's kernel reads from device memory instead of the host values."""

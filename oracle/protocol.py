@@ -237,11 +237,16 @@ def _block_cases():
 
 
 BLOCK_CASES = _block_cases()
+# mobilevitv2.py's separable attention, kept in its own fixture file (blocks_v2.npz): input in the
+# reference layout (batch, embed_dim, pixels-in-patch, patches)
+V2_CASES = {"linattn16": ("LinearSelfAttention", dict(embed_dim=16), (2, 16, 8, 12)),
+            "linattn40": ("LinearSelfAttention", dict(embed_dim=40), (1, 40, 4, 30))}
+_ALL_BLOCKS = {**BLOCK_CASES, **V2_CASES}
 _ACT = {"relu": nn.ReLU, "leaky_relu": nn.LeakyReLU, "hardswish": nn.Hardswish}
 
 
 def build_block(ns, case, device="cpu"):
-    cls_name, kwargs, _ = BLOCK_CASES[case]
+    cls_name, kwargs, _ = _ALL_BLOCKS[case]
     kwargs = dict(kwargs)
     if isinstance(kwargs.get("nonlinearity"), str):
         kwargs["nonlinearity"] = _ACT[kwargs["nonlinearity"]]()
@@ -253,7 +258,7 @@ def build_block(ns, case, device="cpu"):
 def run_block_case(ns, case, device="cpu", dtype=torch.float32, train=True, autocast=False):
     """Full tensors (as float64 arrays): output, input gradient and every parameter gradient of
     L = sum(out * G) for a formula-generated G."""
-    _, _, shape = BLOCK_CASES[case]
+    _, _, shape = _ALL_BLOCKS[case]
     blk = build_block(ns, case, "cpu")
     if dtype == torch.float64:
         blk = blk.double()

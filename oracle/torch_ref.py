@@ -360,6 +360,24 @@ class MobileViT(nn.Module):
                     m.bias.data.zero_()
 
 
+class LinearSelfAttention(nn.Module):
+    """mobilevitv2.py:9-55 (the shape prints of :30-38 left out).  Input (batch, embed_dim, pixels-in-patch, patches)."""
+
+    def __init__(self, embed_dim, dropout=0.0):
+        super().__init__()
+        self.qkv_proj = nn.Conv2d(embed_dim, 1 + 2 * embed_dim, kernel_size=1, bias=True)     # :13-18
+        self.attn_dropout = nn.Dropout(p=dropout)
+        self.out_proj = nn.Conv2d(embed_dim, embed_dim, kernel_size=1, bias=True)             # :20-25
+        self.embed_dim = embed_dim
+
+    def forward(self, hidden_states):
+        qkv = self.qkv_proj(hidden_states)
+        query, key, value = torch.split(qkv, [1, self.embed_dim, self.embed_dim], dim=1)      # :37
+        scores = self.attn_dropout(F.softmax(query, dim=-1))                                  # over the patches, :41-42
+        context = (key * scores).sum(dim=-1, keepdim=True)                                    # :46-48
+        return self.out_proj(F.relu(value) * context.expand_as(value))                        # :52-53
+
+
 class _MeanTHW(nn.Module):
     """einops Reduce('b c t h w -> b c', 'mean') (mobilevit.py:191); parameter-free."""
 

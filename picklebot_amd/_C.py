@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libpicklebot_amd.so")
 
 PB_F32, PB_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY_RELU, ACT_HSWISH, ACT_HSIGMOID, ACT_SILU = range(6)
-ABI_VERSION = 12
+ABI_VERSION = 13
 STAT_SLOTS = 512
 
 
@@ -72,6 +72,8 @@ SIGNATURES = {
     "pb_attention_fwd": [P, P, P, L, I, F, I, I, P],
     "pb_attention_fwd_fp8": [P, P, P, L, I, F, I, P],
     "pb_attention_bwd": [P, P, P, P, P, P, L, I, F, I, I, P],
+    "pb_linattn_fwd": [P, P, P, P, I, I, I, I, I, P],
+    "pb_linattn_bwd": [P, P, P, P, P, P, P, I, I, I, I, I, P],
     "pb_conv_weight_prep": [P, P, I, I, I, I, I, P],
     "pb_conv3d_fwd": [P, P, P, POINTER(ConvShape), I, P, P, I, F, P, I, P],
     "pb_conv3d_fwd_bf16w": [P, P, P, POINTER(ConvShape), P, P, P, I, F, P, I, P],

@@ -9,10 +9,11 @@ a module does (hand-written HIP kernels behind a C ABI, no eager fallback).
 from .mobilenet import Bottleneck3D, MobileNetLarge3D, MobileNetSmall3D, SEBlock3D  # noqa: F401
 from .movinet import CausalConv3d, MoviNetBottleneck, MoViNetA2  # noqa: F401
 from .mobilevit import Attention, FeedForward, MobileViT, MobileViTBlock, Transformer  # noqa: F401
+from .mobilevitv2 import LinearSelfAttention  # noqa: F401
 from .optim import FlatAdamW  # noqa: F401
 from .functional import fp8_attention  # noqa: F401
 from .harness import (DevicePrefetcher, calculate_accuracy, calculate_accuracy_bce, custom_collate, estimate_loss,  # noqa: F401
                       extract_features_labels, strip_compile_prefix)
 
 __all__ = ["SEBlock3D", "Bottleneck3D", "MobileNetLarge3D", "MobileNetSmall3D", "CausalConv3d", "MoviNetBottleneck",
-           "MoViNetA2", "FeedForward", "Attention", "Transformer", "MobileViTBlock", "MobileViT"]
+           "MoViNetA2", "FeedForward", "Attention", "Transformer", "MobileViTBlock", "MobileViT", "LinearSelfAttention"]

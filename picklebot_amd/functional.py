@@ -715,6 +715,42 @@ def ff_block(rows, w1, w2):
     return _FFBlock.apply(rows if rows.is_contiguous() else rows.contiguous(), w1, w2)
 
 
+class _LinAttn(torch.autograd.Function):
+    """out_proj(relu(v) * sum_i softmax_i(q) k)  with (q | k | v) = qkv_proj(x)   (mobilevitv2.py:28-55), rows [G*n, D]:
+    G = batch * pixels-in-patch groups of n patches (the 3-D unfold's token layout)."""
+
+    @staticmethod
+    def forward(ctx, x, w_qkv, b_qkv, w_out, b_out, G, n):
+        qkv = K.pw_fwd(x, w_qkv, out_shift=b_qkv)
+        o, scores, cvec = K.linattn_fwd(qkv, G, n)
+        y = K.pw_fwd(o, w_out, out_shift=b_out)
+        ctx.save_for_backward(x, qkv, o, scores, cvec, w_qkv, w_out)
+        ctx.meta = (G, n, b_qkv is not None, b_out is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, qkv, o, scores, cvec, w_qkv, w_out = ctx.saved_tensors
+        G, n, has_bq, has_bo = ctx.meta
+        dy = dy if dy.is_contiguous() else dy.contiguous()
+        dw_out, dw_qkv = _zeros_many(x, tuple(w_out.shape), tuple(w_qkv.shape))
+        K.pw_bwd_weight(dy, o, dw_out)
+        do = K.pw_fwd(dy, w_out, w_transposed=True)
+        dqkv = K.linattn_bwd(qkv, scores, cvec, do, G, n)
+        K.pw_bwd_weight(dqkv, x, dw_qkv)
+        db_out = db_qkv = None
+        if has_bo:
+            db_out = K.chan_stats(dy, _zeros((K.REPL, 2, dy.shape[1]), x))[:, 0].sum(0)
+        if has_bq:
+            db_qkv = K.chan_stats(dqkv, _zeros((K.REPL, 2, dqkv.shape[1]), x))[:, 0].sum(0)
+        dx = K.pw_fwd(dqkv, w_qkv, w_transposed=True) if ctx.needs_input_grad[0] else None
+        return dx, dw_qkv, db_qkv, dw_out, db_out, None, None
+
+
+def linattn_block(rows, w_qkv, b_qkv, w_out, b_out, G, n):
+    return _LinAttn.apply(rows if rows.is_contiguous() else rows.contiguous(), w_qkv, b_qkv, w_out, b_out, G, n)
+
+
 class _Concat2(torch.autograd.Function):
     """torch.cat((a, b), channel) for NDHWC tensors (mobilevit.py:141)."""
 

@@ -1039,6 +1039,37 @@ def attention_bwd(qkv, out, dout, lse, G, n, scale):
     return dqkv
 
 
+def linattn_fwd(qkv, G, n):
+    """MobileViT-V2 separable attention core on 3-D patch tokens (mobilevitv2.py:37-52): qkv [G*n, 1+2D] in qkv_proj's
+    (q | k | v) column order -> (out [G*n, D] = relu(v) * ctx, scores fp32 [G*n], ctx fp32 [G, D])."""
+    _rows(qkv, "qkv")
+    L = qkv.shape[1]
+    D = (L - 1) // 2
+    if qkv.shape[0] != G * n or L != 1 + 2 * D or D < 1:
+        raise ValueError(f"linattn_fwd: qkv shape {tuple(qkv.shape)} is not ({G * n}, 1 + 2*D)")
+    out = torch.empty((G * n, D), dtype=qkv.dtype, device=qkv.device)
+    scores = torch.empty((G * n,), dtype=torch.float32, device=qkv.device)
+    ctx = torch.empty((G, D), dtype=torch.float32, device=qkv.device)
+    dev, st = _dev_stream(qkv)
+    _launch("linattn_fwd", _nb(qkv, out), "pb_linattn_fwd", _p(qkv), _p(scores), _p(ctx), _p(out), G, n, D, _dt(qkv), dev, st,
+            detail=f"G{G} n{n} D{D}")
+    return out, scores, ctx
+
+
+def linattn_bwd(qkv, scores, ctx, dout, G, n):
+    _rows(qkv, "qkv"); _rows(dout, "dout")
+    D = (qkv.shape[1] - 1) // 2
+    if qkv.shape != (G * n, 1 + 2 * D) or dout.shape != (G * n, D) or dout.dtype != qkv.dtype:
+        raise ValueError("linattn_bwd: shape/dtype mismatch")
+    _f32(scores, (G * n,), "scores"); _f32(ctx, (G, D), "ctx")
+    dqkv = torch.empty_like(qkv)
+    scratch = torch.empty((G * D + G * n,), dtype=torch.float32, device=qkv.device)
+    dev, st = _dev_stream(qkv)
+    _launch("linattn_bwd", _nb(qkv, dout, dqkv), "pb_linattn_bwd", _p(qkv), _p(scores), _p(ctx), _p(dout), _p(scratch[:G * D]),
+            _p(scratch[G * D:]), _p(dqkv), G, n, D, _dt(qkv), dev, st, detail=f"G{G} n{n} D{D}")
+    return dqkv
+
+
 # ------------------------------------------------------------------------------ optimizer step
 def adamw_flat(p, g, m, v, step, lr, beta1, beta2, eps, weight_decay, inv_scale=None, found_inf=None, lr_wd=None):
     """In-place fused AdamW over flat fp32 buffers; `step`: device float tensor holding this update's step number;

@@ -33,6 +33,14 @@ def test_block_dataflow(case, golden, cpu_kernels):
     assert not bad, f"{bad[:5]} worst {worst}"
 
 
+@pytest.mark.parametrize("case", list(protocol.V2_CASES))
+def test_v2_linear_attention_dataflow(case, golden, cpu_kernels):
+    """picklebot_amd.LinearSelfAttention (3-D patch tokens) over the CPU kernel mirrors == the real mobilevitv2 module."""
+    res = protocol.run_block_case(picklebot_amd, case)
+    bad, worst = compare_full(res, golden("blocks_v2"), case + "/", 1e-5, 1e-5)
+    assert not bad, f"{bad[:5]} worst {worst}"
+
+
 @pytest.mark.parametrize("case", MODELS)
 def test_model_dataflow(case, golden, cpu_kernels):
     with contextlib.redirect_stdout(io.StringIO()):

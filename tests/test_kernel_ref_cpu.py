@@ -225,6 +225,22 @@ def test_attention_vs_scaled_dot_product_attention():
     close(R.attention_bwd(qkv.detach(), got, dout, lse, G, n, 16 ** -0.5), gq, 1e-4)
 
 
+def test_linear_attention_vs_torch_restatement_of_mobilevitv2():
+    """mobilevitv2.py:37-52 between qkv_proj and out_proj, in the reference's (b, c, pixels, patches) layout."""
+    b, P, n, D = 2, 3, 7, 5
+    G = b * P
+    qkv = torch.randn(G * n, 1 + 2 * D, requires_grad=True)
+    x = qkv.view(b, P, n, 1 + 2 * D).permute(0, 3, 1, 2)                  # (b, 1+2D, P, n)
+    q, k, v = torch.split(x, [1, D, D], dim=1)
+    want = (F.relu(v) * (k * F.softmax(q, dim=-1)).sum(-1, keepdim=True)).permute(0, 2, 3, 1).reshape(G * n, D)
+    got, scores, ctx = R.linattn_fwd(qkv.detach(), G, n)
+    close(got, want.detach(), 1e-6)
+    close(scores.view(G, n).sum(-1), torch.ones(G), 1e-6)
+    dout = torch.randn(G * n, D)
+    (gq,) = torch.autograd.grad(want, qkv, dout)
+    close(R.linattn_bwd(qkv.detach(), scores, ctx, dout, G, n), gq, 1e-5)
+
+
 def test_adamw_flat_vs_torch_optim_adamw_incl_skip():
     n = 37
     p0, g = torch.randn(n), torch.randn(n)

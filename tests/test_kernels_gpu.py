@@ -448,6 +448,26 @@ def test_attention(K, G, n, dtype):
     check("attn_dqkv", dq, dq_ref, dtype, 1.5)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("G,n,D", [(16, 12, 16), (3, 1, 40), (8, 147, 64), (5, 300, 96), (2, 784, 144), (1, 1000, 240), (7, 33, 256)])
+def test_linear_attention(K, G, n, D, dtype):
+    """mobilevitv2.py:37-52 on 3-D patch tokens: softmax over the patches, context vector, relu(v)*context; backward of
+    all three column blocks.  Two launches of the same input give the same bits (fixed-order sums)."""
+    qkv = rnd((G * n, 1 + 2 * D), dtype, 70, scale=1.5)
+    out_ref, sc_ref, ctx_ref = R.linattn_fwd(qkv, G, n)
+    out, sc, ctx = K.linattn_fwd(dev(qkv), G, n)
+    check("linattn_scores", sc, sc_ref, torch.float32, 2.0)
+    check("linattn_ctx", ctx, ctx_ref, torch.float32, 2.0)
+    check("linattn_out", out, out_ref, dtype)
+    out2, _, _ = K.linattn_fwd(dev(qkv), G, n)
+    assert torch.equal(out, out2)
+    dout = rnd((G * n, D), dtype, 71)
+    dq_ref = R.linattn_bwd(qkv, sc_ref, ctx_ref, dout, G, n)
+    dq = K.linattn_bwd(dev(qkv), dev(sc_ref), dev(ctx_ref), dev(dout), G, n)
+    check("linattn_dqkv", dq, dq_ref, dtype, 1.5)
+    assert torch.equal(dq, K.linattn_bwd(dev(qkv), dev(sc_ref), dev(ctx_ref), dev(dout), G, n))
+
+
 @pytest.mark.parametrize("n", [4096, 1000003, 13])
 def test_adamw_flat_and_grad_check(K, n):
     """Fused AdamW over a flat bucket vs torch.optim.AdamW's rule (CPU mirror), several steps incl. the ragged tail;

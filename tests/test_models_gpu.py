@@ -50,6 +50,20 @@ def test_block_bf16_autocast_vs_golden(case, golden):
     assert not bad, f"{bad[:5]} worst {worst}"
 
 
+@pytest.mark.parametrize("case", list(protocol.V2_CASES))
+def test_v2_linear_attention_vs_golden(case, golden):
+    """mobilevitv2.LinearSelfAttention on the HIP path: output, input gradient and all four parameter
+    gradients against the real module's fp64 values; fp32 flat 1e-3, bf16-autocast within max(2e-2, 8 x the reference's
+    own bf16 deviation) like the other tiny blocks."""
+    _native_loaded()
+    res = protocol.run_block_case(picklebot_amd, case, device=DEV)
+    bad, worst = compare_full(res, golden("blocks_v2"), case + "/", 1e-3, 1e-3)
+    assert not bad, f"{bad[:5]} worst {worst}"
+    res = protocol.run_block_case(picklebot_amd, case, device=DEV, autocast=True)
+    bad, worst = compare_full(res, golden("blocks_v2"), case + "/", 2e-2, 2e-2, dev="refbf16_err", factor=8.0)
+    assert not bad, f"{bad[:5]} worst {worst}"
+
+
 @pytest.mark.parametrize("case", MODELS)
 def test_model_fp32_vs_golden(case, golden):
     """Every key (forward quantities, BN buffers, and per-parameter gradient norms / samples / full-tensor projections)

@@ -47,6 +47,16 @@ def test_block_matches_reference_golden(case, golden):
     assert not bad, f"{bad[:5]} worst {worst}"
 
 
+@pytest.mark.parametrize("case", list(protocol.V2_CASES))
+def test_v2_linear_attention_matches_reference_golden(case, golden):
+    """mobilevitv2.LinearSelfAttention: the restatement against the real module's fp64 values."""
+    res = protocol.run_block_case(torch_ref, case)
+    g = golden("blocks_v2")
+    assert len([k for k in g if k.startswith(case + "/") and "_err/" not in k]) == len(res)
+    bad, worst = compare_full(res, g, case + "/", TOL, TOL)
+    assert not bad, f"{bad[:5]} worst {worst}"
+
+
 @pytest.mark.parametrize("case", ["causal_dw_533", "causal_333"])
 def test_causal_streaming_known_answer(case, golden):
     res = protocol.run_causal_stream_case(torch_ref, case)
