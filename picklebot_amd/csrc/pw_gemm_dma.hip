@@ -19,6 +19,7 @@
 // on the weight side, so they contribute exactly 0.
 #include "pb_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -40,6 +41,8 @@ struct DmaArgs {
   float* stats;
   int n_tiles;
   int m_tiles;
+  int dbg;                   // diagnosis only (PB_GEMM_DMA_DBG): 1 = no X DMA, 2 = no W DMA, 4 = no stores
+  int step_g, step_nt;       // (grid / 8) divided by n_tiles: quotient and remainder (the kernel's tile cursor step)
   // implicit-GEMM convolution (CONV instantiations): X is [N,Ti,Hi,Wi,Cin], row m = output voxel, K = taps*Cin with
   // k = tap*Cin + c; a 16-byte chunk (8 channels) of a row comes from the voxel shifted by the tap, or from `zero`
   int Ti, Hi, Wi, To, Ho, Wo, pt, ph, pw, kh, kw, taps, Cin;
@@ -67,28 +70,36 @@ __global__ __launch_bounds__(256) void pw_gemm_dma_kernel(DmaArgs a) {
   typedef bf16_t T;
   constexpr int VEC = 8, KS = 64, MK = 32;
   constexpr int BN = NT * 16;
+  constexpr int WCH = (NT + 1) / 2;                  // weight chunks (DMA instructions) per thread and stage (rows rounded up to 32)
   constexpr int A_STAGE = BM * 128;                  // bytes
-  constexpr int W_STAGE = BN * 128;
+  constexpr int W_STAGE = WCH * 4096;
   constexpr int STAGE = A_STAGE + W_STAGE;
-  constexpr int WCH = NT / 2;                        // weight chunks (DMA instructions) per thread and stage
   constexpr int GPS = 4 + WCH;                       // DMA instructions per thread and stage
   constexpr int EPI_LD = BN + VEC;
-  constexpr int ER = (NT >= 8 && NS == 2) ? 8 : 16;  // rows per epilogue pass (8: the staging tile halves, two workgroups fit a CU)
-  constexpr int EPI_BYTES = 4 * ER * EPI_LD * 2;
   extern __shared__ __attribute__((aligned(1024))) unsigned char dsmem[];
   unsigned char* ring = dsmem;                                   // [NS][A | W]
   T* epi_base = (T*)(dsmem + NS * STAGE);                        // [4 waves][16][EPI_LD]
-  float* sred = (float*)(dsmem + NS * STAGE + EPI_BYTES);        // [4][BN][2]
+  float* sred = (float*)(dsmem + NS * STAGE);                    // [4][BN][2]: aliases the staging tiles (flush_stats only)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nk = (a.K + KS - 1) / KS;
   const int n_tiles = a.n_tiles, m_tiles = a.m_tiles;
   const int total = n_tiles == 1 ? m_tiles : ((m_tiles + 7) / 8) * 8 * n_tiles;
-  auto tile_mt = [&](int t) { return n_tiles == 1 ? t : ((t >> 3) / n_tiles) * 8 + (t & 7); };
-  auto tile_nt = [&](int t) { return n_tiles == 1 ? 0 : (t >> 3) % n_tiles; };
-  auto next_valid = [&](int t) {
-    while (t < total && tile_mt(t) >= m_tiles) t += gridDim.x;
-    return t;
+  // Tile t = ((g * n_tiles + nt) * 8 + r8): row panel g*8 + r8, column tile nt.  Workgroups b, b+8, b+16, ... (one XCD)
+  // hold the column tiles of the same row panels, so the X panel is fetched from HBM once and re-read through that XCD's
+  // L2.  The grid is a multiple of 8, so r8 is fixed per workgroup and (g, nt) advance by a constant pair per step - no
+  // division in the loop; when the grid is also a multiple of 8*n_tiles (the host arranges that when it can), nt is
+  // fixed too: one weight slice and one statistics flush per workgroup.
+  const int r8 = (int)(blockIdx.x & 7);
+  struct Cur { int t, g, nt; };
+  auto cur_valid = [&](const Cur& c) { return c.g * 8 + r8 < m_tiles; };
+  auto cur_step = [&](Cur& c) {
+    do {
+      c.t += (int)gridDim.x;
+      c.nt += a.step_nt;
+      c.g += a.step_g;
+      if (c.nt >= n_tiles) { c.nt -= n_tiles; ++c.g; }
+    } while (c.t < total && !cur_valid(c));
   };
   // row panel -> first row, end row (exclusive) and weight group
   auto panel = [&](int mt, int64_t& m0, int64_t& mend, int& grp) {
@@ -128,11 +139,22 @@ __global__ __launch_bounds__(256) void pw_gemm_dma_kernel(DmaArgs a) {
     w_cs[i] = ((f & 7) ^ ((w_row[i] >> 1) & 7)) * VEC;
   }
   const int wave_off = __builtin_amdgcn_readfirstlane(wave * 1024);
-  // CONV: the four rows this thread fetches for the tile being requested: coordinates of their tap-(0,0,0) source voxel
+  // the tile being REQUESTED (the issue cursor): this thread's source addresses at k = 0, set once per tile
+  const T* a_src[CONV ? 1 : 4];
+  const T* w_src[WCH];
   int rq_t[CONV ? 4 : 1], rq_h[CONV ? 4 : 1], rq_w[CONV ? 4 : 1], rq_pix[CONV ? 4 : 1];
-  auto set_rows = [&](int t) {
+  auto set_rows = [&](const Cur& c) {
+    int64_t m0, mend;
+    int grp;
+    panel(c.g * 8 + r8, m0, mend, grp);
+    const T* wg = a.WB + (int64_t)grp * a.w_group_stride;
+    const int n0 = c.nt * BN;
+#pragma unroll
+    for (int i = 0; i < WCH; ++i) {
+      const int n = min(n0 + w_row[i], a.N - 1);             // columns past N: any valid row (never stored)
+      w_src[i] = wg + (int64_t)n * a.K + w_cs[i];
+    }
     if constexpr (CONV) {
-      const int64_t m0 = (int64_t)tile_mt(t) * BM;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int m = (int)min(m0 + a_row[i], a.M - 1);
@@ -142,17 +164,19 @@ __global__ __launch_bounds__(256) void pw_gemm_dma_kernel(DmaArgs a) {
         rq_t[i] = to - a.pt; rq_h[i] = ho - a.ph; rq_w[i] = wo - a.pw;
         rq_pix[i] = ((n * a.Ti + rq_t[i]) * a.Hi + rq_h[i]) * a.Wi + rq_w[i];
       }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int64_t m = min(m0 + a_row[i], a.M - 1);       // rows past the panel: any valid row (never stored)
+        a_src[i] = a.X + m * a.K + a_cs[i];
+      }
     }
   };
 
-  auto issue = [&](int t, int ks, int buf) {
-    int64_t m0, mend;
-    int grp;
-    panel(tile_mt(t), m0, mend, grp);
-    const int n0 = tile_nt(t) * BN, k0 = ks * KS;
+  auto issue = [&](int ks, int buf) {
+    const int k0 = ks * KS;
     unsigned char* A = ring + buf * STAGE + wave_off;
     unsigned char* W = ring + buf * STAGE + A_STAGE + wave_off;
-    const T* wg = a.WB + (int64_t)grp * a.w_group_stride;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int k = k0 + a_cs[i];
@@ -169,49 +193,50 @@ __global__ __launch_bounds__(256) void pw_gemm_dma_kernel(DmaArgs a) {
         }
         glds16(src, A + i * 4096);
       } else {
-        const int64_t m = min(m0 + a_row[i], a.M - 1);       // rows past the panel: any valid row (never stored)
-        if (k < a.K) glds16(a.X + m * a.K + k, A + i * 4096);
+        if (k < a.K && !(a.dbg & 1)) glds16(a_src[i] + k0, A + i * 4096);
       }
     }
 #pragma unroll
     for (int i = 0; i < WCH; ++i) {
-      const int k = k0 + w_cs[i];
-      const int n = min(n0 + w_row[i], a.N - 1);             // columns past N: any valid row (never stored)
-      if (k < a.K) glds16(wg + (int64_t)n * a.K + k, W + i * 4096);
+      if (a.dbg & 2) continue;
+      if (k0 + w_cs[i] < a.K) glds16(w_src[i] + k0, W + i * 4096);
       else *reinterpret_cast<u32x4*>(ring + buf * STAGE + A_STAGE + (i * 256 + tid) * 16) = u32x4{0u, 0u, 0u, 0u};
     }
   };
 
+  // Accumulators: the weight slice is the MFMA's A operand and the activation rows its B operand, so a lane holds
+  // FOUR CONSECUTIVE OUTPUT COLUMNS n = j*16 + rgrp*4 + (0..3) of one row m = i*16 + ccol: the epilogue converts them in
+  // pairs and stages 8 bytes per lane and block (instead of four scattered 2-byte writes).
   f32x4 acc[2][NT];
-  float csum[NT], csq[NT];
+  f32x4 csum[NT], csq[NT];
 #pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    csum[j] = csq[j] = 0.f;
-    acc[0][j] = acc[1][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
+  for (int j = 0; j < NT; ++j) csum[j] = csq[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int frow = lane & 15, fk = lane >> 4;
   const int ccol = lane & 15, rgrp = lane >> 4;
   const bool plain = !a.out_scale && !a.out_shift && a.out_act == PB_ACT_NONE;
-  float osc[NT], osh[NT];
-  int osc_n0 = -1;
-#pragma unroll
-  for (int j = 0; j < NT; ++j) { osc[j] = 1.f; osh[j] = 0.f; }
   // fragment read offsets inside a stage (bytes): rows wave*32 + frow (+16) of A, rows j*16 + frow of W
   const int a_rd = (wave * 32 + frow) * 128;
   const int a_sw = ((wave * 32 + frow) >> 1) & 7;            // rows r and r+16 share the swizzle
   const int w_sw = (frow >> 1) & 7;                          // rows j*16 + frow: (j*8 + frow/2) & 7 = frow/2
 
   auto flush_stats = [&](int n0) {
+    lds_barrier();                                           // the staging tiles (aliased by sred) are idle
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      float s = csum[j], q = csq[j];
-      s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
-      q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
-      if (lane < 16) {
-        sred[(wave * BN + j * 16 + lane) * 2 + 0] = s;
-        sred[(wave * BN + j * 16 + lane) * 2 + 1] = q;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float s = csum[j][r], q = csq[j][r];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+          s += __shfl_xor(s, o, 64);
+          q += __shfl_xor(q, o, 64);
+        }
+        if (ccol == 0) {
+          sred[(wave * BN + j * 16 + rgrp * 4 + r) * 2 + 0] = s;
+          sred[(wave * BN + j * 16 + rgrp * 4 + r) * 2 + 1] = q;
+        }
       }
-      csum[j] = csq[j] = 0.f;
+      csum[j] = csq[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     lds_barrier();
     float* st = a.stats + (size_t)blockIdx.x * 2 * a.N;      // this workgroup's own slot (grid <= PB_STAT_SLOTS): plain read-modify-write
@@ -231,44 +256,58 @@ __global__ __launch_bounds__(256) void pw_gemm_dma_kernel(DmaArgs a) {
     lds_barrier();
   };
 
-  int t = next_valid((int)blockIdx.x);
-  if (t >= total) return;                            // uniform
+  Cur ct;
+  ct.t = (int)blockIdx.x;
+  {
+    const int u = ct.t >> 3;
+    ct.g = u / n_tiles;
+    ct.nt = u - ct.g * n_tiles;
+  }
+  if (ct.t < total && !cur_valid(ct)) cur_step(ct);
+  if (ct.t >= total) return;                         // uniform
   lds_barrier();                                     // ring zero-fill visible before the first DMA lands on it
-  // issue cursor: (ti, ksi) is the next stage to request; it runs NS-1 stages ahead of (t, ks)
-  int ti = t, ksi = 0, ahead = 0;
+  // issue cursor: (ci, ksi) is the next stage to request; it runs NS-1 stages ahead of the stage being multiplied
+  Cur ci = ct;
+  int ksi = 0, ahead = 0;
   auto advance_cursor = [&]() {
     if (++ksi == nk) {
       ksi = 0;
-      ti = next_valid(ti + gridDim.x);
-      if (ti < total) set_rows(ti);
+      cur_step(ci);
+      if (ci.t < total) set_rows(ci);
     }
   };
-  set_rows(ti);
+  set_rows(ci);
 #pragma unroll
   for (int s0 = 0; s0 < NS - 1; ++s0) {
-    if (ti < total) {
-      issue(ti, ksi, s0);
+    if (ci.t < total) {
+      issue(ksi, s0);
       advance_cursor();
       ++ahead;
     }
   }
-  int ks = 0, buf = 0;
-  while (t < total) {
-    // stage (t, ks) is the oldest of `ahead` requested stages: leave the younger ones in flight
+  int buf = 0;
+  // one K stage: wait for the oldest requested stage, request the next one, multiply
+  auto stage = [&](auto first_tag) {
+    constexpr bool FIRST = decltype(first_tag)::value;
+    // the oldest of `ahead` requested stages must have landed: the younger ones stay in flight.  (Stores count in vmcnt
+    // on gfx9 and may retire out of order with loads: right after an epilogue only vmcnt(0) is safe, which is what a
+    // 2-deep ring asks for anyway; deeper rings drain the stores at the end of the epilogue.)
     if (ahead >= 3) wait_vmcnt<2 * GPS>();
     else if (ahead == 2) wait_vmcnt<GPS>();
     else wait_vmcnt<0>();
+    if (!(a.dbg & 32))
     lds_barrier();       // everybody's part of the stage has landed; everybody is done reading the previous stage
-    if (ti < total) {
+    if (ci.t < total) {
       int nb = buf + NS - 1;
       if (nb >= NS) nb -= NS;
-      issue(ti, ksi, nb);
+      issue(ksi, nb);
       advance_cursor();
     } else {
       --ahead;
     }
     const unsigned char* As = ring + buf * STAGE;
     const unsigned char* Ws = As + A_STAGE;
+    if (!(a.dbg & 8))
 #pragma unroll
     for (int kk = 0; kk < KS; kk += MK) {
       const int ca = (((kk >> 3) + fk) ^ a_sw) << 4, cw = (((kk >> 3) + fk) ^ w_sw) << 4;
@@ -277,101 +316,95 @@ __global__ __launch_bounds__(256) void pw_gemm_dma_kernel(DmaArgs a) {
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const bf16x8 bw = *reinterpret_cast<const bf16x8*>(Ws + (j * 16 + frow) * 128 + cw);
-        acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bw, acc[0][j], 0, 0, 0);
-        acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bw, acc[1][j], 0, 0, 0);
+        if (FIRST && kk == 0) {
+          acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw, a0, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw, a1, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        } else {
+          acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw, a0, acc[0][j], 0, 0, 0);
+          acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw, a1, acc[1][j], 0, 0, 0);
+        }
       }
     }
     if (++buf == NS) buf = 0;
-    if (ks == nk - 1) {
-      // ---- epilogue: affine/bias + activation, per-column statistics, LDS-transposed store (the ring
-      // keeps filling underneath: epi/sred are not part of it)
-      int64_t m0, mend;
-      int grp;
-      panel(tile_mt(t), m0, mend, grp);
-      const int n0 = tile_nt(t) * BN;
-      T* epi = epi_base + wave * ER * EPI_LD;
-      if (!plain) {
-        if (n0 != osc_n0) {
-          osc_n0 = n0;
+  };
+
+  // ---- epilogue of one tile: affine/bias + activation, per-column statistics, LDS-transposed store (the ring keeps
+  // filling underneath: the staging tiles are not part of it)
+  auto epilogue = [&](auto plain_tag, auto stats_tag, int64_t m0, int64_t mend, int n0) {
+    constexpr bool PLAIN = decltype(plain_tag)::value, STATS = decltype(stats_tag)::value;
+    T* epi = epi_base + wave * 16 * EPI_LD;
 #pragma unroll
-          for (int j = 0; j < NT; ++j) {
-            const int n = n0 + j * 16 + ccol;
-            osc[j] = (a.out_scale && n < a.N) ? a.out_scale[n] : 1.f;
-            osh[j] = (a.out_shift && n < a.N) ? a.out_shift[n] : 0.f;
+    for (int i = 0; i < 2; ++i) {
+      const bool m_ok = m0 + wave * 32 + i * 16 + ccol < mend;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        f32x4 v = acc[i][j];
+        if constexpr (!PLAIN) {
+          const int n = n0 + j * 16 + rgrp * 4;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int nc = min(n + r, a.N - 1);              // (columns past N are never stored)
+            float x = v[r];
+            if (a.out_scale) x *= a.out_scale[nc];
+            if (a.out_shift) x += a.out_shift[nc];
+            v[r] = act_fwd(x, a.out_act, a.out_slope);
           }
         }
-#define PB_EPI_LOOP(EXPR)                                             \
-  _Pragma("unroll") for (int i = 0; i < 2; ++i)                       \
-  _Pragma("unroll") for (int j = 0; j < NT; ++j)                      \
-  _Pragma("unroll") for (int r = 0; r < 4; ++r) {                     \
-    const float x = acc[i][j][r] * osc[j] + osh[j];                   \
-    acc[i][j][r] = (EXPR);                                            \
-  }
-        switch (a.out_act) {
-          case PB_ACT_RELU: PB_EPI_LOOP(x > 0.f ? x : 0.f) break;
-          case PB_ACT_LEAKY_RELU: PB_EPI_LOOP(x > 0.f ? x : x * a.out_slope) break;
-          case PB_ACT_HSWISH: PB_EPI_LOOP(x * fminf(fmaxf(x + 3.f, 0.f), 6.f) * (1.f / 6.f)) break;
-          case PB_ACT_HSIGMOID: PB_EPI_LOOP(fminf(fmaxf(x * (1.f / 6.f) + 0.5f, 0.f), 1.f)) break;
-          case PB_ACT_SILU: PB_EPI_LOOP(x / (1.f + __expf(-x))) break;
-          default: PB_EPI_LOOP(x) break;
+        if constexpr (STATS) {
+          if (m_ok) {                                        // (fp32 values, before the bf16 rounding of the store)
+            csum[j] += v;
+            csq[j] += v * v;
+          }
         }
-#undef PB_EPI_LOOP
+        const bf16x4 o = __builtin_convertvector(v, bf16x4);
+        *reinterpret_cast<bf16x4*>(epi + ccol * EPI_LD + j * 16 + rgrp * 4) = o;
       }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // staging tiles are wave-private: no workgroup barrier
+      __builtin_amdgcn_wave_barrier();
+      {
+        const int row = lane >> 2;
+        const int64_t m = m0 + wave * 32 + i * 16 + row;
+        T* yrow = a.Y + m * a.N + n0;
+        const T* rrow = a.R ? a.R + m * a.N + n0 : nullptr;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+        for (int c = (lane & 3); c < 2 * NT; c += 4) {
+          if (m < mend && n0 + c * VEC < a.N && !(a.dbg & 4)) {
+            Vec16<T> v = vec_load<T>(epi + row * EPI_LD + c * VEC);
+            if (rrow) {                                      // residual connection (MobileViT: x + attn(x), x + ff(x))
+              const Vec16<T> rv = vec_load<T>(rrow + c * VEC);
 #pragma unroll
-        for (int h = 0; h < 16 / ER; ++h) {
-#pragma unroll
-          for (int j = 0; j < NT; ++j) {
-            const int n = n0 + j * 16 + ccol;
-            const bool nok = n < a.N;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int rl = rgrp * 4 + r;
-              if (ER == 16 || rl / ER == h) {
-                const int64_t m = m0 + wave * 32 + i * 16 + rl;
-                const T tv = from_f32<T>(acc[i][j][r]);
-                epi[(rl % ER) * EPI_LD + j * 16 + ccol] = tv;
-                if (a.stats && nok && m < mend) {
-                  const float fv = to_f32(tv);
-                  csum[j] += fv;
-                  csq[j] += fv * fv;
-                }
-              }
+              for (int e = 0; e < VEC; ++e) v.set(e, v.get(e) + rv.get(e));
             }
+            vec_store<T>(yrow + c * VEC, v);
           }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // epi tiles are wave-private: no workgroup barrier
-          __builtin_amdgcn_wave_barrier();
-          constexpr int CPR = BN / VEC;
-          for (int f = lane; f < ER * CPR; f += 64) {
-            const int r = f / CPR, c = f - r * CPR;
-            const int64_t m = m0 + wave * 32 + i * 16 + h * ER + r;
-            const int n = n0 + c * VEC;
-            if (m < mend && n < a.N) {
-              Vec16<T> v = vec_load<T>(epi + r * EPI_LD + c * VEC);
-              if (a.R) {                                   // residual connection (MobileViT: x + attn(x), x + ff(x))
-                const Vec16<T> rv = vec_load<T>(a.R + m * a.N + n);
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) v.set(e, v.get(e) + rv.get(e));
-              }
-              vec_store<T>(a.Y + m * a.N + n, v);
-            }
-          }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          __builtin_amdgcn_wave_barrier();
         }
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
-      ks = 0;
-      const int tn = next_valid(t + gridDim.x);
-      // several column tiles: the sums go out when the workgroup moves to another column tile (with 2 or 4 column
-      // tiles and a grid that is a multiple of 8 it never does: one flush per workgroup instead of one per tile)
-      if (a.stats && n_tiles > 1 && (tn >= total || tile_nt(tn) * BN != n0)) flush_stats(n0);
-      t = tn;
-    } else {
-      ++ks;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
     }
+  };
+
+  while (ct.t < total) {
+    stage(std::true_type{});
+    for (int ks = 1; ks < nk; ++ks) stage(std::false_type{});
+    int64_t m0, mend;
+    int grp;
+    panel(ct.g * 8 + r8, m0, mend, grp);
+    const int n0 = ct.nt * BN;
+    if (a.dbg & 16) {
+    } else if (plain) {
+      if (a.stats) epilogue(std::true_type{}, std::true_type{}, m0, mend, n0);
+      else epilogue(std::true_type{}, std::false_type{}, m0, mend, n0);
+    } else {
+      if (a.stats) epilogue(std::false_type{}, std::true_type{}, m0, mend, n0);
+      else epilogue(std::false_type{}, std::false_type{}, m0, mend, n0);
+    }
+    if (NS > 2) wait_vmcnt<0>();                     // see stage(): the stores must not be mistaken for landed stages
+    const int nt_done = ct.nt;
+    cur_step(ct);
+    // several column tiles: the sums go out when the workgroup moves to another column tile (never, when the grid is a
+    // multiple of 8*n_tiles: one flush per workgroup instead of one per tile)
+    if (a.stats && n_tiles > 1 && (ct.t >= total || ct.nt != nt_done)) flush_stats(n0);
   }
   if (a.stats && n_tiles == 1) flush_stats(0);
 }
@@ -435,17 +468,15 @@ __global__ __launch_bounds__(256) void pw_weight_prep_batch_kernel(const int64_t
 }
 
 // column-tile width: padded MFMA width + 16 per tile (every extra tile re-reads the X panel through L2).  Only
-// tiles of <= 96 columns leave LDS for two workgroups per CU, whose epilogues overlap each other's streaming:
-// measured on the whole step (tools/bench_ab.sh) that beats the 128/192-wide tiles with a deeper ring for every
-// K (11.34 -> 11.06 ms/step), so the wide instantiations are only reachable through PB_GEMM_DMA_NARROWK.
+// tiles of <= 112 columns leave LDS for two workgroups per CU with a 2-deep ring, whose epilogues overlap each other's
+// streaming: measured on the whole step (tools/bench_ab.sh) that beats the 128/192-wide tiles with a deeper ring.
 int pick_nt_dma(int N, int K) {
-  static const int narrow_k = getenv("PB_GEMM_DMA_NARROWK") ? atoi(getenv("PB_GEMM_DMA_NARROWK")) : 1 << 20;
-  static const int max_nt = getenv("PB_GEMM_DMA_MAXNT") ? atoi(getenv("PB_GEMM_DMA_MAXNT")) : 6;
-  const int cand[5] = {2, 4, 6, 8, 12};
+  (void)K;
+  static const int max_nt = getenv("PB_GEMM_DMA_MAXNT") ? atoi(getenv("PB_GEMM_DMA_MAXNT")) : 7;
   int best = 2;
   int64_t best_cost = INT64_MAX;
-  for (int c : cand) {
-    if (K <= narrow_k && c > max_nt) continue;
+  for (int c = 2; c <= 7; ++c) {
+    if (c > max_nt) continue;
     const int bn = c * 16;
     const int64_t tiles = pb_cdiv(N, bn);
     const int64_t cost = tiles * bn + 16 * tiles;
@@ -455,10 +486,9 @@ int pick_nt_dma(int N, int K) {
 }
 
 template <int NT, int NS, bool CONV = false>
-int launch_dma(const DmaArgs& a, int64_t total, int device, hipStream_t st) {
+int launch_dma(const DmaArgs& a_in, int64_t total, int device, hipStream_t st) {
   constexpr int BN = NT * 16;
-  constexpr int ER = (NT >= 8 && NS == 2) ? 8 : 16;
-  constexpr size_t lds = (size_t)NS * (BM * 128 + BN * 128) + 4 * ER * (BN + 8) * 2 + 4 * BN * 2 * 4;
+  constexpr size_t lds = (size_t)NS * (BM * 128 + ((NT + 1) / 2) * 4096) + 4 * 16 * (BN + 8) * 2;
   static int resident_dev[16] = {0};                 // per device: the attribute is per (function, device)
   int& resident = resident_dev[device & 15];
   if (resident == 0) {
@@ -471,10 +501,21 @@ int launch_dma(const DmaArgs& a, int64_t total, int device, hipStream_t st) {
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) cus = 256;
     resident = per_cu * cus;
   }
+  DmaArgs a = a_in;
+  static const int dbg = getenv("PB_GEMM_DMA_DBG") ? atoi(getenv("PB_GEMM_DMA_DBG")) : 0;
+  a.dbg = dbg;
   int64_t blocks = resident;
-  if (blocks > total) blocks = total;
-  blocks = pb_cdiv(blocks, 8) * 8;
   if (a.stats && blocks > PB_STAT_SLOTS) blocks = PB_STAT_SLOTS;   // one statistics slot per workgroup
+  if (blocks > total) blocks = total;
+  // a multiple of 8 (the kernel's tile cursor) and, when the chip is not left short of workgroups by it, of 8*n_tiles:
+  // every workgroup then keeps ONE column tile (one weight slice, one statistics flush)
+  const int64_t unit = 8 * (int64_t)a.n_tiles;
+  if (a.n_tiles > 1 && blocks >= 2 * unit) blocks = blocks / unit * unit;
+  else blocks = pb_cdiv(blocks, 8) * 8;
+  if (a.stats && blocks > PB_STAT_SLOTS) blocks = PB_STAT_SLOTS;   // (a multiple of 8)
+  const int64_t gq = blocks / 8;
+  a.step_g = (int)(gq / a.n_tiles);
+  a.step_nt = (int)(gq % a.n_tiles);
   hipLaunchKernelGGL((pw_gemm_dma_kernel<NT, NS, CONV>), dim3((unsigned)blocks), dim3(256), lds, st, a);
   return 0;
 }
@@ -507,6 +548,11 @@ extern "C" int pb_pw_weight_prep_batch(const int64_t* desc, int count, int devic
   return 0;
 }
 
+__attribute__((visibility("hidden"))) int pb_pw_stream_fwd(const void* x, const void* wb, void* y, int64_t M, int K, int N,
+                                                           const float* out_scale, const float* out_shift, pb_act out_act,
+                                                           float out_slope, float* stats, const void* residual, int device,
+                                                           hipStream_t st);
+
 extern "C" int pb_pwconv_fwd_bf16w(const void* x, const void* wb, void* y, int64_t M, int K, int N, int groups,
                                    int64_t rows_per_group, const float* out_scale, const float* out_shift,
                                    pb_act out_act, float out_slope, float* stats, const void* residual, int device,
@@ -519,6 +565,15 @@ extern "C" int pb_pwconv_fwd_bf16w(const void* x, const void* wb, void* y, int64
   PB_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)wb % 16) == 0, "pb_pwconv_fwd_bf16w: unaligned pointer");
   PB_ENTER(device);
   PB_CHECK_ARG(!residual || (((uintptr_t)residual % 16) == 0 && !stats), "pb_pwconv_fwd_bf16w: residual must be 16-byte aligned and excludes stats");
+  if (groups == 1) {
+    // short reductions: the weight-stationary streaming kernel (pw_stream.hip)
+    const int rc = pb_pw_stream_fwd(x, wb, y, M, K, N, out_scale, out_shift, out_act, out_slope, stats, residual, device, (hipStream_t)stream);
+    if (rc > 0) return rc;
+    if (rc == 0) {
+      PB_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   DmaArgs a = {};
   a.X = (const bf16_t*)x; a.WB = (const bf16_t*)wb; a.Y = (bf16_t*)y; a.M = M; a.K = K; a.N = N;
   a.R = (const bf16_t*)residual;
@@ -538,36 +593,14 @@ extern "C" int pb_pwconv_fwd_bf16w(const void* x, const void* wb, void* y, int64
   PB_CHECK_ARG(total <= 0x3fffffffLL, "pb_pwconv_fwd_bf16w: too many tiles");
   hipStream_t st = (hipStream_t)stream;
   int rc = 0;
-  // narrow tiles (BN <= 96): a 2-stage ring leaves room for two workgroups per CU, whose epilogues overlap each
-  // other's streaming (measured -7 % on the family); wide tiles need the LDS for a 3-stage ring of one workgroup
-  static const int ns2 = getenv("PB_GEMM_DMA_NS2") ? atoi(getenv("PB_GEMM_DMA_NS2")) : 1;
-  if (ns2 && nt <= 6) {
-    if (nt == 2) rc = launch_dma<2, 2>(a, total, device, st);
-    else if (nt == 4) rc = launch_dma<4, 2>(a, total, device, st);
-    else rc = launch_dma<6, 2>(a, total, device, st);
-    if (rc) return rc;
-    PB_LAUNCH_CHECK();
-    return 0;
-  }
-  static const int ns2w = getenv("PB_GEMM_DMA_NS2W") ? atoi(getenv("PB_GEMM_DMA_NS2W")) : 0;
-  if (ns2w == 1 && nt == 8) {
-    rc = launch_dma<8, 2>(a, total, device, st);
-    if (rc) return rc;
-    PB_LAUNCH_CHECK();
-    return 0;
-  }
-  if (ns2w == 4 && nt == 8) {
-    rc = launch_dma<8, 4>(a, total, device, st);
-    if (rc) return rc;
-    PB_LAUNCH_CHECK();
-    return 0;
-  }
+  // a 2-stage ring leaves room for two workgroups per CU, whose epilogues overlap each other's streaming
   switch (nt) {
-    case 2: rc = launch_dma<2, 4>(a, total, device, st); break;
-    case 4: rc = launch_dma<4, 4>(a, total, device, st); break;
-    case 6: rc = launch_dma<6, 3>(a, total, device, st); break;
-    case 8: rc = launch_dma<8, 3>(a, total, device, st); break;
-    default: rc = launch_dma<12, 3>(a, total, device, st); break;
+    case 2: rc = launch_dma<2, 2>(a, total, device, st); break;
+    case 3: rc = launch_dma<3, 2>(a, total, device, st); break;
+    case 4: rc = launch_dma<4, 2>(a, total, device, st); break;
+    case 5: rc = launch_dma<5, 2>(a, total, device, st); break;
+    case 6: rc = launch_dma<6, 2>(a, total, device, st); break;
+    default: rc = launch_dma<7, 2>(a, total, device, st); break;
   }
   if (rc) return rc;
   PB_LAUNCH_CHECK();
@@ -610,6 +643,7 @@ extern "C" int pb_conv3d_fwd_bf16w(const void* x, const void* wb, void* y, const
   a.zero = (const bf16_t*)zero16;
   // few row panels (small frames): narrower column tiles give the chip more workgroups
   int nt = pick_nt_dma(a.N, a.K);
+  if (nt & 1) nt = nt + 1 > 6 ? 6 : nt + 1;          // (the convolution instantiations: 2, 4, 6)
   static const int min_tiles = getenv("PB_CONV_MIN_TILES") ? atoi(getenv("PB_CONV_MIN_TILES")) : 1200;
   while (nt > 2 && (int64_t)a.m_tiles * pb_cdiv(a.N, nt * 16) < min_tiles) nt -= 2;
   a.n_tiles = (int)pb_cdiv(a.N, nt * 16);

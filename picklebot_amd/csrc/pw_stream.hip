@@ -1,0 +1,44 @@
+// Entry point and tile choice of the weight-stationary streaming GEMM (kernel: pw_stream_impl.h); the instantiations with
+// BatchNorm statistics are compiled in pw_stream_stats.hip.
+#include "pw_stream_impl.h"
+
+__attribute__((visibility("hidden"))) int pb_pw_stream_stats_launch(const void* args, int ks, int nt, int cg, int device, hipStream_t st);
+
+// -> 0 launched, > 0 error, -1 shape not taken (the caller falls back to the ring kernel)
+__attribute__((visibility("hidden"))) int pb_pw_stream_fwd(const void* x, const void* wb, void* y, int64_t M, int K, int N,
+                                                           const float* out_scale, const float* out_shift, pb_act out_act,
+                                                           float out_slope, float* stats, const void* residual, int device,
+                                                           hipStream_t st) {
+  static const int on = getenv("PB_GEMM_STREAM") ? atoi(getenv("PB_GEMM_STREAM")) : 1;
+  static const int force_cg = getenv("PB_GEMM_STREAM_CG") ? atoi(getenv("PB_GEMM_STREAM_CG")) : 0;
+  if (!on || K > 160 || K % 8 || N % 8 || M < 1024) return -1;
+  const int ks = (K + 31) / 32;
+  // (column tile, column groups per workgroup): the MFMA work is padded to tiles*BN columns and to wgc*CG tiles; the rows
+  // are fetched by LDS-DMA once per workgroup column; and a grid of 8*wgc*q workgroups should cover the 256 CUs
+  int best_nt = 0, best_cg = 0;
+  double best_cost = 1e30;
+  const int64_t groups = pb_cdiv(pb_cdiv(M, 128), 8);
+  for (int cg = 1; cg <= 8; cg *= 2) {
+    if (force_cg && cg != force_cg) continue;
+    for (int c = (cg == 1 ? 1 : 4); c <= kMaxNT[stats != nullptr][ks]; ++c) {
+      const int64_t tiles = pb_cdiv(N, c * 16);
+      const int64_t wgc = pb_cdiv(tiles, cg);
+      if (8 * wgc > 256) continue;
+      int64_t q = 256 / (8 * wgc);
+      if (q > groups) q = groups;
+      const double occupancy = (double)(8 * wgc * q) / 256.0;
+      const double mfma = (double)(wgc * cg * c * 16) / N;                  // padded MFMA columns per real column
+      const double dma = (double)wgc * K / (K + N);                           // row re-fetches relative to the traffic
+      const double fixed = cg == 1 ? 0.5 : 0.0;                               // per-stage overhead of the 16-row-per-wave layout
+      const double cost = (0.6 * mfma + 0.8 * dma + fixed + 1.0) / occupancy;
+      if (cost < best_cost) { best_cost = cost; best_nt = c; best_cg = cg; }
+    }
+  }
+  if (!best_nt) return -1;
+  StreamArgs a = {};
+  a.X = (const bf16_t*)x; a.WB = (const bf16_t*)wb; a.Y = (bf16_t*)y; a.R = (const bf16_t*)residual;
+  a.M = M; a.K = K; a.N = N;
+  a.out_scale = out_scale; a.out_shift = out_shift; a.out_act = (int)out_act; a.out_slope = out_slope; a.stats = stats;
+  a.n_tiles = (int)pb_cdiv(N, best_nt * 16);
+  return stats ? pb_pw_stream_stats_launch(&a, ks, best_nt, best_cg, device, st) : dispatch_ks<false>(a, ks, best_nt, best_cg, device, st);
+}

@@ -120,6 +120,42 @@ def test_pw_bwd_weight_training_paths(K, M, Kd, N, G, dtype):
         check("pw_bwd_weight_se", got, want, dtype)
 
 
+@pytest.mark.parametrize("M,Kd,N,G", [
+    (70000, 24, 72, 0), (7 * 9431, 72, 24, 7), (20000, 40, 120, 0), (20001, 40, 240, 0), (9000, 80, 184, 0), (9000, 80, 200, 0),
+    (5 * 1801, 80, 480, 5), (12000, 112, 672, 0), (6 * 2001, 672, 112, 6), (5000, 160, 960, 0), (4 * 1250, 960, 160, 4), (3000, 480, 112, 0),
+    (130, 200, 80, 0), (40000, 64, 16, 0), (129, 24, 48, 0), (70000, 16, 112, 0), (3 * 3528, 672, 160, 3), (8 * 131, 120, 40, 8)])
+def test_pw_fwd_dma_ring_gemm(K, M, Kd, N, G):
+    """The bf16 LDS-DMA ring GEMM on its own: every column-tile width (2..7 MFMA blocks), several column tiles per row
+    panel, persistent workgroups walking many tiles, ragged last panels, clip-aligned panels with per-clip weights,
+    statistics (one slot per workgroup, flushed once), affine + activation epilogue, residual.  Bit-identical reruns."""
+    bf = torch.bfloat16
+    x, w = rnd((M, Kd), bf, 41), rnd((N, Kd), seed=42, scale=Kd ** -0.5)
+    kw = {}
+    if G:
+        kw = dict(row_scale=torch.rand(G, Kd) + 0.5, rows_per_group=M // G)
+    dkw = {k: (dev(v) if torch.is_tensor(v) else v) for k, v in kw.items()}
+    st_ref = torch.zeros(R.REPL, 2, N)
+    want = R.pw_fwd(x, w, stats=st_ref, **kw)
+    st = torch.zeros(K.REPL, 2, N, device=DEV)
+    got = K.pw_fwd(dev(x), dev(w), stats=st, **dkw)
+    check("dma_stats_y", got, want, bf)
+    check("dma_stats", st.sum(0), st_ref.sum(0), bf)
+    st2 = torch.zeros(K.REPL, 2, N, device=DEV)
+    got2 = K.pw_fwd(dev(x), dev(w), stats=st2, **dkw)
+    assert torch.equal(got, got2) and torch.equal(st, st2)
+    plain = K.pw_fwd(dev(x), dev(w), **dkw)
+    assert torch.equal(plain, got)
+    ep = dict(out_scale=rnd((N,), seed=43) * 0.2 + 1, out_shift=rnd((N,), seed=44) * 0.1, out_act="hardswish")
+    check("dma_epilogue", K.pw_fwd(dev(x), dev(w), **dkw, **{k: (dev(v) if torch.is_tensor(v) else v) for k, v in ep.items()}),
+          R.pw_fwd(x, w, **kw, **ep), bf)
+    check("dma_bias", K.pw_fwd(dev(x), dev(w), out_shift=dev(ep["out_shift"])), R.pw_fwd(x, w, out_shift=ep["out_shift"]), bf)
+    if not G:
+        r = rnd((M, N), bf, 45)
+        check("dma_residual", K.pw_fwd(dev(x), dev(w), residual=dev(r)), R.pw_fwd(x, w, residual=r), bf)
+        dy = rnd((M, N), bf, 46)
+        check("dma_dgrad", K.pw_fwd(dev(dy), dev(w), w_transposed=True), R.pw_fwd(dy, w, w_transposed=True), bf)
+
+
 @pytest.mark.parametrize("M,Kd,N,trans", [(1024, 192, 144, False), (777, 144, 288, True), (96, 768, 192, False), (32, 128, 64, False)])
 def test_pw_fwd_residual(K, M, Kd, N, trans):
     """y = x W^T + r in the GEMM's store pass (MobileViT residual connections); also the copy fallback for M <= 64."""
