@@ -399,7 +399,6 @@ __global__ __launch_bounds__(256) void pw_gemm_dma_kernel(DmaArgs a) {
       if (a.stats) epilogue(std::false_type{}, std::true_type{}, m0, mend, n0);
       else epilogue(std::false_type{}, std::false_type{}, m0, mend, n0);
     }
-    if (NS > 2) wait_vmcnt<0>();                     // see stage(): the stores must not be mistaken for landed stages
     const int nt_done = ct.nt;
     cur_step(ct);
     // several column tiles: the sums go out when the workgroup moves to another column tile (never, when the grid is a
@@ -553,6 +552,11 @@ __attribute__((visibility("hidden"))) int pb_pw_stream_fwd(const void* x, const 
                                                            float out_slope, float* stats, const void* residual, int device,
                                                            hipStream_t st);
 
+__attribute__((visibility("hidden"))) int pb_pw_kloop_fwd(const void* x, const void* wb, void* y, int64_t M, int K, int N,
+                                                          int groups, int64_t rows_per_group, const float* out_scale,
+                                                          const float* out_shift, pb_act out_act, float out_slope, float* stats,
+                                                          const void* residual, int device, hipStream_t st);
+
 extern "C" int pb_pwconv_fwd_bf16w(const void* x, const void* wb, void* y, int64_t M, int K, int N, int groups,
                                    int64_t rows_per_group, const float* out_scale, const float* out_shift,
                                    pb_act out_act, float out_slope, float* stats, const void* residual, int device,
@@ -568,6 +572,16 @@ extern "C" int pb_pwconv_fwd_bf16w(const void* x, const void* wb, void* y, int64
   if (groups == 1) {
     // short reductions: the weight-stationary streaming kernel (pw_stream.hip)
     const int rc = pb_pw_stream_fwd(x, wb, y, M, K, N, out_scale, out_shift, out_act, out_slope, stats, residual, device, (hipStream_t)stream);
+    if (rc > 0) return rc;
+    if (rc == 0) {
+      PB_LAUNCH_CHECK();
+      return 0;
+    }
+  }
+  {
+    // long reductions and per-clip weights: X by register-ring loads, the weight slices through LDS (pw_kloop.hip)
+    const int rc = pb_pw_kloop_fwd(x, wb, y, M, K, N, groups, rows_per_group, out_scale, out_shift, out_act, out_slope, stats, residual,
+                                   device, (hipStream_t)stream);
     if (rc > 0) return rc;
     if (rc == 0) {
       PB_LAUNCH_CHECK();
@@ -593,6 +607,25 @@ extern "C" int pb_pwconv_fwd_bf16w(const void* x, const void* wb, void* y, int64
   PB_CHECK_ARG(total <= 0x3fffffffLL, "pb_pwconv_fwd_bf16w: too many tiles");
   hipStream_t st = (hipStream_t)stream;
   int rc = 0;
+  static const int ns_exp = getenv("PB_GEMM_DMA_NS") ? atoi(getenv("PB_GEMM_DMA_NS")) : 0;      // experiment: ring depth
+  if (ns_exp == 3 || ns_exp == 4) {
+    switch (nt * 10 + ns_exp) {
+      case 43: rc = launch_dma<4, 3>(a, total, device, st); break;
+      case 44: rc = launch_dma<4, 4>(a, total, device, st); break;
+      case 53: rc = launch_dma<5, 3>(a, total, device, st); break;
+      case 54: rc = launch_dma<5, 4>(a, total, device, st); break;
+      case 63: rc = launch_dma<6, 3>(a, total, device, st); break;
+      case 64: rc = launch_dma<6, 4>(a, total, device, st); break;
+      case 73: rc = launch_dma<7, 3>(a, total, device, st); break;
+      case 74: rc = launch_dma<7, 4>(a, total, device, st); break;
+      default: rc = -1; break;
+    }
+    if (rc > 0) return rc;
+    if (rc == 0) {
+      PB_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   // a 2-stage ring leaves room for two workgroups per CU, whose epilogues overlap each other's streaming
   switch (nt) {
     case 2: rc = launch_dma<2, 2>(a, total, device, st); break;

@@ -26,7 +26,8 @@ def timeit(fn, iters=8, warm=2):
         fn()
     ts = []
     for i in range(iters):
-        _FLUSH.fill_(i)
+        if not os.environ.get("PB_KB_NOFLUSH"):
+            _FLUSH.fill_(i)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); fn(); e1.record()
         torch.cuda.synchronize()
