@@ -41,7 +41,6 @@ struct DmaArgs {
   float* stats;
   int n_tiles;
   int m_tiles;
-  int dbg;                   // diagnosis only (PB_GEMM_DMA_DBG): 1 = no X DMA, 2 = no W DMA, 4 = no stores
   int step_g, step_nt;       // (grid / 8) divided by n_tiles: quotient and remainder (the kernel's tile cursor step)
   // implicit-GEMM convolution (CONV instantiations): X is [N,Ti,Hi,Wi,Cin], row m = output voxel, K = taps*Cin with
   // k = tap*Cin + c; a 16-byte chunk (8 channels) of a row comes from the voxel shifted by the tap, or from `zero`
@@ -193,12 +192,11 @@ __global__ __launch_bounds__(256) void pw_gemm_dma_kernel(DmaArgs a) {
         }
         glds16(src, A + i * 4096);
       } else {
-        if (k < a.K && !(a.dbg & 1)) glds16(a_src[i] + k0, A + i * 4096);
+        if (k < a.K) glds16(a_src[i] + k0, A + i * 4096);
       }
     }
 #pragma unroll
     for (int i = 0; i < WCH; ++i) {
-      if (a.dbg & 2) continue;
       if (k0 + w_cs[i] < a.K) glds16(w_src[i] + k0, W + i * 4096);
       else *reinterpret_cast<u32x4*>(ring + buf * STAGE + A_STAGE + (i * 256 + tid) * 16) = u32x4{0u, 0u, 0u, 0u};
     }
@@ -295,7 +293,6 @@ __global__ __launch_bounds__(256) void pw_gemm_dma_kernel(DmaArgs a) {
     if (ahead >= 3) wait_vmcnt<2 * GPS>();
     else if (ahead == 2) wait_vmcnt<GPS>();
     else wait_vmcnt<0>();
-    if (!(a.dbg & 32))
     lds_barrier();       // everybody's part of the stage has landed; everybody is done reading the previous stage
     if (ci.t < total) {
       int nb = buf + NS - 1;
@@ -307,7 +304,6 @@ __global__ __launch_bounds__(256) void pw_gemm_dma_kernel(DmaArgs a) {
     }
     const unsigned char* As = ring + buf * STAGE;
     const unsigned char* Ws = As + A_STAGE;
-    if (!(a.dbg & 8))
 #pragma unroll
     for (int kk = 0; kk < KS; kk += MK) {
       const int ca = (((kk >> 3) + fk) ^ a_sw) << 4, cw = (((kk >> 3) + fk) ^ w_sw) << 4;
@@ -368,7 +364,7 @@ __global__ __launch_bounds__(256) void pw_gemm_dma_kernel(DmaArgs a) {
         const T* rrow = a.R ? a.R + m * a.N + n0 : nullptr;
 #pragma unroll
         for (int c = (lane & 3); c < 2 * NT; c += 4) {
-          if (m < mend && n0 + c * VEC < a.N && !(a.dbg & 4)) {
+          if (m < mend && n0 + c * VEC < a.N) {
             Vec16<T> v = vec_load<T>(epi + row * EPI_LD + c * VEC);
             if (rrow) {                                      // residual connection (MobileViT: x + attn(x), x + ff(x))
               const Vec16<T> rv = vec_load<T>(rrow + c * VEC);
@@ -391,8 +387,7 @@ __global__ __launch_bounds__(256) void pw_gemm_dma_kernel(DmaArgs a) {
     int grp;
     panel(ct.g * 8 + r8, m0, mend, grp);
     const int n0 = ct.nt * BN;
-    if (a.dbg & 16) {
-    } else if (plain) {
+    if (plain) {
       if (a.stats) epilogue(std::true_type{}, std::true_type{}, m0, mend, n0);
       else epilogue(std::true_type{}, std::false_type{}, m0, mend, n0);
     } else {
@@ -501,8 +496,6 @@ int launch_dma(const DmaArgs& a_in, int64_t total, int device, hipStream_t st) {
     resident = per_cu * cus;
   }
   DmaArgs a = a_in;
-  static const int dbg = getenv("PB_GEMM_DMA_DBG") ? atoi(getenv("PB_GEMM_DMA_DBG")) : 0;
-  a.dbg = dbg;
   int64_t blocks = resident;
   if (a.stats && blocks > PB_STAT_SLOTS) blocks = PB_STAT_SLOTS;   // one statistics slot per workgroup
   if (blocks > total) blocks = total;
@@ -552,11 +545,6 @@ __attribute__((visibility("hidden"))) int pb_pw_stream_fwd(const void* x, const 
                                                            float out_slope, float* stats, const void* residual, int device,
                                                            hipStream_t st);
 
-__attribute__((visibility("hidden"))) int pb_pw_kloop_fwd(const void* x, const void* wb, void* y, int64_t M, int K, int N,
-                                                          int groups, int64_t rows_per_group, const float* out_scale,
-                                                          const float* out_shift, pb_act out_act, float out_slope, float* stats,
-                                                          const void* residual, int device, hipStream_t st);
-
 extern "C" int pb_pwconv_fwd_bf16w(const void* x, const void* wb, void* y, int64_t M, int K, int N, int groups,
                                    int64_t rows_per_group, const float* out_scale, const float* out_shift,
                                    pb_act out_act, float out_slope, float* stats, const void* residual, int device,
@@ -572,16 +560,6 @@ extern "C" int pb_pwconv_fwd_bf16w(const void* x, const void* wb, void* y, int64
   if (groups == 1) {
     // short reductions: the weight-stationary streaming kernel (pw_stream.hip)
     const int rc = pb_pw_stream_fwd(x, wb, y, M, K, N, out_scale, out_shift, out_act, out_slope, stats, residual, device, (hipStream_t)stream);
-    if (rc > 0) return rc;
-    if (rc == 0) {
-      PB_LAUNCH_CHECK();
-      return 0;
-    }
-  }
-  {
-    // long reductions and per-clip weights: X by register-ring loads, the weight slices through LDS (pw_kloop.hip)
-    const int rc = pb_pw_kloop_fwd(x, wb, y, M, K, N, groups, rows_per_group, out_scale, out_shift, out_act, out_slope, stats, residual,
-                                   device, (hipStream_t)stream);
     if (rc > 0) return rc;
     if (rc == 0) {
       PB_LAUNCH_CHECK();
@@ -607,25 +585,6 @@ extern "C" int pb_pwconv_fwd_bf16w(const void* x, const void* wb, void* y, int64
   PB_CHECK_ARG(total <= 0x3fffffffLL, "pb_pwconv_fwd_bf16w: too many tiles");
   hipStream_t st = (hipStream_t)stream;
   int rc = 0;
-  static const int ns_exp = getenv("PB_GEMM_DMA_NS") ? atoi(getenv("PB_GEMM_DMA_NS")) : 0;      // experiment: ring depth
-  if (ns_exp == 3 || ns_exp == 4) {
-    switch (nt * 10 + ns_exp) {
-      case 43: rc = launch_dma<4, 3>(a, total, device, st); break;
-      case 44: rc = launch_dma<4, 4>(a, total, device, st); break;
-      case 53: rc = launch_dma<5, 3>(a, total, device, st); break;
-      case 54: rc = launch_dma<5, 4>(a, total, device, st); break;
-      case 63: rc = launch_dma<6, 3>(a, total, device, st); break;
-      case 64: rc = launch_dma<6, 4>(a, total, device, st); break;
-      case 73: rc = launch_dma<7, 3>(a, total, device, st); break;
-      case 74: rc = launch_dma<7, 4>(a, total, device, st); break;
-      default: rc = -1; break;
-    }
-    if (rc > 0) return rc;
-    if (rc == 0) {
-      PB_LAUNCH_CHECK();
-      return 0;
-    }
-  }
   // a 2-stage ring leaves room for two workgroups per CU, whose epilogues overlap each other's streaming
   switch (nt) {
     case 2: rc = launch_dma<2, 2>(a, total, device, st); break;

@@ -43,7 +43,6 @@ struct StreamArgs {
   int n_tiles, m_tiles;      // column tiles of BN, row panels of SBM
   int wgc;                   // workgroup columns = ceil(n_tiles / CG)
   int q;                     // grid = 8 * wgc * q: a workgroup's row panels are (g0 + i*q)*8 + (blockIdx & 7)
-  int dbg;                   // diagnosis only (PB_GEMM_DMA_DBG): 1 = no X DMA, 4 = no stores, 8 = one k-step only
 };
 
 __device__ __forceinline__ void glds16s(const void* gsrc, unsigned char* lds_dst) {
@@ -147,7 +146,7 @@ __global__ __launch_bounds__(STHREADS) void pw_stream_kernel(StreamArgs a) {
   }
 
   auto issue = [&](int i, int buf) {                 // panel i of this workgroup (or nothing: dummies keep vmcnt uniform)
-    const bool real = i < n_my && !(a.dbg & 1);
+    const bool real = i < n_my;
     unsigned char* dst = smem + buf * stage_bytes + wave * 1024;
     const int64_t m0 = (int64_t)((g0 + i * a.q) * 8 + r8) * SBM;
     const bool last = real && m0 + SBM > a.M;
@@ -185,7 +184,7 @@ __global__ __launch_bounds__(STHREADS) void pw_stream_kernel(StreamArgs a) {
 #pragma unroll
   for (int p = 0; p < NP; ++p) n_st += n0 + p * 32 < a.N;
   if (NT & 1) n_st += n0 + (NT - 1) * 16 < a.N;
-  n_st = (a.R || !active || (a.dbg & 4)) ? 0 : n_st * RB;   // (residual loads are waited for with vmcnt(0) by the compiler)
+  n_st = (a.R || !active) ? 0 : n_st * RB;   // (residual loads are waited for with vmcnt(0) by the compiler)
   int allow = (NS - 2) * DPS + (NS - 2) * n_st;
   allow = allow > 63 ? 63 : allow;
 
@@ -202,12 +201,10 @@ __global__ __launch_bounds__(STHREADS) void pw_stream_kernel(StreamArgs a) {
     f32x4 acc[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][0], af[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-    if (!(a.dbg & 8)) {
 #pragma unroll
-      for (int ks = 1; ks < KS; ++ks)
+    for (int ks = 1; ks < KS; ++ks)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][ks], af[ks], acc[j], 0, 0, 0);
-    }
+      for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][ks], af[ks], acc[j], 0, 0, 0);
     // lane (frow, fk) holds columns n0 + j*16 + fk*4 + (0..3) of row m
     const bool m_ok = m < a.M;
     if constexpr (!PLAIN) {
@@ -241,7 +238,7 @@ __global__ __launch_bounds__(STHREADS) void pw_stream_kernel(StreamArgs a) {
       const bf16x4 o = __builtin_convertvector(acc[j], bf16x4);
       pk[j] = __builtin_bit_cast(u32x2, o);
     }
-    const bool st_ok = m_ok && !(a.dbg & 4);
+    const bool st_ok = m_ok;
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
       // rows of 16 lanes, (D, S) = (block 2p, block 2p+1);  swap: D <- [D0 S0 D2 S2], S <- [D1 S1 D3 S3]
@@ -396,8 +393,6 @@ int launch_stream(StreamArgs a, int device, hipStream_t st) {
   if (q > groups) q = groups;
   if (q < 1) q = 1;
   a.q = q;
-  static const int dbg = getenv("PB_GEMM_DMA_DBG") ? atoi(getenv("PB_GEMM_DMA_DBG")) : 0;
-  a.dbg = dbg;
   hipLaunchKernelGGL((pw_stream_kernel<NT, KS, CG, RB, STATS>), dim3((unsigned)(unit * q)), dim3(STHREADS), lds, st, a);
   return 0;
 }
