@@ -219,19 +219,17 @@ def _keep_job(job, *tensors):
 
 # ------------------------------------------------------------------------------ pointwise conv
 _GEMM_DMA = os.environ.get("PB_GEMM_DMA", "1") != "0"
-_GEMM_DMA_ALL = os.environ.get("PB_GEMM_DMA_ALL", "0") != "0"
+_GEMM_DMA_ALL = os.environ.get("PB_GEMM_DMA_ALL", "1") != "0"
 _K16_FOLD = os.environ.get("PB_K16_FOLD", "1") != "0"
 
 
 def _dma_gemm_pays(M, K, N):
-    """Measured per layer on MI355X (MobileNetLarge3D, batch 32; tools/bench_ab.sh): the LDS-DMA ring GEMM wins
-    everywhere (1.1-2.3x) except on the K = 16 layers of the first stage, where a K stage is a quarter full and
-    the register-staged kernel's three workgroups per CU stream 4M rows at 3-3.4 TB/s."""
+    """bf16 GEMMs of more than a few rows go to pb_pwconv_fwd_bf16w: the weight-stationary streaming kernel (K <= 160,
+    pw_stream) or the LDS-DMA ring kernel.  (Round 1 kept the K = 16 layers on the register-staged kernel, 3.0-3.4 TB/s on
+    the 4M-row tensors; the streaming kernel measured 4.2 TB/s there.)  PB_GEMM_DMA_ALL=0 restores that split."""
     if M <= 64:
         return False
-    if _GEMM_DMA_ALL:
-        return True
-    return K >= 24
+    return _GEMM_DMA_ALL or K >= 24
 
 
 # bf16 weight copies live for one "weight scope" = one top-level module forward and its backward.  Version
