@@ -21,6 +21,13 @@ template <> struct Pair<float> {
   static __device__ __forceinline__ f32x2 down(f32x2 v) { return v; }
 };
 
+// acc += x * w on a pair of channels, as ONE instruction whose place in the instruction stream is kept: hipcc's scheduler
+// lines the FMAs of an accumulator up one behind the other, and every dependent v_pk_fma_f32 then costs an s_nop (as
+// many wait states as FMAs in the depthwise kernels' ISA).  Issued round-robin over several accumulators - the order the
+// kernels write them in - no two neighbours depend on each other.
+__device__ __forceinline__ void pk_fma_keep(f32x2& acc, const f32x2& x, const f32x2& w) {
+  asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(x), "v"(w));
+}
 
 #define PB_HIDDEN __attribute__((visibility("hidden")))
 

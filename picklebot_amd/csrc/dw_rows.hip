@@ -127,18 +127,24 @@ __global__ __launch_bounds__(256) void dw_rows_fwd_kernel(RowsArgs a) {
           for (int s = 0; s < S; ++s) load_row(hs_base + (t + 1) * S + K - S + s, raw[s]);
         }
         raw_t* orow = dst + (int64_t)t * a.Wd * ps;
+        // taps outside, the WSEG outputs inside: consecutive FMAs belong to different accumulators (a chain of dependent
+        // v_pk_fma_f32 costs an s_nop per link - as many wait states as FMAs in the ISA of the output-major order)
+        f32x2 acc[WSEG];
+#pragma unroll
+        for (int j = 0; j < WSEG; ++j) acc[j] = f32x2{0.f, 0.f};
+#pragma unroll
+        for (int kh = 0; kh < K; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < K; ++kw) {
+            const int tap = FLIP ? (K - 1 - kh) * K + (K - 1 - kw) : kh * K + kw;
+            const f32x2 w2 = f32x2{wt[tap], wt[K * K + tap]};
+#pragma unroll
+            for (int j = 0; j < WSEG; ++j) pk_fma_keep(acc[j], win[(r * S + kh) % K][j * S + kw], w2);
+          }
 #pragma unroll
         for (int j = 0; j < WSEG; ++j) {
-          f32x2 acc = {0.f, 0.f};
-#pragma unroll
-          for (int kh = 0; kh < K; ++kh)
-#pragma unroll
-            for (int kw = 0; kw < K; ++kw) {
-              const int tap = FLIP ? (K - 1 - kh) * K + (K - 1 - kw) : kh * K + kw;
-              acc += win[(r * S + kh) % K][j * S + kw] * f32x2{wt[tap], wt[K * K + tap]};
-            }
           if (w0 + j < a.Wd) {
-            const raw_t o = Pair<T>::down(acc);
+            const raw_t o = Pair<T>::down(acc[j]);
             orow[(int64_t)j * ps] = o;
             if (a.pool) psum += Pair<T>::up(o);
           }
