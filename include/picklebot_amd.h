@@ -34,7 +34,7 @@ typedef enum {
   PB_ACT_HSIGMOID = 4, PB_ACT_SILU = 5
 } pb_act;
 
-#define PB_ABI_VERSION 13
+#define PB_ABI_VERSION 14
 
 /* Determinism.  Nothing in this library accumulates with floating-point atomics: two runs of the same binary on the
  * same inputs give bit-identical outputs and gradients.  Every reduction that spans workgroups stores one partial
@@ -106,6 +106,10 @@ int pb_pw_weight_prep_batch(const int64_t* desc, int count, int device, void* st
 int pb_pwconv_fwd_bf16w(const void* x, const void* wb, void* y, int64_t M, int K, int N, int groups,
                         int64_t rows_per_group, const float* out_scale, const float* out_shift, pb_act out_act,
                         float out_slope, float* stats, const void* residual, int device, void* stream);
+/* Which kernel pb_pwconv_fwd_bf16w runs for a shape: 1 = the weight-stationary streaming kernel (pw_stream_kernel: one
+ * weight matrix, K <= 160), 2 = its long-reduction form (pw_stream_wide_kernel: the output columns spread over the waves),
+ * 0 = the LDS-DMA ring kernel (pw_gemm_dma_kernel).  For profilers' labels; no device work. */
+int pb_pwconv_fwd_bf16w_path(int64_t M, int K, int N, int groups, int64_t rows_per_group, int has_stats);
 
 /* Weight gradient  dW[N,K] += sum_m dY[m,n] * P(X)[m,k]   (same prologue P as above).
  * Replaces the weight half of Conv3d/Linear backward for the sites listed above.

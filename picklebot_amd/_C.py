@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libpicklebot_amd.so")
 
 PB_F32, PB_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY_RELU, ACT_HSWISH, ACT_HSIGMOID, ACT_SILU = range(6)
-ABI_VERSION = 13
+ABI_VERSION = 14
 STAT_SLOTS = 512
 
 
@@ -103,6 +103,7 @@ SIZE_SIGNATURES = {
 COUNT_SIGNATURES = {
     "pb_dwconv3d_pool_slots": [POINTER(DwShape), I],
     "pb_rowgroup_slots": [L, L, I, I],
+    "pb_pwconv_fwd_bf16w_path": [L, I, I, I, L, I],
 }
 
 

@@ -545,6 +545,11 @@ __attribute__((visibility("hidden"))) int pb_pw_stream_fwd(const void* x, const 
                                                            float out_slope, float* stats, const void* residual, int device,
                                                            hipStream_t st);
 
+__attribute__((visibility("hidden"))) int pb_pw_stream_wide_fwd(const void* x, const void* wb, void* y, int64_t M, int K, int N,
+                                                                int groups, int64_t rows_per_group, const float* out_scale,
+                                                                const float* out_shift, pb_act out_act, float out_slope,
+                                                                float* stats, const void* residual, int device, hipStream_t st);
+
 extern "C" int pb_pwconv_fwd_bf16w(const void* x, const void* wb, void* y, int64_t M, int K, int N, int groups,
                                    int64_t rows_per_group, const float* out_scale, const float* out_shift,
                                    pb_act out_act, float out_slope, float* stats, const void* residual, int device,
@@ -560,6 +565,16 @@ extern "C" int pb_pwconv_fwd_bf16w(const void* x, const void* wb, void* y, int64
   if (groups == 1) {
     // short reductions: the weight-stationary streaming kernel (pw_stream.hip)
     const int rc = pb_pw_stream_fwd(x, wb, y, M, K, N, out_scale, out_shift, out_act, out_slope, stats, residual, device, (hipStream_t)stream);
+    if (rc > 0) return rc;
+    if (rc == 0) {
+      PB_LAUNCH_CHECK();
+      return 0;
+    }
+  }
+  {
+    // long reductions (also with per-clip weights): the columns-over-waves form of the streaming kernel (pw_stream_wide.hip)
+    const int rc = pb_pw_stream_wide_fwd(x, wb, y, M, K, N, groups, rows_per_group, out_scale, out_shift, out_act, out_slope, stats,
+                                         residual, device, (hipStream_t)stream);
     if (rc > 0) return rc;
     if (rc == 0) {
       PB_LAUNCH_CHECK();

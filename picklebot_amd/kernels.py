@@ -371,7 +371,7 @@ def pw_fwd(x, w, *, w_transposed=False, in_scale=None, in_shift=None, in_act="no
         # of the rows (4x the MFMA work, on zeros - the kernel is HBM-bound): 3.2 -> 4.6 TB/s on the 4M-row tensors when
         # the folded output stays one column tile (N = 16); wider outputs (N = 64 -> 256 columns) measured slower
         wb4 = _prepped_weight(w, w_transposed, fold4=True)
-        _launch("pw_gemm_dma_kernel", _nb(x, y) + 4 * N * 64 * 2, "pb_pwconv_fwd_bf16w", _p(x), _p(wb4), _p(y), M // 4, 64, 4 * N, 1,
+        _launch(_bf16w_family(M // 4, 64, 4 * N, 1, False), _nb(x, y) + 4 * N * 64 * 2, "pb_pwconv_fwd_bf16w", _p(x), _p(wb4), _p(y), M // 4, 64, 4 * N, 1,
                 0, None, None, ACT[out_act], float(out_slope), None, None, dev, st, detail=f"M{M} K{K} N{N} (4-row fold)")
         return y
     if (_GEMM_DMA and x.dtype == torch.bfloat16 and _dma_gemm_pays(M, K, N) and K % 8 == 0 and N % 8 == 0
@@ -390,7 +390,7 @@ def pw_fwd(x, w, *, w_transposed=False, in_scale=None, in_shift=None, in_act="no
                 _launch("pw_weight_prep_kernel", _nb(w, row_scale, wbs), "pb_pw_weight_prep", _p(w), N, K, 0, _p(row_scale), groups,
                         _p(wbs), dev, st)
             wb = wbs
-        _launch("pw_gemm_dma_kernel", _nb(x, y) + N * K * 2, "pb_pwconv_fwd_bf16w", _p(x), _p(wb), _p(y), M, K, N, groups,
+        _launch(_bf16w_family(M, K, N, groups, stats is not None), _nb(x, y) + N * K * 2, "pb_pwconv_fwd_bf16w", _p(x), _p(wb), _p(y), M, K, N, groups,
                 int(rows_per_group) if groups > 1 else 0, _p(out_scale), _p(out_shift), ACT[out_act], float(out_slope),
                 _p(stats), _p(residual), dev, st, detail=f"M{M} K{K} N{N}")
         return y
@@ -412,6 +412,17 @@ def pw_fwd(x, w, *, w_transposed=False, in_scale=None, in_shift=None, in_act="no
 
 
 _ws_bytes = {}
+_family_memo = {}
+
+
+def _bf16w_family(M, K, N, groups, has_stats):
+    """The kernel pb_pwconv_fwd_bf16w runs for this shape (the profile labels follow the library's own dispatch)."""
+    key = (M, K, N, groups, has_stats)
+    fam = _family_memo.get(key)
+    if fam is None:
+        path = _C.load().pb_pwconv_fwd_bf16w_path(M, K, N, groups, M // max(groups, 1), int(has_stats))
+        fam = _family_memo[key] = ("pw_gemm_dma_kernel", "pw_stream_kernel", "pw_stream_wide_kernel")[path]
+    return fam
 
 
 def pw_bwd_weight(dy, x, dw, *, in_scale=None, in_shift=None, in_act="none", in_slope=0.0, row_scale=None,
