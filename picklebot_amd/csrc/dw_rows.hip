@@ -163,6 +163,8 @@ struct RowsWgArgs {
   const float* g_shift;
   int N, C, Tsrc, Hs, Ws, Tdst, Hd, Wd, t_mul, t_off;
   int nseg, nbands, band_rows, CP, FG;     // FG frame groups: a thread walks the frames z = fg, fg + FG, ...
+  int tap_stride, tap_off;                 // a channel's k*k taps sit at [c*tap_stride + tap_off, +k*k) of a partial: a (kt,k,k)
+                                           // filter is kt launches of this kernel, one per temporal tap plane (tap_off = dt*k*k)
 };
 
 // Weight gradient with the same thread layout: the k*k taps of the thread's two channels accumulate in
@@ -291,8 +293,11 @@ __global__ __launch_bounds__(256) void dw_rows_wgrad_kernel(RowsWgArgs a) {
       }
       __syncthreads();
     }
-    float* part = a.dw + (int64_t)blockIdx.x * nall;
-    for (int i = threadIdx.x; i < nall; i += 256) part[i] = ra[i];
+    float* part = a.dw + (int64_t)blockIdx.x * 2 * a.CP * a.tap_stride + a.tap_off;
+    for (int i = threadIdx.x; i < nall; i += 256) {
+      const int c = i / KK;
+      part[(int64_t)c * a.tap_stride + (i - c * KK)] = ra[i];
+    }
     return;
   }
   // wave-private transposition: lane l holds the 2*KK consecutive floats [c0*KK, (c0+2)*KK) of its unit's partial
@@ -315,7 +320,8 @@ __global__ __launch_bounds__(256) void dw_rows_wgrad_kernel(RowsWgArgs a) {
       const int u2 = (int)(g2 - (int64_t)fb2 * per_frame);
       const int sg2 = u2 / a.CP, cp2 = u2 - sg2 * a.CP;
       // slot (frame group, band, segment) has exactly one unit per channel pair: plain stores, every element written
-      a.dw[((int64_t)fb2 * a.nseg + sg2) * nall + (int64_t)cp2 * 2 * KK + off] = rw[e];
+      const int ch2 = off >= KK;                            // which of the pair's two channels
+      a.dw[(((int64_t)fb2 * a.nseg + sg2) * 2 * a.CP + cp2 * 2 + ch2) * a.tap_stride + a.tap_off + (off - ch2 * KK)] = rw[e];
     }
   }
 }
@@ -433,7 +439,18 @@ int launch_rows_wgrad(RowsWgArgs a, hipStream_t st, int64_t* slots) {
 
 }  // namespace
 
+// (kt,k,k) filters with temporal stride 1 (MoViNet's depthwise convs, movinet.py:53): the weight gradient of tap plane dt
+// is the (1,k,k) weight gradient of dy against x shifted by dt - pt frames - kt launches of the kernel above (the generic
+// kernel these layers used ran at 0.09 TB/s: a third of a MoViNet-A2 training step)
+bool rows_wgrad_planes_ok(const pb_dwconv_shape* s) {
+  if (s->kt <= 1 || s->kt > 7 || s->st != 1) return false;
+  pb_dwconv_shape p = *s;
+  p.kt = 1;
+  return rows_ok(&p);
+}
+
 bool pb_dw_rows_eligible(const pb_dwconv_shape* s, bool wgrad) {
+  if (wgrad && rows_wgrad_planes_ok(s)) return true;
   // weight gradient, measured per layer on MI355X (MobileNetLarge3D, batch 32): this kernel wins on the wide layers
   // (C >= 480: 1.3-1.7x over the tile kernel) and on frames of 28x28 outputs or more (1.4-2.1x); the tile kernel
   // keeps the narrow 14x14 layers, the strip kernel the 64-channel 112-wide input
@@ -462,18 +479,24 @@ int pb_dw_rows_wgrad(const void* dy, const void* x, float* part, const pb_dwconv
   RowsWgArgs a = {};
   a.x = x; a.dy = dy; a.dw = part; a.g_scale = g_scale; a.g_shift = g_shift;
   a.N = s->N; a.C = s->C; a.Tsrc = s->Ti; a.Hs = s->Hi; a.Ws = s->Wi; a.Tdst = s->To; a.Hd = s->Ho; a.Wd = s->Wo;
-  a.t_mul = s->st; a.t_off = -s->pt;
+  a.t_mul = s->st;
   const int K = s->kh, S = s->sh;
-#define PB_ROWSW(TT)                                                                 \
-  do {                                                                               \
-    if (K == 3 && S == 1) return launch_rows_wgrad<TT, 3, 1>(a, st, slots);          \
-    if (K == 3 && S == 2) return launch_rows_wgrad<TT, 3, 2>(a, st, slots);          \
-    if (K == 5 && S == 1) return launch_rows_wgrad<TT, 5, 1>(a, st, slots);          \
-    return launch_rows_wgrad<TT, 5, 2>(a, st, slots);                                \
-  } while (0)
-  if (dtype == PB_BF16) PB_ROWSW(bf16_t);
-  PB_ROWSW(float);
+  a.tap_stride = s->kt * K * K;
+  // one launch per temporal tap plane: output frame t pairs with input frame t*st + dt - pt (frames outside the clip are zero)
+  for (int dt = 0; dt < s->kt; ++dt) {
+    a.t_off = dt - s->pt;
+    a.tap_off = dt * K * K;
+    int rc;
+#define PB_ROWSW(TT)                                                                  \
+  (K == 3 && S == 1 ? launch_rows_wgrad<TT, 3, 1>(a, st, slots)                        \
+   : K == 3 && S == 2 ? launch_rows_wgrad<TT, 3, 2>(a, st, slots)                      \
+   : K == 5 && S == 1 ? launch_rows_wgrad<TT, 5, 1>(a, st, slots) : launch_rows_wgrad<TT, 5, 2>(a, st, slots))
+    if (dtype == PB_BF16) rc = PB_ROWSW(bf16_t);
+    else rc = PB_ROWSW(float);
 #undef PB_ROWSW
+    if (rc) return rc;
+  }
+  return 0;
 }
 
 int pb_dw_rows_pool_slots(const pb_dwconv_shape* s) {
