@@ -136,17 +136,23 @@ __device__ __forceinline__ void slot_sum_to_lds(const float* part, int slots, in
   for (int c = threadIdx.x; c < C; c += nthreads) {
     const float* p = part + (int64_t)g * C + c;
     const int64_t st = (int64_t)G * C;
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    int sl = 0;
-    for (; sl + 8 <= slots; sl += 8) {
-      float v[8];
+    // 16 loads in flight per round, the tail predicated (a dynamic tail loop was one memory round trip per slot); the
+    // association - sixteen interleaved chains, combined pairwise - is fixed
+    float acc[16];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = p[(sl + u) * st];
+    for (int u = 0; u < 16; ++u) acc[u] = 0.f;
+    for (int sl = 0; sl < slots; sl += 16) {
+      float v[16];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) acc[u] += v[u];
+      for (int u = 0; u < 16; ++u) v[u] = sl + u < slots ? p[(sl + u) * st] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) acc[u] += v[u];
     }
-    for (; sl < slots; ++sl) acc[0] += p[sl * st];
-    dst[c] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+#pragma unroll
+    for (int w = 8; w >= 1; w >>= 1)
+#pragma unroll
+      for (int u = 0; u < w; ++u) acc[u] += acc[u + w];
+    dst[c] = acc[0];
   }
 }
 
@@ -164,11 +170,20 @@ __global__ __launch_bounds__(SE_HT) void se_hidden_kernel(SeFwdArgs a) {
     for (int c = threadIdx.x; c < C; c += SE_HT) a.pool[(int64_t)g * C + c] = sm[c];
   const int j0 = blockIdx.x * SE_JB + wave * 4;
   float s[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int c = lane; c < C; c += 64) {
-    const float p = sm[c];
+  // four column steps per round: 16 weight loads in flight per lane (one step per round was ~11 dependent round trips)
+  for (int cb = 0; cb < C; cb += 256) {
+    float wv[4][4], pv[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      if (j0 + q < a.Cm) s[q] += a.w1[(int64_t)(j0 + q) * C + c] * p;
+    for (int u = 0; u < 4; ++u) {
+      const int c = cb + u * 64 + lane;
+      pv[u] = c < C ? sm[c] : 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) wv[u][q] = (c < C && j0 + q < a.Cm) ? a.w1[(int64_t)(j0 + q) * C + c] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) s[q] += wv[u][q] * pv[u];
   }
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -188,22 +203,26 @@ __global__ __launch_bounds__(256) void se_scale_kernel(SeFwdArgs a) {
   for (int j = tid; j < Cm; j += 256) hid[j] = a.hidden[(int64_t)g * Cm + j];
   __syncthreads();
   const int cb = blockIdx.x * 64;
+  {
+    // the wave's 16 channels together: 16 weight loads in flight per lane and step of 64 hidden units
+    const int c0 = cb + wave * 16;
+    float sacc[16];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {                 // 16 channels per wave, 4 at a time
-    const int c0 = cb + wave * 16 + r * 4;
-    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < 16; ++q) sacc[q] = 0.f;
     for (int j = lane; j < Cm; j += 64) {
       const float h = hid[j];
+      float wv[16];
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        if (c0 + q < C) s[q] += a.w2[(int64_t)(c0 + q) * Cm + j] * h;
+      for (int q = 0; q < 16; ++q) wv[q] = c0 + q < C ? a.w2[(int64_t)(c0 + q) * Cm + j] : 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) sacc[q] += wv[q] * h;
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      float v = wave_sum(s[q]) + ((a.b2 && c0 + q < C) ? a.b2[c0 + q] : 0.f);
+    for (int q = 0; q < 16; ++q) {
+      float v = wave_sum(sacc[q]) + ((a.b2 && c0 + q < C) ? a.b2[c0 + q] : 0.f);
       v = fminf(fmaxf(v * (1.f / 6.f) + 0.5f, 0.f), 1.f);
       if (lane == 0) {
-        scl[wave * 16 + r * 4 + q] = v;
+        scl[wave * 16 + q] = v;
         if (c0 + q < C) a.scale[(int64_t)g * C + c0 + q] = v;
       }
     }
@@ -213,17 +232,31 @@ __global__ __launch_bounds__(256) void se_scale_kernel(SeFwdArgs a) {
   // this clip's scaled bf16 copy of the projection weights, columns cb .. cb+63 ((X * s) W^T = X (W * s)^T)
   const int chunks = min(64, C - cb) / 8;       // C % 8 == 0
   bf16_t* out = a.wbs + (int64_t)g * a.N * C;
-  for (int i = tid; i < a.N * chunks; i += 256) {
-    const int n = i / chunks, ch = i - n * chunks;
-    const int64_t e = (int64_t)n * C + cb + ch * 8;
-    const f32x4 w0 = *reinterpret_cast<const f32x4*>(a.wproj + e), w1v = *reinterpret_cast<const f32x4*>(a.wproj + e + 4);
-    bf16x8 o;
+  for (int i0 = tid; i0 < a.N * chunks; i0 += 4 * 256) {
+    f32x4 w0[4], w1v[4];
+    int64_t e[4];
+    int chv[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      o[q] = (bf16_t)(w0[q] * scl[ch * 8 + q]);
-      o[4 + q] = (bf16_t)(w1v[q] * scl[ch * 8 + 4 + q]);
+    for (int u = 0; u < 4; ++u) {                // all eight 16-byte loads of a round in flight
+      const int i = min(i0 + u * 256, a.N * chunks - 1);
+      const int n = i / chunks;
+      chv[u] = i - n * chunks;
+      e[u] = (int64_t)n * C + cb + chv[u] * 8;
+      w0[u] = *reinterpret_cast<const f32x4*>(a.wproj + e[u]);
+      w1v[u] = *reinterpret_cast<const f32x4*>(a.wproj + e[u] + 4);
     }
-    *reinterpret_cast<bf16x8*>(out + e) = o;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (i0 + u * 256 < a.N * chunks) {
+        bf16x8 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          o[q] = (bf16_t)(w0[u][q] * scl[chv[u] * 8 + q]);
+          o[4 + q] = (bf16_t)(w1v[u][q] * scl[chv[u] * 8 + 4 + q]);
+        }
+        *reinterpret_cast<bf16x8*>(out + e[u]) = o;
+      }
+    }
   }
 }
 
