@@ -293,14 +293,19 @@ __global__ __launch_bounds__(SEB_T) void se_bwd_dh_kernel(SeBwdArgs a) {
   const int cq = (C + SEB_W - 1) / SEB_W, c0 = wave * cq, c1 = min(C, c0 + cq);
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (j < Cm) {
-    int c = c0;
-    for (; c + 4 <= c1; c += 4) {
-      s0 += a.w2[(int64_t)c * Cm + j] * dpre2[c];
-      s1 += a.w2[(int64_t)(c + 1) * Cm + j] * dpre2[c + 1];
-      s2 += a.w2[(int64_t)(c + 2) * Cm + j] * dpre2[c + 2];
-      s3 += a.w2[(int64_t)(c + 3) * Cm + j] * dpre2[c + 3];
+    // 16 weight loads in flight per round (predicated tail), four interleaved chains
+    for (int c = c0; c < c1; c += 16) {
+      float wv[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) wv[u] = c + u < c1 ? a.w2[(int64_t)(c + u) * Cm + j] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 16; u += 4) {
+        s0 += wv[u] * (c + u < c1 ? dpre2[c + u] : 0.f);
+        s1 += wv[u + 1] * (c + u + 1 < c1 ? dpre2[c + u + 1] : 0.f);
+        s2 += wv[u + 2] * (c + u + 2 < c1 ? dpre2[c + u + 2] : 0.f);
+        s3 += wv[u + 3] * (c + u + 3 < c1 ? dpre2[c + u + 3] : 0.f);
+      }
     }
-    for (; c < c1; ++c) s0 += a.w2[(int64_t)c * Cm + j] * dpre2[c];
   }
   red[wave * 64 + lane] = (s0 + s1) + (s2 + s3);
   __syncthreads();
@@ -326,12 +331,16 @@ __global__ __launch_bounds__(SEB_T) void se_bwd_gshift_kernel(SeBwdArgs a) {
   const int jq = (Cm + SEB_W - 1) / SEB_W, j0 = wave * jq, j1 = min(Cm, j0 + jq);
   float s0 = 0.f, s1 = 0.f;
   if (c < C) {
-    int j = j0;
-    for (; j + 2 <= j1; j += 2) {
-      s0 += a.w1[(int64_t)j * C + c] * dh[j];
-      s1 += a.w1[(int64_t)(j + 1) * C + c] * dh[j + 1];
+    for (int j = j0; j < j1; j += 8) {            // 8 weight loads in flight per round (predicated tail)
+      float wv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) wv[u] = j + u < j1 ? a.w1[(int64_t)(j + u) * C + c] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; u += 2) {
+        s0 += wv[u] * (j + u < j1 ? dh[j + u] : 0.f);
+        s1 += wv[u + 1] * (j + u + 1 < j1 ? dh[j + u + 1] : 0.f);
+      }
     }
-    if (j < j1) s0 += a.w1[(int64_t)j * C + c] * dh[j];
   }
   red[wave * 64 + lane] = s0 + s1;
   __syncthreads();
