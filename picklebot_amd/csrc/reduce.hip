@@ -24,7 +24,7 @@ struct ReduceJobs {
 };
 
 // out[e] (+)= sum_{s < split} part[s*stride + e].  A workgroup = 32 columns x 8 slot groups; group g adds the slots
-// g, g+8, g+16, ... with four independent accumulators, the eight groups are combined through LDS in index order:
+// g, g+8, g+16, ... with four independent accumulators (eight loads in flight), the eight groups are combined through LDS in index order:
 // the association is a function of `split` alone.  Columns are float4 when n, stride and the pointers allow.
 __global__ __launch_bounds__(256) void partials_reduce_kernel(ReduceJobs J) {
   __shared__ f32x4 red[8][32];
@@ -42,27 +42,27 @@ __global__ __launch_bounds__(256) void partials_reduce_kernel(ReduceJobs J) {
   const int64_t e = (int64_t)(blockIdx.x - J.blk0[j]) * 32 + col;
   f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
   if (e < cols) {
+    // eight slots' loads in flight per round, the tail predicated (a tail loop of single loads was one memory round trip
+    // per slot); chain u & 3 takes the u-th slot of a round: the association is still a function of `split` alone
     if (vec) {
       const f32x4* p = reinterpret_cast<const f32x4*>(P) + e;
       const int64_t st4 = stride / 4;
-      int i = grp;
-      for (; i + 24 < split; i += 32) {
-        s0 += p[(int64_t)i * st4];
-        s1 += p[(int64_t)(i + 8) * st4];
-        s2 += p[(int64_t)(i + 16) * st4];
-        s3 += p[(int64_t)(i + 24) * st4];
+      for (int i = grp; i < split; i += 64) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = i + 8 * u < split ? p[(int64_t)(i + 8 * u) * st4] : f32x4{0.f, 0.f, 0.f, 0.f};
+        s0 += v[0]; s1 += v[1]; s2 += v[2]; s3 += v[3];
+        s0 += v[4]; s1 += v[5]; s2 += v[6]; s3 += v[7];
       }
-      for (; i < split; i += 8) s0 += p[(int64_t)i * st4];
     } else {
       const float* p = P + e;
-      int i = grp;
-      for (; i + 24 < split; i += 32) {
-        s0[0] += p[(int64_t)i * stride];
-        s1[0] += p[(int64_t)(i + 8) * stride];
-        s2[0] += p[(int64_t)(i + 16) * stride];
-        s3[0] += p[(int64_t)(i + 24) * stride];
+      for (int i = grp; i < split; i += 64) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = i + 8 * u < split ? p[(int64_t)(i + 8 * u) * stride] : 0.f;
+        s0[0] += v[0]; s1[0] += v[1]; s2[0] += v[2]; s3[0] += v[3];
+        s0[0] += v[4]; s1[0] += v[5]; s2[0] += v[6]; s3[0] += v[7];
       }
-      for (; i < split; i += 8) s0[0] += p[(int64_t)i * stride];
     }
   }
   red[grp][col] = (s0 + s1) + (s2 + s3);
