@@ -133,26 +133,28 @@ struct SeFwdArgs {
 // sum over the slots of part[.][g][c] for c = tid, tid + nthreads, ... -> dst (LDS).  Eight loads in flight per thread:
 // with 4 the loop was a chain of ~50 memory round trips (20 us per launch).
 __device__ __forceinline__ void slot_sum_to_lds(const float* part, int slots, int G, int g, int C, float* dst, int nthreads) {
+  const int n8 = slots & ~7;
   for (int c = threadIdx.x; c < C; c += nthreads) {
     const float* p = part + (int64_t)g * C + c;
     const int64_t st = (int64_t)G * C;
-    // 16 loads in flight per round, the tail predicated (a dynamic tail loop was one memory round trip per slot); the
-    // association - sixteen interleaved chains, combined pairwise - is fixed
-    float acc[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) acc[u] = 0.f;
-    for (int sl = 0; sl < slots; sl += 16) {
+    // Eight chains (chain k adds the slots k, k+8, ... of the full groups of eight, in order), the tail of fewer than eight
+    // slots goes to chain 0, then ((0+1)+(2+3))+((4+5)+(6+7)): the association the goldens were validated with.  Sixteen
+    // loads are in flight per round and the tail's loads are issued together (a tail loop of single loads was one
+    // memory round trip per slot).
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int sl = 0; sl < n8; sl += 16) {
       float v[16];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) v[u] = sl + u < slots ? p[(sl + u) * st] : 0.f;
+      for (int u = 0; u < 16; ++u) v[u] = sl + u < n8 ? p[(sl + u) * st] : 0.f;
 #pragma unroll
-      for (int u = 0; u < 16; ++u) acc[u] += v[u];
+      for (int u = 0; u < 16; ++u) acc[u & 7] += v[u];           // (adding 0.f to a finite sum leaves its bits alone)
     }
+    float t[7];
 #pragma unroll
-    for (int w = 8; w >= 1; w >>= 1)
+    for (int u = 0; u < 7; ++u) t[u] = n8 + u < slots ? p[(n8 + u) * st] : 0.f;
 #pragma unroll
-      for (int u = 0; u < w; ++u) acc[u] += acc[u + w];
-    dst[c] = acc[0];
+    for (int u = 0; u < 7; ++u) acc[0] += t[u];
+    dst[c] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
   }
 }
 
