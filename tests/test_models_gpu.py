@@ -250,6 +250,48 @@ def test_weight_copies_follow_a_fused_optimizer_step():
     assert torch.allclose(y2, y2_fresh, rtol=2e-2, atol=2e-2), (y2 - y2_fresh).abs().max()
 
 
+def test_inference_batchnorm_fold_is_cached_and_never_stale():
+    """Eval mode under no_grad folds the running statistics into (scale, shift) once per BatchNorm (functional._bn_forward).
+    The fold must follow everything that can change it: an in-place edit of a buffer (version counter), a training forward
+    (our kernel updates the running statistics without bumping versions) and a fused optimiser step on the affine
+    parameters (no version bump either; every step is preceded by a grad-enabled forward, which drops the fold)."""
+    import copy
+    torch.manual_seed(5)
+    model = picklebot_amd.MobileNetSmall3D(5)
+    formula.fill_state_dict(model)                   # (weights and running statistics under which the signal survives)
+    model = model.to(DEV).eval()
+    x = torch.randn(2, 3, 8, 64, 64, device=DEV)
+
+    def fresh_output():
+        fresh = picklebot_amd.MobileNetSmall3D(5).to(DEV).eval()
+        fresh.load_state_dict(copy.deepcopy(model.state_dict()))
+        with torch.no_grad():
+            return fresh(x)
+
+    with torch.no_grad():
+        y1, y2 = model(x), model(x)                  # second call: every fold comes from the cache
+    assert torch.equal(y1, y2) and torch.equal(y1, fresh_output()) and not torch.equal(y1[0], y1[1])
+    bns = [m for m in model.modules() if isinstance(m, torch.nn.BatchNorm3d)]
+    assert all(getattr(b.running_mean, "_pb_fold", None) is not None for b in bns)
+    with torch.no_grad():
+        bns[3].running_mean.add_(0.25)               # torch sees this one: version counter
+        y3 = model(x)
+    assert not torch.equal(y3, y1) and torch.equal(y3, fresh_output())
+    opt = torch.optim.AdamW(model.parameters(), lr=5e-2, fused=True)
+    model.train()
+    model(x).square().mean().backward()              # updates the running statistics; grad-enabled: folds dropped
+    opt.step()                                       # changes gamma / beta without bumping their versions
+    model.eval()
+    with torch.no_grad():
+        y4 = model(x)
+    assert not torch.equal(y4, y3) and torch.equal(y4, fresh_output())
+    model(x).sum().backward()                        # eval mode, grad enabled (frozen-BN fine-tuning): no fold is kept
+    opt.step()
+    with torch.no_grad():
+        y5 = model(x)
+    assert torch.equal(y5, fresh_output())
+
+
 @pytest.mark.parametrize("name", ["large", "movinet", "vit"])
 def test_training_reduces_loss_on_a_fixed_batch(name):
     """Beyond one step: 25 AdamW steps on ONE synthetic batch (bf16 autocast, the reference's training mode) must
