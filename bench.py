@@ -129,21 +129,38 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    run_stream = torch.cuda.Stream(device)      # warm-up, capture, replay and the profiling pass all run on this ONE stream:
+    torch.cuda.set_stream(run_stream)           # autograd's AccumulateGrad nodes are created under the stream they later run on
+
     def capture(fn):
-        """Warm up on a side stream, then capture fn() into a HIP graph; returns (graph, fn's result)."""
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(3):
-                fn()
-        torch.cuda.current_stream().wait_stream(side)
+        """Warm up, then capture fn() into a HIP graph on the same stream; returns (graph, fn's result)."""
+        for _ in range(3):
+            fn()
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         K.reset_zero_arena()              # the zero-filled scratch must be allocated AND filled inside the graph
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, stream=run_stream):
             out = fn()
         K.reset_zero_arena()
         return g, out
+
+    def all_ranks_ok(ok):
+        """Launch-mode decisions are COLLECTIVE: every rank reports whether its capture attempt succeeded and all ranks take
+        the fallback together when any one failed (ranks in different modes would issue collectives from different places)."""
+        if not dp_path:
+            return ok
+        t = torch.tensor([1 if ok else 0], device=device, dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
+
+    def recover(what, e):
+        print(f"[bench] rank {rank}: {what} failed ({type(e).__name__}: {e})", file=sys.stderr)
+        try:
+            torch.cuda.synchronize()
+            K.reset_zero_arena()
+        except Exception as e2:          # a rank that cannot get back to a clean state must not continue in a divergent mode
+            print(f"[bench] rank {rank}: cannot recover after failed capture ({e2}); aborting", file=sys.stderr)
+            os._exit(3)
 
     # One training step = ~340 kernel launches through ctypes (6-8 ms of host time on a quiet box, 20+ ms on a
     # busy one, against ~12 ms of GPU work): on one GPU the whole step (forward, loss, backward, fused AdamW) is
@@ -160,9 +177,7 @@ def main():
                 return graph_loss
             launch_mode = "hipgraph"
         except Exception as e:  # capture is an optimisation: fall back to eager submission
-            print(f"[bench] HIP graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
-            torch.cuda.synchronize()
-            K.reset_zero_arena()
+            recover("HIP graph capture", e)
             step = eager_step
     elif dp_path and not args.no_graph:
         # data parallel.  First choice: the WHOLE step in one HIP graph, the exchange included - backward hands its gradients
@@ -170,6 +185,7 @@ def main():
         # stream (a fork inside the capture), so bucket k travels over xGMI while the rest of backward replays; the
         # optimizer joins behind the last reduction.  Second choice (capture of the collective refused): forward +
         # backward from a graph, then the bucket all-reduces and the optimizer eagerly (no overlap).  Third: eager.
+        # After every attempt the ranks agree (all-reduce MIN of a success flag) and fall back TOGETHER.
         def overlapped_step():
             reducer.adopt_grads()
             with torch.autocast("cuda", dtype=torch.bfloat16):
@@ -192,23 +208,33 @@ def main():
         sync()
         captured = False
         if flat_opt and not os.environ.get("PB_BENCH_NO_OVERLAP_GRAPH"):
+            ok, graph = True, None
             try:
                 graph, graph_loss = capture(overlapped_step)
-
+            except Exception as e:
+                ok = False
+                recover("capture with in-graph all-reduce", e)
+            if all_ranks_ok(ok):
                 def step():  # noqa: F811
                     graph.replay()
                     return graph_loss
                 launch_mode = "hipgraph(whole step; RCCL all-reduce per bucket on a forked stream, overlapped with backward)"
                 captured = True
                 eager_step = overlapped_step
-            except Exception as e:
-                print(f"[bench] capture with in-graph all-reduce failed ({type(e).__name__}: {e}); trying fwd+bwd only", file=sys.stderr)
-                torch.cuda.synchronize()
-                K.reset_zero_arena()
+            else:
+                graph = None
+                reducer.reset()
                 reducer.adopt_grads(False)
+                reducer.attach_grads()
+                reducer.zero_grad()
         if not captured:
+            ok, graph = True, None
             try:
                 graph, graph_loss = capture(fwd_bwd)
+            except Exception as e:
+                ok = False
+                recover("HIP graph capture (fwd+bwd)", e)
+            if all_ranks_ok(ok):
                 reducer.attach_grads()                    # the optimiser reads the (reduced) buckets from now on
 
                 def step():  # noqa: F811
@@ -217,10 +243,11 @@ def main():
                     opt_step_reduced()
                     return graph_loss
                 launch_mode = "hipgraph(fwd+bwd) + eager all-reduce/optimizer"
-            except Exception as e:
-                print(f"[bench] HIP graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
-                torch.cuda.synchronize()
-                K.reset_zero_arena()
+            else:
+                graph = None
+                reducer.reset()
+                reducer.attach_grads()
+                reducer.zero_grad()
                 step = eager_step
     for _ in range(args.warmup):
         step()

@@ -34,7 +34,7 @@ typedef enum {
   PB_ACT_HSIGMOID = 4, PB_ACT_SILU = 5
 } pb_act;
 
-#define PB_ABI_VERSION 14
+#define PB_ABI_VERSION 15
 
 /* Determinism.  Nothing in this library accumulates with floating-point atomics: two runs of the same binary on the
  * same inputs give bit-identical outputs and gradients.  Every reduction that spans workgroups stores one partial
@@ -251,6 +251,13 @@ int pb_bn_finalize(const float* stats, int slots, double count, const float* gam
                    float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked,
                    int use_running, float* scale, float* shift, float* mean, float* rstd, int C, int device,
                    void* stream);
+
+/* Inference fold of `count` BatchNorm modules in ONE launch (one per top-level eval forward; nothing is cached across
+ * forwards, so statistics / affine parameters updated by a replayed HIP graph are always seen).  desc: device array of
+ * count x 8 int64 = {gamma*, beta* (NULL = affine-free), running_mean*, running_var*, out* (4*C floats: scale, shift,
+ * mean, rstd), C, eps as the bit pattern of a double, 0}.  Replaces nn.BatchNorm3d in eval mode (mobilenet.py:80,
+ * movinet.py:65, mobilevit.py:15). */
+int pb_bn_fold_batch(const int64_t* desc, int count, int device, void* stream);
 
 /* y = act((x - mean[c])*scale[c] + shift[c]) * row_scale[g, c] + row_shift[g, c], g = m / rows_per_group;
  * optional stats of y.  For BatchNorm pass scale = gamma*rstd, shift = beta, mean = the batch mean: the

@@ -1,0 +1,77 @@
+"""Conditioning screen for the train-mode gradient fixtures (test infrastructure; build container only).
+
+A fixture can carry a FLAT tolerance only if the function it pins is well conditioned at that input: if the reference's own
+fp32 arithmetic, re-associated in equally valid ways, moves a gradient by more than the tolerance, the fixture measures the
+summation order of whoever is compared with it, not correctness (MoViNet-A2's train8 fixture sat one ulp from a
+kink; MobileNetLarge3D's ended in 4x4 frames).  For a candidate (clip shape, input salt) this module runs the REAL reference
+
+  * once in fp64                                  -> the golden values,
+  * in fp32 under several arithmetic VARIANTS     -> per-key deviation from fp64 of every variant; `spread` = the largest,
+      v0: 8 threads, channels-last-3d input (train.py:106), oneDNN on      v1: 1 thread
+      v2: oneDNN (mkldnn) off                                                v3: contiguous NCDHW input, 3 threads
+  * under bf16 autocast for the same variants      -> `bf16_bound` = mean + 3 sigma of the per-key deviation (floor 1e-2),
+
+and accepts the candidate when every gradient key's fp32 spread is <= LIMIT (2.5e-4: a quarter of the 1e-3 bar).
+"""
+import contextlib
+import io
+
+import numpy as np
+import torch
+
+from . import protocol
+
+LIMIT = 2.5e-4
+VARIANTS = ("v0", "v1", "v2", "v3")
+
+
+@contextlib.contextmanager
+def variant(name):
+    old_threads = torch.get_num_threads()
+    try:
+        if name == "v1":
+            torch.set_num_threads(1)
+        elif name == "v3":
+            torch.set_num_threads(3)
+        else:
+            torch.set_num_threads(8)
+        if name == "v2":
+            with torch.backends.mkldnn.flags(enabled=False):
+                yield
+        else:
+            yield
+    finally:
+        torch.set_num_threads(old_threads)
+
+
+def run(ns, case, shape, salt, dtype, autocast=False, vname="v0"):
+    quiet = io.StringIO()
+    with contextlib.redirect_stdout(quiet), variant(vname):
+        return protocol.collect_grad_case(ns, case, "train8", dtype=dtype, autocast=autocast, shape=shape, salt=salt,
+                                          contiguous_input=(vname == "v3"))
+
+
+def screen(ns, case, shape, salt, with_bf16=True, verbose=True):
+    """-> (accepted, truth, spread {key: float}, bf16_bound {key: float}, report str)."""
+    truth = run(ns, case, shape, salt, torch.float64)
+    devs = {v: protocol.deviations(run(ns, case, shape, salt, torch.float32, vname=v), truth) for v in VARIANTS}
+    spread = {k: max(float(devs[v][k][0]) for v in VARIANTS) for k in devs["v0"]}
+    gkeys = [k for k in spread if k.startswith("grad/")]
+    gmax = max(float(torch.linalg.vector_norm(truth[k])) for k in gkeys)
+    live = [k for k in gkeys if float(torch.linalg.vector_norm(truth[k])) >= 1e-6 * gmax]     # (structural zeros: conv bias before BN)
+    worst = max(live, key=lambda k: spread[k])
+    g = np.array([spread[k] for k in live])
+    ok = bool(g.max() <= LIMIT)
+    rep = (f"[{case} {shape} salt {salt}] fp32 spread over {len(VARIANTS)} variants, {len(live)} gradient keys: median {np.median(g):.2e} "
+           f"p90 {np.percentile(g, 90):.2e} max {g.max():.2e} ({worst}) -> {'ACCEPT' if ok else 'reject'}")
+    bound = {}
+    if with_bf16 and ok:
+        draws = {v: protocol.deviations(run(ns, case, shape, salt, torch.float32, autocast=True, vname=v), truth) for v in VARIANTS}
+        for k in draws["v0"]:
+            d = np.array([float(draws[v][k][0]) for v in VARIANTS])
+            bound[k] = max(1e-2, float(d.mean() + 3.0 * d.std(ddof=1)))
+        b = np.array([bound[k] for k in live])
+        rep += f"; bf16 bound (mean+3sigma over {len(VARIANTS)} draws, floor 1e-2): median {np.median(b):.2e} max {b.max():.2e}"
+    if verbose:
+        print(rep, flush=True)
+    return ok, truth, spread, bound, rep

@@ -124,8 +124,11 @@ def collect_model_case(ns, case, device="cpu", dtype=torch.float32, do_eval=True
     return out
 
 
-def collect_grad_case(ns, case, mode, device="cpu", dtype=torch.float32, autocast=False):
-    """mode "evalgrad" | "train8" (see GRAD_CASES) -> RAW tensors {"logits", "loss", "grad/<param>"} (float64, CPU)."""
+def collect_grad_case(ns, case, mode, device="cpu", dtype=torch.float32, autocast=False, shape=None, salt=1234,
+                      contiguous_input=False):
+    """mode "evalgrad" | "train8" (see GRAD_CASES) -> RAW tensors {"logits", "loss", "grad/<param>"} (float64, CPU).
+    shape / salt override the clip (oracle/condition_screen.py); contiguous_input: NCDHW-contiguous instead of the
+    channels-last-3d view train.py:106 produces (an arithmetic variant for the screen: other conv kernels)."""
     cls_name, kwargs, _, train_shape = MODEL_CASES[case]
     ncls = kwargs["num_classes"]
     model = build_model(ns, case, "cpu")
@@ -134,13 +137,18 @@ def collect_grad_case(ns, case, mode, device="cpu", dtype=torch.float32, autocas
     model = model.to(device)
     if mode == "evalgrad":
         model.eval()
-        shape = train_shape
+        shape = shape or train_shape
     elif mode == "train8":
         model.train()
-        shape = GRAD_CASES[case]
+        shape = shape or GRAD_CASES[case][:4]
+        if len(GRAD_CASES[case]) > 4 and salt == 1234:
+            salt = GRAD_CASES[case][4]
     else:
         raise ValueError(mode)
-    x = formula.clip_features(*shape, dtype=dtype).to(device)
+    x = formula.clip_features(*shape, dtype=dtype, salt=salt)
+    if contiguous_input:
+        x = x.contiguous()
+    x = x.to(device)
     y = formula.labels(shape[0], ncls).to(device)
     model.zero_grad(set_to_none=True)
     if autocast:

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libpicklebot_amd.so")
 
 PB_F32, PB_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY_RELU, ACT_HSWISH, ACT_HSIGMOID, ACT_SILU = range(6)
-ABI_VERSION = 14
+ABI_VERSION = 15
 STAT_SLOTS = 512
 
 
@@ -52,6 +52,7 @@ SIGNATURES = {
     "pb_stem_conv3d_bwd_weight": [P, P, I, F, P, P, POINTER(StemShape), I, P, L, I, P],
     "pb_chan_stats": [P, L, I, I, P, I, P],
     "pb_bn_finalize": [P, I, D, P, P, F, F, P, P, P, I, P, P, P, P, I, I, P],
+    "pb_bn_fold_batch": [P, I, I, P],
     "pb_affine_act_fwd": [P, P, L, I, I, P, P, P, I, F, P, P, L, P, I, P],
     "pb_act_bwd_reduce": [P, P, P, L, I, I, P, P, I, F, P, L, L, F, P, P, P, I, P],
     "pb_bn_bwd_finalize": [P, I, D, P, P, P, I, P, P, P, P, P, I, I, P],

@@ -15,6 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(LIBDIR, "obj")
+ASMDIR = os.path.join(LIBDIR, "asm")           # gfx950 ISA of every source (tools/lint_isa.py, tests/test_isa_lint_cpu.py)
 LIB = os.path.join(LIBDIR, "libpicklebot_amd.so")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
@@ -42,6 +43,7 @@ def sources():
 
 def build(force=False, verbose=True):
     os.makedirs(OBJDIR, exist_ok=True)
+    os.makedirs(ASMDIR, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers += [os.path.join(INCLUDE, f) for f in os.listdir(INCLUDE) if f.endswith(".h")]
     hipcc = _hipcc()
@@ -51,15 +53,26 @@ def build(force=False, verbose=True):
         stamp = obj + ".sha"
         dig = _digest([src] + headers, " ".join(FLAGS))
         objs.append(obj)
-        if force or not os.path.exists(obj) or not os.path.exists(stamp) or open(stamp).read() != dig:
+        asm = os.path.join(ASMDIR, os.path.basename(src)[:-4] + ".s")
+        if (force or not os.path.exists(obj) or not os.path.exists(stamp) or open(stamp).read() != dig
+                or (not os.path.exists(asm) and os.access(ASMDIR, os.W_OK) and not os.environ.get("PB_BUILD_NO_ASM"))):
             jobs.append((src, obj, stamp, dig))
 
     def compile_one(job):
         src, obj, stamp, dig = job
-        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        # -save-temps=obj: the device assembly is kept (lib/asm/<name>.s) for the ISA lint; the other temporaries are removed
+        cmd = [hipcc] + FLAGS + ["-save-temps=obj", "-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
+        base = os.path.basename(obj)[:-2]
+        for f in os.listdir(OBJDIR):
+            if f.startswith((base + "-hip-", base + "-host-", base + ".hip-")):
+                full = os.path.join(OBJDIR, f)
+                if f.endswith("gfx950.s"):
+                    os.replace(full, os.path.join(ASMDIR, base + ".s"))
+                else:
+                    os.remove(full)
         if verbose and r.stderr.strip():
             sys.stderr.write(r.stderr)
         with open(stamp, "w") as f:

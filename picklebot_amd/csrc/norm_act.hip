@@ -440,6 +440,29 @@ __global__ __launch_bounds__(FIN_T) void bn_finalize_kernel(const float* stats, 
   if (rstd_o) rstd_o[c] = (float)rstd;
 }
 
+// Inference fold of MANY BatchNorm modules in one launch: desc[j] = {gamma, beta, running_mean, running_var, out, C, eps bits};
+// out[0..C) = scale = gamma*rstd, out[C..2C) = shift = beta - mean*scale, out[2C..3C) = mean, out[3C..4C) = rstd.
+__global__ __launch_bounds__(256) void bn_fold_batch_kernel(const int64_t* desc) {
+  const int64_t* d = desc + (size_t)blockIdx.x * 8;
+  const float* gamma = reinterpret_cast<const float*>(d[0]);
+  const float* beta = reinterpret_cast<const float*>(d[1]);
+  const float* rm = reinterpret_cast<const float*>(d[2]);
+  const float* rv = reinterpret_cast<const float*>(d[3]);
+  float* out = reinterpret_cast<float*>(d[4]);
+  const int C = (int)d[5];
+  double eps;
+  { int64_t bits = d[6]; __builtin_memcpy(&eps, &bits, 8); }
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const double mean = rm[c], var = rv[c];
+    const double rstd = 1.0 / sqrt(var + eps);
+    const double g = gamma ? gamma[c] : 1.0, b = beta ? beta[c] : 0.0;
+    out[c] = (float)(g * rstd);
+    out[C + c] = (float)(b - mean * g * rstd);
+    out[2 * C + c] = (float)mean;
+    out[3 * C + c] = (float)rstd;
+  }
+}
+
 __global__ __launch_bounds__(FIN_T) void bn_bwd_finalize_kernel(const float* sums, int slots, double count, const float* gamma, const float* mean,
                                                               const float* rstd, int training, float* cA, float* cB, float* cC,
                                                               float* dgamma, float* dbeta, int C) {
@@ -502,6 +525,14 @@ extern "C" int pb_bn_finalize(const float* stats, int slots, double count, const
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)pb_cdiv(C, 32)), dim3(FIN_T), 0, (hipStream_t)stream, stats,
                      slots, count, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, use_running, scale,
                      shift, mean, rstd, C);
+  PB_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pb_bn_fold_batch(const int64_t* desc, int count, int device, void* stream) {
+  PB_CHECK_ARG(desc && count > 0 && count <= 65535, "pb_bn_fold_batch: bad arguments");
+  PB_ENTER(device);
+  hipLaunchKernelGGL(bn_fold_batch_kernel, dim3((unsigned)count), dim3(256), 0, (hipStream_t)stream, desc);
   PB_LAUNCH_CHECK();
   return 0;
 }

@@ -83,10 +83,10 @@ __global__ __launch_bounds__(256) void partials_reduce_kernel(ReduceJobs J) {
 }  // namespace
 
 int pb_launch_partials_reduce(const pb_reduce_job* jobs, int count, hipStream_t st) {
-  for (int base = 0; base < count; base += MAX_JOBS) {
+  for (int i = 0; i < count;) {        // the running index is carried across batches: skipped (empty) jobs must not shift them
     ReduceJobs J = {};
     int nb = 0, k = 0;
-    for (int i = base; i < count && k < MAX_JOBS; ++i) {
+    for (; i < count && k < MAX_JOBS; ++i) {
       const pb_reduce_job& q = jobs[i];
       if (q.n <= 0 || q.split <= 0) continue;
       J.part[k] = q.part; J.out[k] = q.out; J.n[k] = q.n; J.stride[k] = q.stride; J.split[k] = q.split;

@@ -20,15 +20,38 @@ import torch
 from . import kernels as K
 
 
+def _prepare_bn_folds(model):
+    """Inference forwards: fold every eval-mode BatchNorm of `model` in ONE launch, valid for this forward only."""
+    fs_cls = getattr(K, "BnFoldSet", None)
+    if fs_cls is None or not isinstance(model, torch.nn.Module):
+        return
+    bns = model.__dict__.get("_pb_bn_mods")
+    if bns is None:
+        bns = [m for m in model.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)]
+        model.__dict__["_pb_bn_mods"] = bns
+    todo = [(m.weight, m.bias, m.running_mean, m.running_var, float(m.eps)) for m in bns
+            if not m.training and m.running_mean is not None and m.running_mean.is_cuda]
+    if not todo:
+        return
+    fs = model.__dict__.get("_pb_foldset")
+    if fs is None:
+        fs = model.__dict__["_pb_foldset"] = fs_cls()
+    fs.prepare(todo)
+
+
 def scoped(fn):
     """Decorator for every module forward: the outermost one opens a new weight generation (kernels.weight_scope),
-    so that the bf16 weight copies derived inside it and in its backward are never reused after an optimiser step."""
+    so that the bf16 weight copies derived inside it and in its backward are never reused after an optimiser step.
+    An outermost forward that needs no gradients also folds the module's eval-mode BatchNorms (one launch)."""
     @functools.wraps(fn)
     def wrapper(*args, **kwargs):
         scope = getattr(K, "weight_scope", None)
         if scope is None:
             return fn(*args, **kwargs)
+        outer = getattr(K._wscope_depth, "d", 0) == 0
         with scope():
+            if outer and args and not torch.is_grad_enabled():
+                _prepare_bn_folds(args[0])
             return fn(*args, **kwargs)
     return wrapper
 
@@ -93,34 +116,23 @@ def _bn_state(bn):
 def _bn_forward(z2, stats, count, gamma, beta, rmean, rvar, eps, momentum, training, nbt=None, infer=False):
     """-> (scale, shift, mean, rstd); updates running stats (and the step counter nbt) in training.
 
-    Inference (eval mode under torch.no_grad) folds the running statistics into (scale, shift) ONCE per BatchNorm and keeps
-    the result on the running_mean tensor object: 29 finalize launches per MoViNet-A2 forward were 8 % of its kernel time.
-    The fold is dropped by any forward that could precede a change this code cannot see - training mode (our kernel updates
-    the running statistics without bumping tensor versions) and any forward that needs gradients (fused optimisers do not
-    bump parameter versions either) - and it is keyed on the tensors' version counters for everything torch does see
-    (load_state_dict, in-place edits)."""
+    Inference (eval mode, no gradients needed): the outermost module forward has folded all its eval-mode BatchNorms in one
+    launch (`scoped` -> kernels.BnFoldSet) - 29 finalize launches per MoViNet-A2 forward were 8 % of its kernel time.  That
+    fold is valid for THIS top-level forward only: a training step replayed from a HIP graph changes running statistics and
+    affine parameters without any Python-visible trace, so nothing is kept across forwards."""
     use_running = not training
     if not use_running and rmean is None:
         rmean_, rvar_ = None, None
     else:
         rmean_, rvar_ = rmean, rvar
     C = (stats.shape[-1] if stats is not None else rmean.shape[0])
-    # `infer`: the caller's forward needs no gradient (inside an autograd.Function grad mode is off either way)
-    cacheable = bool(infer and use_running and rmean is not None and rmean.is_cuda and not torch.cuda.is_current_stream_capturing())
-    if rmean is not None and not cacheable and getattr(rmean, "_pb_fold", None) is not None:
-        rmean._pb_fold = None
-    key = None
-    if cacheable:
-        key = (rmean._version, rvar._version, None if gamma is None else (gamma._version, gamma.data_ptr()),
-               None if beta is None else (beta._version, beta.data_ptr()), rvar.data_ptr(), float(eps))
-        hit = getattr(rmean, "_pb_fold", None)
-        if hit is not None and hit[0] == key:
-            return hit[1]
-    out = K.bn_finalize(None if use_running else stats, count, gamma, beta, eps, momentum, rmean_, rvar_,
-                        use_running, C, z2.device, num_batches_tracked=None if use_running else nbt)
-    if cacheable:
-        rmean._pb_fold = (key, out)
-    return out
+    if infer and use_running and rmean is not None and rmean.is_cuda:
+        lookup = getattr(K, "bn_fold_lookup", None)
+        hit = lookup(gamma, beta, rmean, rvar, eps) if lookup is not None else None
+        if hit is not None:
+            return hit
+    return K.bn_finalize(None if use_running else stats, count, gamma, beta, eps, momentum, rmean_, rvar_,
+                         use_running, C, z2.device, num_batches_tracked=None if use_running else nbt)
 
 
 class _BnCtx:
@@ -650,20 +662,20 @@ class _AttnBlock(torch.autograd.Function):
     """x + to_out(attention(to_qkv(LayerNorm(x))))   (mobilevit.py:68-86 + the residual of :102), rows [G*n, D]."""
 
     @staticmethod
-    def forward(ctx, x, w_qkv, w_out, G, n, scale, eps):
+    def forward(ctx, x, w_qkv, w_out, G, n, scale, eps, residual=True):
         D = x.shape[1]
         xn, stat = K.layernorm_fwd(x, eps)
         qkv = K.pw_fwd(xn, w_qkv)
         o, lse = K.attention_fwd(qkv, G, n, scale)
-        y = K.pw_fwd(o, w_out, residual=x)
+        y = K.pw_fwd(o, w_out, residual=x if residual else None)
         ctx.save_for_backward(x, stat, xn, qkv, o, lse, w_qkv, w_out)
-        ctx.meta = (G, n, scale, eps)
+        ctx.meta = (G, n, scale, eps, residual)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, stat, xn, qkv, o, lse, w_qkv, w_out = ctx.saved_tensors
-        G, n, scale, eps = ctx.meta
+        G, n, scale, eps, residual = ctx.meta
         D = x.shape[1]
         dy = dy if dy.is_contiguous() else dy.contiguous()
         dw_out, dw_qkv = _zeros_many(x, tuple(w_out.shape), tuple(w_qkv.shape))
@@ -673,21 +685,23 @@ class _AttnBlock(torch.autograd.Function):
         K.pw_bwd_weight(dqkv, xn, dw_qkv)
         dxn = K.pw_fwd(dqkv, w_qkv, w_transposed=True)
         dx = K.layernorm_bwd(x, dxn, stat, eps)
-        K.copy_cols(dy, 0, dx, 0, D, accumulate=True)
-        return dx, dw_qkv, dw_out, None, None, None, None
+        if residual:
+            K.copy_cols(dy, 0, dx, 0, D, accumulate=True)
+        return dx, dw_qkv, dw_out, None, None, None, None, None
 
 
 class _FFBlock(torch.autograd.Function):
     """x + W2 silu(W1 x)   (mobilevit.py:28-40 + the residual of :103)."""
 
     @staticmethod
-    def forward(ctx, x, w1, w2):
+    def forward(ctx, x, w1, w2, residual=True):
         D = x.shape[1]
+        ctx.residual = residual
         hpre = K.pw_fwd(x, w1)
         # silu in its own pass (12 MB) so that both GEMMs on it are the LDS-DMA kernels: the activation-prologue
         # GEMM measured 146 us against 21 + 5 on the [4096,768]x[768,192] layer
         h = K.affine_act_fwd(hpre, act="silu")
-        y = K.pw_fwd(h, w2, residual=x)
+        y = K.pw_fwd(h, w2, residual=x if residual else None)
         ctx.save_for_backward(x, hpre, h, w1, w2)
         return y
 
@@ -701,8 +715,8 @@ class _FFBlock(torch.autograd.Function):
         dh = K.pw_fwd(dy, w2, w_transposed=True)
         dhpre = K.act_bwd_reduce(dh, hpre, act="silu")
         K.pw_bwd_weight(dhpre, x, dw1)
-        dx = K.pw_fwd(dhpre, w1, w_transposed=True, residual=dy)
-        return dx, dw1, dw2
+        dx = K.pw_fwd(dhpre, w1, w_transposed=True, residual=dy if ctx.residual else None)
+        return dx, dw1, dw2, None
 
 
 _fp8_attention = False
@@ -723,17 +737,18 @@ class fp8_attention:
         return False
 
 
-def attn_block(rows, w_qkv, w_out, G, n, scale, eps):
+def attn_block(rows, w_qkv, w_out, G, n, scale, eps, residual=True):
+    """residual=True: x + attn(x) (Transformer.forward, mobilevit.py:102); False: attn(x) alone (Attention.forward)."""
     rows = rows if rows.is_contiguous() else rows.contiguous()
     if _fp8_attention and not torch.is_grad_enabled() and rows.dtype == torch.bfloat16 and n <= 1024:
         xn, _ = K.layernorm_fwd(rows, eps)
         o, _ = K.attention_fwd(K.pw_fwd(xn, w_qkv), G, n, scale, fp8=True)
-        return K.pw_fwd(o, w_out, residual=rows)
-    return _AttnBlock.apply(rows, w_qkv, w_out, G, n, scale, eps)
+        return K.pw_fwd(o, w_out, residual=rows if residual else None)
+    return _AttnBlock.apply(rows, w_qkv, w_out, G, n, scale, eps, residual)
 
 
-def ff_block(rows, w1, w2):
-    return _FFBlock.apply(rows if rows.is_contiguous() else rows.contiguous(), w1, w2)
+def ff_block(rows, w1, w2, residual=True):
+    return _FFBlock.apply(rows if rows.is_contiguous() else rows.contiguous(), w1, w2, residual)
 
 
 class _LinAttn(torch.autograd.Function):

@@ -336,6 +336,58 @@ class WeightSet:
                 _wcache[(w.data_ptr(), w.numel(), True, "fold4")] = (_wgen, f1)
 
 
+
+# ------------------------------------------------------------------------------ inference BatchNorm folds
+# (scale, shift, mean, rstd) of every eval-mode BatchNorm of a model, computed by ONE launch per top-level forward and valid
+# for that forward only (`_wgen`): a training step replayed from a HIP graph updates running statistics and affine parameters
+# through raw pointers - no Python, no version bump - so nothing derived from them may outlive the forward that derived it.
+_foldcache = {}
+
+
+class BnFoldSet:
+    def __init__(self):
+        self.key = None
+        self.desc = None
+        self.out = None
+        self.views = None
+
+    def prepare(self, bns):
+        """bns: list of (gamma|None, beta|None, running_mean, running_var, eps).  Must be called inside a weight_scope."""
+        import struct
+        bns = [b for b in bns if b[2] is not None and b[2].is_cuda]
+        if not bns:
+            return
+        key = tuple((0 if g is None else g.data_ptr(), 0 if b is None else b.data_ptr(), m.data_ptr(), v.data_ptr(), m.numel(), float(e))
+                    for g, b, m, v, e in bns)
+        dev_t = bns[0][2].device
+        if key != self.key:
+            total = sum(4 * k[4] for k in key)
+            self.out = torch.empty(total, dtype=torch.float32, device=dev_t)
+            rows, views, off = [], [], 0
+            for k in key:
+                C = k[4]
+                rows.append([k[0], k[1], k[2], k[3], self.out.data_ptr() + 4 * off, C,
+                             struct.unpack("<q", struct.pack("<d", k[5]))[0], 0])
+                views.append(tuple(self.out[off + i * C: off + (i + 1) * C] for i in range(4)))
+                off += 4 * C
+            self.desc = torch.tensor(rows, dtype=torch.int64, device=dev_t)
+            self.key, self.views = key, views
+        dev, st = _dev_stream(self.out)
+        _launch("bn_fold_batch", self.out.numel() * 4, "pb_bn_fold_batch", _p(self.desc), len(key), dev, st)
+        for k, v in zip(key, self.views):
+            _foldcache[k[2]] = (_wgen, k, v)
+
+
+def bn_fold_lookup(gamma, beta, running_mean, running_var, eps):
+    """The fold BnFoldSet.prepare made for this BatchNorm in the CURRENT top-level forward, or None."""
+    ent = _foldcache.get(running_mean.data_ptr())
+    if ent is None or ent[0] != _wgen or getattr(_wscope_depth, "d", 0) <= 0:
+        return None
+    k = (0 if gamma is None else gamma.data_ptr(), 0 if beta is None else beta.data_ptr(), running_mean.data_ptr(),
+         running_var.data_ptr(), running_mean.numel(), float(eps))
+    return ent[2] if ent[1] == k else None
+
+
 def pw_fwd(x, w, *, w_transposed=False, in_scale=None, in_shift=None, in_act="none", in_slope=0.0, row_scale=None,
            rows_per_group=0, out_scale=None, out_shift=None, out_act="none", out_slope=0.0, stats=None, residual=None,
            scaled_weights=None):

@@ -50,16 +50,16 @@ class FeedForward(nn.Module):
         self.net = nn.Sequential(nn.Linear(embed_dim, hidden_dim, bias=False), nn.SiLU(), nn.Dropout(dropout),
                                  nn.Linear(hidden_dim, embed_dim, bias=False), nn.Dropout(dropout))
 
-    def rows(self, rows):
-        """x + net(x) on token rows [R, D] (the residual of Transformer.forward is fused in)."""
+    def rows(self, rows, residual=True):
+        """x + net(x) on token rows [R, D] (the residual of Transformer.forward is fused in); residual=False: net(x)."""
         _no_dropout(self.net[2].p if self.training else 0, "FeedForward")
-        return PF.ff_block(rows, self.net[0].weight, self.net[3].weight)
+        return PF.ff_block(rows, self.net[0].weight, self.net[3].weight, residual)
 
     @torch.compiler.disable
     @PF.scoped
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         rows = x.reshape(-1, x.shape[-1]).to(compute_dtype(x))
-        return (self.rows(rows) - rows).view(x.shape)          # module contract is net(x) without the residual
+        return self.rows(rows, residual=False).view(x.shape)    # module contract is net(x) without the residual
 
 
 class Attention(nn.Module):
@@ -76,19 +76,19 @@ class Attention(nn.Module):
         self.to_out = nn.Sequential(nn.Linear(self.inner_dim, embed_dim, bias=False), nn.Dropout(dropout))
         self.flash = True
 
-    def rows(self, rows, G, n):
-        """x + to_out(attention(...)) on token rows [G*n, D]."""
+    def rows(self, rows, G, n, residual=True):
+        """x + to_out(attention(...)) on token rows [G*n, D]; residual=False: without the x."""
         if self.heads != 8 or self.inner_dim != 128:
             raise NotImplementedError("picklebot_amd.Attention: kernels are built for 8 heads of 16 (mobilevit.py:116)")
         _no_dropout(self.dropout_p if self.training else 0, "Attention")
-        return PF.attn_block(rows, self.to_qkv.weight, self.to_out[0].weight, G, n, self.scale, self.norm.eps)
+        return PF.attn_block(rows, self.to_qkv.weight, self.to_out[0].weight, G, n, self.scale, self.norm.eps, residual)
 
     @torch.compiler.disable
     @PF.scoped
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         b, p, n, d = x.shape
         rows = x.reshape(-1, d).to(compute_dtype(x))
-        return (self.rows(rows, b * p, n) - rows).view(x.shape)
+        return self.rows(rows, b * p, n, residual=False).view(x.shape)
 
 
 class Transformer(nn.Module):

@@ -167,6 +167,11 @@ class GradReducer:
         self._pending = []
         self._ready = [0] * len(self.buckets)
 
+    def reset(self):
+        """Forget reductions in flight and hook counts (after a failed HIP-graph capture attempt)."""
+        self._pending = []
+        self._ready = [0] * len(self.buckets)
+
     @contextlib.contextmanager
     def no_sync(self):
         old, self._enabled = self._enabled, False
@@ -202,5 +207,10 @@ def setup_distributed(backend=None):
     if backend == "nccl":
         torch.cuda.set_device(local_rank)
     if not dist.is_initialized():
-        dist.init_process_group(backend)
+        if backend == "nccl":
+            # device_id binds the communicator to this rank's GPU up front (eager init; no "barrier(): using the device
+            # under current context" guess, no lazy communicator creation inside a HIP-graph capture)
+            dist.init_process_group(backend, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     return local_rank, rank, world

@@ -627,3 +627,22 @@ def test_attention_fp8_forward(K, G, n):
     assert rel_err(lse.cpu().numpy(), lse_ref.numpy()) <= 2e-2
     bf, _ = K.attention_fwd(dev(qkv), G, n, 0.25)
     assert rel_err(bf.float().cpu().numpy(), want.float().numpy()) <= 1.2e-2
+
+
+def test_partials_reduce_more_than_eight_jobs_with_empty_and_accumulate(K):
+    """pb_partials_reduce batches 8 jobs per launch; empty jobs are skipped and must not shift the batches (a job run
+    twice would double-add with accumulate=1)."""
+    g = torch.Generator().manual_seed(5)
+    jobs, want, outs = [], [], []
+    for j in range(13):
+        n = [64, 0, 37, 128, 4, 0, 256, 19, 8, 1000, 12, 0, 333][j]
+        split = [3, 2, 5, 1, 7, 4, 2, 9, 1, 3, 6, 1, 2][j]
+        acc = j % 2
+        part = torch.randn(split, max(n, 1), generator=g).to(DEV)
+        out = torch.randn(max(n, 1), generator=g).to(DEV)
+        ref = (out.double().cpu() if acc else 0) + part.double().cpu().sum(0)
+        jobs.append((part, out, n, max(n, 1), split, acc))
+        outs.append(out); want.append(ref if n else out.double().cpu().clone())
+    K.partials_reduce(jobs, torch.device(DEV))
+    for j, (o, w) in enumerate(zip(outs, want)):
+        assert torch.allclose(o.double().cpu(), w, rtol=1e-5, atol=1e-5), f"job {j}"

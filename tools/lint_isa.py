@@ -65,21 +65,35 @@ def lint(name, body):
     return hazards
 
 
+def lint_asm(asm):
+    """-> (hazards: [(kernel, label, first copies)], wide: [(kernel, vgprs)] for kernels needing > 256 VGPRs)."""
+    meta = open(asm).read()
+    counts = dict(zip(re.findall(r"\.name:\s+(\S+)", meta), (int(v) for v in re.findall(r"\.vgpr_count:\s+(\d+)", meta))))
+    hazards, wide = [], []
+    for name, body in kernels(asm):
+        for label, vec in lint(name, body):
+            hazards.append((name, label, vec[:2]))
+        if counts.get(name, 0) > 256:
+            wide.append((name, counts[name]))
+    return hazards, wide
+
+
 def main():
-    srcs = sys.argv[1:] or sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+    """Without arguments: lint the assembly the build keeps (picklebot_amd/lib/asm/*.s); with .hip files: compile them first."""
     total = 0
+    asmdir = os.path.join(ROOT, "picklebot_amd", "lib", "asm")
     with tempfile.TemporaryDirectory() as td:
-        for src in srcs:
-            asm = compile_to_asm(os.path.abspath(src), td)
-            meta = open(asm).read()
-            counts = dict(zip(re.findall(r"\.name:\s+(\S+)", meta), re.findall(r"\.vgpr_count:\s+(\d+)", meta)))
-            for name, body in kernels(asm):
-                hz = lint(name, body)
-                nacc = sum(1 for l in body if "v_accvgpr_write" in l)
-                if hz:
-                    total += len(hz)
-                    print(f"{os.path.basename(src)}: {name[:90]} vgprs={counts.get(name, '?')} agpr_copies={nacc}: {len(hz)} join block(s) with "
-                          f"vector copies ahead of the exec restore, e.g. {hz[0][0]} {hz[0][1][:2]}")
+        if sys.argv[1:]:
+            asms = [compile_to_asm(os.path.abspath(src), td) for src in sys.argv[1:]]
+        else:
+            asms = sorted(os.path.join(asmdir, f) for f in os.listdir(asmdir) if f.endswith(".s"))
+        for asm in asms:
+            hazards, wide = lint_asm(asm)
+            for name, vg in wide:
+                print(f"{os.path.basename(asm)}: {name[:100]} needs {vg} VGPRs (> 256: live ranges split into AGPRs)")
+            for name, label, vec in hazards:
+                total += 1
+                print(f"{os.path.basename(asm)}: {name[:90]}: join block {label} has vector copies ahead of the exec restore: {vec}")
     print(f"{total} suspicious join blocks")
     return 1 if total else 0
 
