@@ -51,6 +51,39 @@ def run(ns, case, shape, salt, dtype, autocast=False, vname="v0"):
                                           contiguous_input=(vname == "v3"))
 
 
+KINKS = {"ReLU": (0.0,), "LeakyReLU": (0.0,), "Hardswish": (-3.0, 3.0), "Hardsigmoid": (-3.0, 3.0), "ReLU6": (0.0, 6.0)}
+
+
+def kink_census(ns, case, shape, salt, radius=1e-5):
+    """fp64 train-mode forward of the REAL reference: how many activation inputs lie within `radius` of a point where the
+    activation's derivative jumps (ReLU 0; hardswish / hardsigmoid +-3), and the smallest distance.  One such element flipping
+    between two arithmetics changes every upstream gradient by ~1e-3..1e-2 (measured: MobileNetLarge3D 8x8x112x112, two
+    single-element hardswish flips under a 1e-6 parameter perturbation moved all gradients by 1.4 %)."""
+    import torch.nn as nn
+    quiet = io.StringIO()
+    with contextlib.redirect_stdout(quiet):
+        model = protocol.build_model(ns, case, "cpu").double().train()
+    stat = {"near": 0, "min": float("inf"), "elems": 0}
+
+    def hook(mod, inp):                  # a PRE-hook: nn.ReLU(inplace=True) (mobilenet.py:18) overwrites its input
+        ks = KINKS.get(type(mod).__name__)
+        if ks is None:
+            return
+        x = inp[0].detach()
+        for k in ks:
+            d = (x - k).abs()
+            stat["near"] += int((d < radius).sum())
+            stat["min"] = min(stat["min"], float(d.min()))
+        stat["elems"] += x.numel()
+    hs = [m.register_forward_pre_hook(hook) for m in model.modules() if type(m).__name__ in KINKS]
+    from . import formula
+    with torch.no_grad(), contextlib.redirect_stdout(quiet):
+        model(formula.clip_features(*shape, dtype=torch.float64, salt=salt))
+    for h in hs:
+        h.remove()
+    return stat
+
+
 def screen(ns, case, shape, salt, with_bf16=True, verbose=True):
     """-> (accepted, truth, spread {key: float}, bf16_bound {key: float}, report str)."""
     truth = run(ns, case, shape, salt, torch.float64)

@@ -191,17 +191,24 @@ class _Bottleneck(torch.autograd.Function):
         act, slope, training = cfg["act"], cfg["slope"], cfg["training"]
         has_bn, has_se = cfg["bn"] is not None, se_w1 is not None
         x2 = x5.view(-1, Cin)
-        e2 = K.pw_fwd(x2, w1.view(E, Cin))
-        e5 = e2.view(N, T, H, W, E)
         training_bn = has_bn and training
         stats = _zeros((K.REPL, 2, Cout), x5) if training_bn else None
         pool = se_scale = hidden = wbs = None
-        if has_se:
-            # squeeze partial sums ride on the depthwise kernel; ONE launch turns them into pool / hidden / scale and the
-            # per-clip scaled bf16 projection weights (the squeeze-excite scale is folded into the GEMM's weights)
-            d5, pool_part = K.dw_fwd_pool(e5, wdw.view(E, -1), kernel, stride, pad)
+        # expansion conv -> depthwise conv in ONE kernel where the shape allows (bf16, (1,k,k)): the expanded tensor e never
+        # reaches HBM - not written, not read back, not saved (backward recomputes its tiles from x)
+        fused = bool(getattr(K, "xdw_supported", None) and K.xdw_enabled() and K.xdw_supported(x5, E, kernel, stride, pad))
+        e5 = None
+        if fused:
+            d5, pool_part = K.xdw_fwd(x5, w1.view(E, Cin), wdw.view(E, -1), kernel, stride, pad, pool=has_se)
         else:
-            d5 = K.dw_fwd(e5, wdw.view(E, -1), kernel, stride, pad)
+            e2 = K.pw_fwd(x2, w1.view(E, Cin))
+            e5 = e2.view(N, T, H, W, E)
+            if has_se:
+                # squeeze partial sums ride on the depthwise kernel; ONE launch turns them into pool / hidden / scale and the
+                # per-clip scaled bf16 projection weights (the squeeze-excite scale is folded into the GEMM's weights)
+                d5, pool_part = K.dw_fwd_pool(e5, wdw.view(E, -1), kernel, stride, pad)
+            else:
+                d5 = K.dw_fwd(e5, wdw.view(E, -1), kernel, stride, pad)
         To, Ho, Wo = d5.shape[1:4]
         R2 = To * Ho * Wo
         d2 = d5.view(-1, E)
@@ -232,6 +239,7 @@ class _Bottleneck(torch.autograd.Function):
                               mean=bnc.mean if bnc is not None else None)
         if need_grad:
             ctx.cfg, ctx.bnc, ctx.dims = cfg, bnc, (N, T, H, W, Cin, E, Cout, To, Ho, Wo)
+            ctx.fused = fused
             ctx.save_for_backward(x5, e5, d5, z2, w1, wdw, w2, se_w1, se_w2, pool, se_scale, hidden, gamma, drop)
         return y2.view(N, To, Ho, Wo, Cout)
 
@@ -264,7 +272,10 @@ class _Bottleneck(torch.autograd.Function):
                 g_scale = se_scale
                 dse_w1, dse_w2 = dse_w1.view_as(se_w1), dse_w2.view_as(se_w2)
             dS5 = dS2.view(N, To, Ho, Wo, E)
-            K.dw_bwd_weight(dS5, e5, dwdw, kernel, stride, pad, g_scale, g_shift)
+            if ctx.fused:
+                K.xdw_bwd_weight(dS5, x5, w1.view(E, Cin), dwdw, kernel, stride, pad, g_scale, g_shift)
+            else:
+                K.dw_bwd_weight(dS5, e5, dwdw, kernel, stride, pad, g_scale, g_shift)
             dE5 = K.dw_bwd_data(dS5, wdw.view(E, -1), (T, H, W), kernel, stride, pad, g_scale, g_shift)
             dE2 = dE5.view(-1, E)
             K.pw_bwd_weight(dE2, x5.view(-1, Cin), dw1)
