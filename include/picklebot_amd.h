@@ -227,6 +227,14 @@ int pb_xdw_bwd_weight(const void* x, const void* w1_bf16, const void* dy, float*
                       const float* g_scale, const float* g_shift, void* ws, int64_t ws_bytes, pb_reduce_job* deferred,
                       int device, void* stream);
 
+/* ---------------------------------------------------------------- frame gather / scatter (temporally strided bottlenecks)
+ * Bottleneck3D's depthwise conv has a (1,k,k) kernel and strides T as well (mobilenet.py:67-75): with stride 2 only every
+ * other input frame is ever read.  gather: dst[N][Tdst][frame] = src[N][Tsrc][frame] frames t0, t0+tstep, ...; scatter
+ * (scatter != 0): dst[n][t] = src[n][(t - t0) / tstep] where that is a frame of src, exact zeros elsewhere (the input
+ * gradient of the unread frames).  frame_bytes % 16 == 0. */
+int pb_frames_gather(const void* src, void* dst, int N, int Tsrc, int Tdst, int64_t frame_bytes, int t0, int tstep,
+                     int scatter, int device, void* stream);
+
 /* Name of the HIP kernel the dispatcher picks for this shape (profiling labels: rocprofv3 kernel names
  * <-> bench.py families).  which: 0 = forward, 1 = backward-data, 2 = backward-weight.  Static string. */
 const char* pb_dwconv3d_kernel_name(const pb_dwconv_shape* s, pb_dtype dtype, int which);

@@ -165,6 +165,16 @@ def xdw_bwd_weight(dy, x, w1, dwdw, kernel, stride, pad, g_scale=None, g_shift=N
     return dw_bwd_weight(dy, e5, dwdw, kernel, stride, pad, g_scale, g_shift)
 
 
+def frames_gather(x, t0, tstep, count):
+    return x[:, t0:t0 + (count - 1) * tstep + 1:tstep].contiguous()
+
+
+def frames_scatter(xs, T, t0, tstep):
+    out = torch.zeros((xs.shape[0], T) + tuple(xs.shape[2:]), dtype=xs.dtype)
+    out[:, t0:t0 + (xs.shape[1] - 1) * tstep + 1:tstep] = xs
+    return out
+
+
 def _g(dy, g_scale, g_shift):
     g = dy.float()
     if g_scale is not None:

@@ -50,6 +50,7 @@ SIGNATURES = {
     "pb_dwconv3d_bwd_weight": [P, P, P, POINTER(DwShape), I, P, P, P, L, POINTER(ReduceJob), I, P],
     "pb_xdw_fwd": [P, P, P, P, POINTER(DwShape), I, P, I, I, P],
     "pb_xdw_bwd_weight": [P, P, P, P, POINTER(DwShape), I, P, P, P, L, POINTER(ReduceJob), I, P],
+    "pb_frames_gather": [P, P, I, I, I, L, I, I, I, I, P],
     "pb_stem_conv3d_fwd": [P, I, F, P, P, P, POINTER(StemShape), I, P, I, I, P],
     "pb_stem_conv3d_bwd_weight": [P, P, I, F, P, P, POINTER(StemShape), I, P, L, I, P],
     "pb_chan_stats": [P, L, I, I, P, I, P],

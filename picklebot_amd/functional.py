@@ -190,25 +190,43 @@ class _Bottleneck(torch.autograd.Function):
         kernel, stride, pad = cfg["kernel"], cfg["stride"], cfg["pad"]
         act, slope, training = cfg["act"], cfg["slope"], cfg["training"]
         has_bn, has_se = cfg["bn"] is not None, se_w1 is not None
-        x2 = x5.view(-1, Cin)
         training_bn = has_bn and training
         stats = _zeros((K.REPL, 2, Cout), x5) if training_bn else None
         pool = se_scale = hidden = wbs = None
+        # Temporal stride with a (1,k,k) kernel (mobilenet.py:67-75: the scalar stride also strides T): an output frame reads
+        # exactly ONE input frame, so with stride 2 half of the input frames are never read.  The used frames are gathered
+        # first: the expansion conv, the depthwise conv and all their backward passes run on those rows only (the reference
+        # expands every frame), and the depthwise conv sees a temporal stride of 1 with `lead` zero frames in front.
+        tskip = None
+        xs5, dkernel, dstride, dpad, dpad_back = x5, kernel, stride, pad, None
+        if kernel[0] == 1 and stride[0] > 1 and hasattr(K, "frames_gather"):
+            To_full = (T + 2 * pad[0] - 1) // stride[0] + 1
+            used = [to for to in range(To_full) if 0 <= to * stride[0] - pad[0] < T]
+            if used and len(used) < T:
+                lead, Tu = used[0], len(used)
+                t0 = used[0] * stride[0] - pad[0]
+                tskip = (t0, stride[0], Tu)
+                xs5 = K.frames_gather(x5, t0, stride[0], Tu)
+                dstride = (1,) + tuple(stride[1:])
+                dpad = (lead,) + tuple(pad[1:])
+                dpad_back = (To_full - lead - Tu,) + tuple(pad[1:])
+        Ts = xs5.shape[1]
+        x2 = xs5.view(-1, Cin)
         # expansion conv -> depthwise conv in ONE kernel where the shape allows (bf16, (1,k,k)): the expanded tensor e never
         # reaches HBM - not written, not read back, not saved (backward recomputes its tiles from x)
-        fused = bool(getattr(K, "xdw_supported", None) and K.xdw_enabled() and K.xdw_supported(x5, E, kernel, stride, pad))
+        fused = bool(tskip is None and getattr(K, "xdw_supported", None) and K.xdw_enabled() and K.xdw_supported(x5, E, kernel, stride, pad))
         e5 = None
         if fused:
             d5, pool_part = K.xdw_fwd(x5, w1.view(E, Cin), wdw.view(E, -1), kernel, stride, pad, pool=has_se)
         else:
             e2 = K.pw_fwd(x2, w1.view(E, Cin))
-            e5 = e2.view(N, T, H, W, E)
+            e5 = e2.view(N, Ts, H, W, E)
             if has_se:
                 # squeeze partial sums ride on the depthwise kernel; ONE launch turns them into pool / hidden / scale and the
                 # per-clip scaled bf16 projection weights (the squeeze-excite scale is folded into the GEMM's weights)
-                d5, pool_part = K.dw_fwd_pool(e5, wdw.view(E, -1), kernel, stride, pad)
+                d5, pool_part = K.dw_fwd_pool(e5, wdw.view(E, -1), dkernel, dstride, dpad, dpad_back)
             else:
-                d5 = K.dw_fwd(e5, wdw.view(E, -1), kernel, stride, pad)
+                d5 = K.dw_fwd(e5, wdw.view(E, -1), dkernel, dstride, dpad, dpad_back)
         To, Ho, Wo = d5.shape[1:4]
         R2 = To * Ho * Wo
         d2 = d5.view(-1, E)
@@ -239,8 +257,8 @@ class _Bottleneck(torch.autograd.Function):
                               mean=bnc.mean if bnc is not None else None)
         if need_grad:
             ctx.cfg, ctx.bnc, ctx.dims = cfg, bnc, (N, T, H, W, Cin, E, Cout, To, Ho, Wo)
-            ctx.fused = fused
-            ctx.save_for_backward(x5, e5, d5, z2, w1, wdw, w2, se_w1, se_w2, pool, se_scale, hidden, gamma, drop)
+            ctx.fused, ctx.tskip, ctx.dconv = fused, tskip, (dkernel, dstride, dpad)
+            ctx.save_for_backward(xs5, e5, d5, z2, w1, wdw, w2, se_w1, se_w2, pool, se_scale, hidden, gamma, drop)
         return y2.view(N, To, Ho, Wo, Cout)
 
     @staticmethod
@@ -272,16 +290,20 @@ class _Bottleneck(torch.autograd.Function):
                 g_scale = se_scale
                 dse_w1, dse_w2 = dse_w1.view_as(se_w1), dse_w2.view_as(se_w2)
             dS5 = dS2.view(N, To, Ho, Wo, E)
+            dkernel, dstride, dpad = ctx.dconv       # (x5 here = the gathered frames when the block strides T)
+            Ts = x5.shape[1]
             if ctx.fused:
                 K.xdw_bwd_weight(dS5, x5, w1.view(E, Cin), dwdw, kernel, stride, pad, g_scale, g_shift)
             else:
-                K.dw_bwd_weight(dS5, e5, dwdw, kernel, stride, pad, g_scale, g_shift)
-            dE5 = K.dw_bwd_data(dS5, wdw.view(E, -1), (T, H, W), kernel, stride, pad, g_scale, g_shift)
+                K.dw_bwd_weight(dS5, e5, dwdw, dkernel, dstride, dpad, g_scale, g_shift)
+            dE5 = K.dw_bwd_data(dS5, wdw.view(E, -1), (Ts, H, W), dkernel, dstride, dpad, g_scale, g_shift)
             dE2 = dE5.view(-1, E)
             K.pw_bwd_weight(dE2, x5.view(-1, Cin), dw1)
             dx5 = None
             if ctx.needs_input_grad[0]:
-                dx5 = K.pw_fwd(dE2, w1.view(E, Cin), w_transposed=True).view(N, T, H, W, Cin)
+                dx5 = K.pw_fwd(dE2, w1.view(E, Cin), w_transposed=True).view(N, Ts, H, W, Cin)
+                if ctx.tskip is not None:                 # exact zeros in the frames the block never read
+                    dx5 = K.frames_scatter(dx5, T, ctx.tskip[0], ctx.tskip[1])
         return (dx5, dw1.view_as(w1), dwdw.view_as(wdw), dw2.view_as(w2), dse_w1, dse_b1, dse_w2, dse_b2, dgamma,
                 dbeta, None, None, None, None)
 

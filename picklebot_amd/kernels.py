@@ -715,6 +715,35 @@ def xdw_bwd_weight(dy, x, w1, dwdw, kernel, stride, pad, g_scale=None, g_shift=N
     return dwdw
 
 
+# ------------------------------------------------------------------------------ frame gather / scatter
+def frames_gather(x, t0, tstep, count):
+    """x [N,T,H,W,C] -> [N,count,H,W,C]: frames t0, t0+tstep, ... (contiguous copy)."""
+    _ndhwc(x, "x")
+    N, T = x.shape[:2]
+    fb = x[0, 0].numel() * x.element_size()
+    if fb % 16 or t0 < 0 or t0 + (count - 1) * tstep >= T:
+        raise ValueError(f"frames_gather: frames {t0}+{tstep}*[0,{count}) of {tuple(x.shape)}")
+    out = torch.empty((N, count) + tuple(x.shape[2:]), dtype=x.dtype, device=x.device)
+    dev, st = _dev_stream(x)
+    _launch("frames_kernel", _nb(out) * 2, "pb_frames_gather", _p(x), _p(out), N, T, count, fb, int(t0), int(tstep), 0, dev, st,
+            detail=f"gather {tuple(x.shape)} -> T{count}")
+    return out
+
+
+def frames_scatter(xs, T, t0, tstep):
+    """xs [N,Tu,H,W,C] -> [N,T,H,W,C] with xs[:, j] at frame t0 + j*tstep and exact zeros in all other frames."""
+    _ndhwc(xs, "xs")
+    N, Tu = xs.shape[:2]
+    fb = xs[0, 0].numel() * xs.element_size()
+    if fb % 16:
+        raise ValueError("frames_scatter: frame size must be a multiple of 16 bytes")
+    out = torch.empty((N, T) + tuple(xs.shape[2:]), dtype=xs.dtype, device=xs.device)
+    dev, st = _dev_stream(xs)
+    _launch("frames_kernel", _nb(out, xs), "pb_frames_gather", _p(xs), _p(out), N, Tu, T, fb, int(t0), int(tstep), 1, dev, st,
+            detail=f"scatter T{Tu} -> {tuple(out.shape)}")
+    return out
+
+
 # ------------------------------------------------------------------------------ stem conv
 _XDT = {torch.float32: 0, torch.bfloat16: 1, torch.uint8: 2}
 

@@ -692,3 +692,18 @@ def test_xdw_fused_expand_depthwise_forward_and_weight_gradient(K, N, Cin, E, th
         got_w = K.xdw_bwd_weight(dev(dy), xd, dev(w1), torch.zeros(E, k * k, device=DEV), kernel, stride, pad,
                                  **{a: dev(b) for a, b in kw.items()})
         check("xdw_wgrad", got_w, want_w, torch.bfloat16)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("N,T,frame,t0,step", [(2, 10, (5, 6, 8), 1, 2), (3, 8, (4, 4, 16), 0, 2), (1, 7, (3, 3, 24), 2, 3), (2, 5, (2, 2, 8), 4, 2)])
+def test_frames_gather_scatter(K, N, T, frame, t0, step, dtype):
+    """Temporally strided bottlenecks read every `step`-th frame only: gather == strided slice, scatter == its adjoint with
+    exact zeros in the unread frames (bit-exact: pure data movement)."""
+    x = rnd((N, T) + frame, dtype, 61)
+    count = (T - 1 - t0) // step + 1
+    got = K.frames_gather(dev(x), t0, step, count)
+    assert torch.equal(got.cpu(), R.frames_gather(x, t0, step, count))
+    back = K.frames_scatter(got, T, t0, step)
+    assert torch.equal(back.cpu(), R.frames_scatter(R.frames_gather(x, t0, step, count), T, t0, step))
+    unread = [t for t in range(T) if t < t0 or (t - t0) % step]
+    assert all(float(back[:, t].abs().max()) == 0.0 for t in unread)
