@@ -231,9 +231,11 @@ int pb_xdw_bwd_weight(const void* x, const void* w1_bf16, const void* dy, float*
  * Bottleneck3D's depthwise conv has a (1,k,k) kernel and strides T as well (mobilenet.py:67-75): with stride 2 only every
  * other input frame is ever read.  gather: dst[N][Tdst][frame] = src[N][Tsrc][frame] frames t0, t0+tstep, ...; scatter
  * (scatter != 0): dst[n][t] = src[n][(t - t0) / tstep] where that is a frame of src, exact zeros elsewhere (the input
- * gradient of the unread frames).  frame_bytes % 16 == 0. */
+ * gradient of the unread frames) - or, with `fill` (one pixel row of fill_bytes, a multiple of 16 that divides the frame), that
+ * row repeated: the frames a (1,k,k) depthwise conv pads in time are exact zeros before BatchNorm and the per-channel
+ * constant act(shift) after a folded inference BatchNorm.  frame_bytes % 16 == 0. */
 int pb_frames_gather(const void* src, void* dst, int N, int Tsrc, int Tdst, int64_t frame_bytes, int t0, int tstep,
-                     int scatter, int device, void* stream);
+                     int scatter, const void* fill, int fill_bytes, int device, void* stream);
 
 /* Name of the HIP kernel the dispatcher picks for this shape (profiling labels: rocprofv3 kernel names
  * <-> bench.py families).  which: 0 = forward, 1 = backward-data, 2 = backward-weight.  Static string. */
@@ -294,7 +296,13 @@ int pb_bn_fold_batch(const int64_t* desc, int count, int device, void* stream);
  * mean is subtracted first (a folded shift = beta - mean*scale cancels badly when |mean| >> std). */
 int pb_affine_act_fwd(const void* x, void* y, int64_t M, int C, pb_dtype dtype, const float* scale,
                       const float* shift, const float* mean, pb_act act, float slope, const float* row_scale,
-                      const float* row_shift, int64_t rows_per_group, float* stats, int device, void* stream);
+                      const float* row_shift, int64_t rows_per_group, float* stats, int64_t fm_full, int64_t fm_data,
+                      int64_t fm_lead, int device, void* stream);
+/* Frame map (fm_full > 0; pb_affine_act_fwd and pb_act_bwd_reduce): M counts the rows of the FULL tensor [clips][fm_full];
+ * the pre-BatchNorm tensor (x resp. z) is COMPACT - it holds only the fm_data data rows of every clip, full rows
+ * [fm_lead, fm_lead + fm_data) - and reads as exact zeros on the other rows (the frames a (1,k,k) depthwise conv pads in
+ * time, mobilenet.py:67-75); pb_affine_act_fwd writes the full y, pb_act_bwd_reduce reads the full dy, sums over all M rows
+ * and writes g compact. */
 
 /* g = dy * row_scale * act'((z-mean)*scale+shift); sums[0..C) += sum g, sums[C..2C) += sum g*(z-mean)*rstd.
  * dy_rows_per_group > 0: dy is [M/dy_rows_per_group][C] broadcast over each row group (the
@@ -303,7 +311,7 @@ int pb_affine_act_fwd(const void* x, void* y, int64_t M, int C, pb_dtype dtype, 
 int pb_act_bwd_reduce(const void* dy, const void* z, void* g_out, int64_t M, int C, pb_dtype dtype,
                       const float* scale, const float* shift, pb_act act, float slope,
                       const float* row_scale, int64_t rows_per_group, int64_t dy_rows_per_group, float dy_mul,
-                      const float* mean, const float* rstd, float* sums, int device, void* stream);
+                      const float* mean, const float* rstd, float* sums, int64_t fm_full, int64_t fm_data, int64_t fm_lead, int device, void* stream);
 
 /* BatchNorm backward coefficients: dz = A*g + B*(z - mean) + Cc;  dgamma = sum g*xhat, dbeta = sum g. */
 int pb_bn_bwd_finalize(const float* sums, int slots, double count, const float* gamma, const float* mean, const float* rstd,

@@ -165,12 +165,18 @@ def xdw_bwd_weight(dy, x, w1, dwdw, kernel, stride, pad, g_scale=None, g_shift=N
     return dw_bwd_weight(dy, e5, dwdw, kernel, stride, pad, g_scale, g_shift)
 
 
+def act_row(shift, act, slope, dtype):
+    return affine_act_fwd(shift.view(1, -1), act=act, slope=slope).to(dtype).view(-1)
+
+
 def frames_gather(x, t0, tstep, count):
     return x[:, t0:t0 + (count - 1) * tstep + 1:tstep].contiguous()
 
 
-def frames_scatter(xs, T, t0, tstep):
+def frames_scatter(xs, T, t0, tstep, fill=None):
     out = torch.zeros((xs.shape[0], T) + tuple(xs.shape[2:]), dtype=xs.dtype)
+    if fill is not None:
+        out[:] = fill
     out[:, t0:t0 + (xs.shape[1] - 1) * tstep + 1:tstep] = xs
     return out
 
@@ -259,8 +265,25 @@ def bn_finalize(stats, count, gamma, beta, eps, momentum, running_mean, running_
     return (g * rstd).float(), (b - mean * g * rstd).float(), mean.float(), rstd.float()
 
 
+def _fm_expand(t, frame_map):
+    """compact rows -> full rows with exact zeros on the padded ones (mirror of the kernels' frame map)."""
+    full, data, lead = frame_map
+    n = t.shape[0] // data
+    out = torch.zeros((n, full, t.shape[1]), dtype=t.dtype)
+    out[:, lead:lead + data] = t.view(n, data, -1)
+    return out.view(n * full, -1)
+
+
+def _fm_compact(t, frame_map):
+    full, data, lead = frame_map
+    n = t.shape[0] // full
+    return t.view(n, full, -1)[:, lead:lead + data].reshape(n * data, -1).contiguous()
+
+
 def affine_act_fwd(x, scale=None, shift=None, act="none", slope=0.0, row_scale=None, rows_per_group=0, stats=None,
-                   row_shift=None, mean=None):
+                   row_shift=None, mean=None, frame_map=None):
+    if frame_map is not None:
+        x = _fm_expand(x, frame_map)
     xf = x.float()
     if mean is not None:
         xf = xf - mean
@@ -281,7 +304,12 @@ def affine_act_fwd(x, scale=None, shift=None, act="none", slope=0.0, row_scale=N
 
 
 def act_bwd_reduce(dy, z, *, scale=None, shift=None, act="none", slope=0.0, row_scale=None, rows_per_group=0,
-                   dy_rows_per_group=0, dy_mul=1.0, mean=None, rstd=None, sums=None, want_g=True):
+                   dy_rows_per_group=0, dy_mul=1.0, mean=None, rstd=None, sums=None, want_g=True, frame_map=None):
+    if frame_map is not None:
+        g = act_bwd_reduce(dy, _fm_expand(z, frame_map), scale=scale, shift=shift, act=act, slope=slope, row_scale=row_scale,
+                           rows_per_group=rows_per_group, dy_rows_per_group=dy_rows_per_group, dy_mul=dy_mul, mean=mean, rstd=rstd,
+                           sums=sums, want_g=True)
+        return _fm_compact(g, frame_map) if want_g else None
     zf = z.float()
     pre = zf if mean is None else zf - mean
     if scale is not None:

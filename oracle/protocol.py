@@ -27,16 +27,21 @@ MODEL_CASES = {
     "mobilevit_xxs": ("MobileViT", dict(num_classes=13, **MOBILEVIT_CFG["xxs"]), (1, 32, 224, 224), (1, 10, 96, 96)),
 }
 
-# Well-conditioned gradient fixtures (round 2): the train-mode gradients of MODEL_CASES run BatchNorm over a 2-clip
-# batch, where the reference's own fp32 path is up to 1.5e-2 off fp64.  Two more protocols per model:
+# Gradient fixtures (tests/golden/grad_*.npz), two protocols per model:
 #   evalgrad: model.eval() (running-statistics BatchNorm, SURVEY 8a-T "in eval-mode"), the train clip of MODEL_CASES
-#   train8  : model.train() on 8 clips at reduced resolution
-GRAD_CASES = {   # name -> train8 clip (N,T,H,W)
-    "small3d": (8, 8, 64, 64),
-    "large3d": (8, 8, 112, 112),
-    "movinet_a2": (8, 8, 64, 64),
-    "mobilevit_s": (8, 8, 64, 64),
-    "mobilevit_xxs": (8, 8, 64, 64),
+#   train   : model.train() (batch-statistics BatchNorm, train.py:254-289) on the clip below
+# The train clips were chosen by oracle/condition_screen.py (round 3): clip shape and input salt such that, in the REAL
+# reference's fp64 run, no activation input lies within 1e-5 of a point where the activation's derivative jumps (ReLU 0,
+# hardswish / hardsigmoid +-3) and the gradient moves smoothly under perturbation (kappa <= 2000).  A single element on the
+# other side of such a kink changes every upstream gradient by ~1e-2 in these BatchNorm-coupled nets, whatever fp32
+# implementation computes it - round 2's MobileNetLarge3D fixture (8x8x112x112, 13 M activations) had 17 elements within
+# 1e-5, MoViNet-A2's sat 1 ulp from one.
+GRAD_CASES = {   # name -> (N, T, H, W, input salt)
+    "small3d": (8, 8, 64, 64, 2),
+    "large3d": (4, 8, 64, 64, 30),
+    "movinet_a2": (4, 8, 64, 64, 15),
+    "mobilevit_s": (8, 8, 64, 64, 22),
+    "mobilevit_xxs": (8, 8, 64, 64, 18),
 }
 
 N_SAMPLE = 8
@@ -126,7 +131,7 @@ def collect_model_case(ns, case, device="cpu", dtype=torch.float32, do_eval=True
 
 def collect_grad_case(ns, case, mode, device="cpu", dtype=torch.float32, autocast=False, shape=None, salt=1234,
                       contiguous_input=False):
-    """mode "evalgrad" | "train8" (see GRAD_CASES) -> RAW tensors {"logits", "loss", "grad/<param>"} (float64, CPU).
+    """mode "evalgrad" | "train" (see GRAD_CASES) -> RAW tensors {"logits", "loss", "grad/<param>"} (float64, CPU).
     shape / salt override the clip (oracle/condition_screen.py); contiguous_input: NCDHW-contiguous instead of the
     channels-last-3d view train.py:106 produces (an arithmetic variant for the screen: other conv kernels)."""
     cls_name, kwargs, _, train_shape = MODEL_CASES[case]
@@ -138,11 +143,10 @@ def collect_grad_case(ns, case, mode, device="cpu", dtype=torch.float32, autocas
     if mode == "evalgrad":
         model.eval()
         shape = shape or train_shape
-    elif mode == "train8":
+    elif mode == "train":
         model.train()
-        shape = shape or GRAD_CASES[case][:4]
-        if len(GRAD_CASES[case]) > 4 and salt == 1234:
-            salt = GRAD_CASES[case][4]
+        if shape is None:
+            shape, salt = GRAD_CASES[case][:4], GRAD_CASES[case][4]
     else:
         raise ValueError(mode)
     x = formula.clip_features(*shape, dtype=dtype, salt=salt)

@@ -50,14 +50,14 @@ SIGNATURES = {
     "pb_dwconv3d_bwd_weight": [P, P, P, POINTER(DwShape), I, P, P, P, L, POINTER(ReduceJob), I, P],
     "pb_xdw_fwd": [P, P, P, P, POINTER(DwShape), I, P, I, I, P],
     "pb_xdw_bwd_weight": [P, P, P, P, POINTER(DwShape), I, P, P, P, L, POINTER(ReduceJob), I, P],
-    "pb_frames_gather": [P, P, I, I, I, L, I, I, I, I, P],
+    "pb_frames_gather": [P, P, I, I, I, L, I, I, I, P, I, I, P],
     "pb_stem_conv3d_fwd": [P, I, F, P, P, P, POINTER(StemShape), I, P, I, I, P],
     "pb_stem_conv3d_bwd_weight": [P, P, I, F, P, P, POINTER(StemShape), I, P, L, I, P],
     "pb_chan_stats": [P, L, I, I, P, I, P],
     "pb_bn_finalize": [P, I, D, P, P, F, F, P, P, P, I, P, P, P, P, I, I, P],
     "pb_bn_fold_batch": [P, I, I, P],
-    "pb_affine_act_fwd": [P, P, L, I, I, P, P, P, I, F, P, P, L, P, I, P],
-    "pb_act_bwd_reduce": [P, P, P, L, I, I, P, P, I, F, P, L, L, F, P, P, P, I, P],
+    "pb_affine_act_fwd": [P, P, L, I, I, P, P, P, I, F, P, P, L, P, L, L, L, I, P],
+    "pb_act_bwd_reduce": [P, P, P, L, I, I, P, P, I, F, P, L, L, F, P, P, P, L, L, L, I, P],
     "pb_bn_bwd_finalize": [P, I, D, P, P, P, I, P, P, P, P, P, I, I, P],
     "pb_affine2": [P, P, P, L, I, I, P, P, P, P, P, L, P, P, I, F, I, P],
     "pb_rowgroup_reduce": [P, P, P, L, L, I, I, P, L, I, P],

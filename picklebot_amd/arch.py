@@ -96,6 +96,18 @@ MOVINET_A2 = {
     "head_hidden": 2048,                  # movinet.py:149
 }
 
+def movinet_a2_depthwise_layers(h=172, w=172):
+    """(expanded channels, kernel, stride, (H_in, W_in)) of the 26 depthwise convs of MoViNetA2 at an h x w clip
+    (movinet.py:92, 98-137): the stem halves H and W, then every bottleneck's depthwise conv strides them by its row."""
+    hh, ww = conv_out(h, 3, 2, 1), conv_out(w, 3, 2, 1)
+    out = []
+    for rows in MOVINET_A2["blocks"].values():
+        for r in rows:
+            out.append((r.exp, tuple(r.kernel), tuple(r.stride), (hh, ww)))
+            hh, ww = conv_out(hh, r.kernel[1], r.stride[1], r.padding[1]), conv_out(ww, r.kernel[2], r.stride[2], r.padding[2])
+    return out
+
+
 # train.py:156-161 registry names
 MODEL_NAMES = ("MoViNetA2", "MobileNetLarge3D", "MobileNetSmall3D", "MobileViT")
 

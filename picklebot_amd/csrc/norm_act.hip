@@ -126,6 +126,12 @@ struct EwArgs {
   const float* cC;
   float* sums;          // [2][C]
   RowMap map;
+  // Frame map (fm_full > 0): the kernel walks M rows of a FULL tensor [clips][fm_full rows]; an operand marked compact holds
+  // only the fm_data data rows of every clip (full rows [fm_lead, fm_lead + fm_data) of the clip) and reads as 0 elsewhere;
+  // a compact output is written at the data rows only.  (The frames a (1,k,k) depthwise conv pads in time: zero before
+  // BatchNorm, but counted by its statistics and present in its output.)
+  int64_t fm_full, fm_data, fm_lead;
+  int a_compact, b_compact, out_compact;
 };
 
 
@@ -182,23 +188,34 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs a) {
     const int act_ = ACT_C >= 0 ? ACT_C : a.act;
     for (int64_t mb = mlo + p; mb < mhi; mb += (int64_t)UNR * mp.P) {
       RawRow<T, CH> ra[UNR], rb[UNR];
-      bool ok[UNR];
+      bool ok[UNR], dat[UNR];
+      int64_t offo[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) dat[u] = true;
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
         const int64_t m = mb + (int64_t)u * mp.P;
         ok[u] = m < mhi;
         const int64_t mc = ok[u] ? m : mlo + p;          // shadow a valid row, discard later
         const int64_t off = mc * a.C + c0;
+        int64_t offc = off;                               // the row's offset in a compact operand (frame map)
+        if (a.fm_full > 0) {
+          const uint32_t n_ = (uint32_t)mc / (uint32_t)a.fm_full;
+          const int64_t j = mc - (int64_t)n_ * a.fm_full - a.fm_lead;
+          dat[u] = j >= 0 && j < a.fm_data;
+          offc = ((int64_t)n_ * a.fm_data + (dat[u] ? j : 0)) * a.C + c0;      // (a padded row shadows a data row, value dropped)
+        }
         if constexpr (MODE == 2) {
           if (a.dy_rows_per_group > 0) ra[u].load(A + (int64_t)((uint32_t)mc / (uint32_t)a.dy_rows_per_group) * a.C + c0);
-          else ra[u].load(A + off);
+          else ra[u].load(A + (a.a_compact ? offc : off));
         } else {
-          ra[u].load(A + off);
+          ra[u].load(A + (a.a_compact ? offc : off));
         }
         if constexpr (MODE == 2 || MODE == 3 || MODE == 4) {
-          if (B) rb[u].load(B + off);
+          if (B) rb[u].load(B + (a.b_compact ? offc : off));
           else rb[u].zero();
         }
+        offo[u] = a.out_compact ? offc : off;
       }
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
@@ -222,11 +239,12 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs a) {
           }
         }
         float vo[CH];
+        const bool a_zero = a.a_compact && !dat[u], b_zero = a.b_compact && !dat[u];
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
-          const float va_ = ra[u].get(i);
+          const float va_ = a_zero ? 0.f : ra[u].get(i);
           float vb_ = 0.f;
-          if constexpr (MODE == 2 || MODE == 3 || MODE == 4) vb_ = rb[u].get(i);
+          if constexpr (MODE == 2 || MODE == 3 || MODE == 4) vb_ = b_zero ? 0.f : rb[u].get(i);
           (void)vb_;
           if constexpr (MODE == 0) {
             acc[0][i] += va_;
@@ -257,7 +275,7 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs a) {
           }
         }
         if constexpr (MODE != 0) {
-          if (O) stv<T, CH>(O + off, vo);
+          if (O && (!a.out_compact || dat[u])) stv<T, CH>(O + offo[u], vo);
         }
       }
     }
@@ -537,11 +555,20 @@ extern "C" int pb_bn_fold_batch(const int64_t* desc, int count, int device, void
   return 0;
 }
 
+static int check_frame_map(int64_t M, int64_t fm_full, int64_t fm_data, int64_t fm_lead, const char* who) {
+  if (fm_full <= 0) return 0;
+  PB_CHECK_ARG(M % fm_full == 0 && fm_data > 0 && fm_lead >= 0 && fm_lead + fm_data <= fm_full && M < 0x7fffffffLL,
+               "%s: bad frame map (M %lld, rows per clip %lld, data rows %lld at %lld)", who, (long long)M, (long long)fm_full,
+               (long long)fm_data, (long long)fm_lead);
+  return 0;
+}
+
 extern "C" int pb_affine_act_fwd(const void* x, void* y, int64_t M, int C, pb_dtype dtype, const float* scale,
                                  const float* shift, const float* mean, pb_act act, float slope,
                                  const float* row_scale, const float* row_shift, int64_t rows_per_group, float* stats,
-                                 int device, void* stream) {
+                                 int64_t fm_full, int64_t fm_data, int64_t fm_lead, int device, void* stream) {
   PB_CHECK_ARG(x && y, "pb_affine_act_fwd: null pointer");
+  if (int rc = check_frame_map(M, fm_full, fm_data, fm_lead, "pb_affine_act_fwd")) return rc;
   if (int rc = check_mc(M, C, dtype, "pb_affine_act_fwd")) return rc;
   PB_CHECK_ARG(!(row_scale || row_shift) || rows_per_group > 0, "pb_affine_act_fwd: row_scale/shift need rows_per_group > 0");
   if (M == 0) return 0;
@@ -550,6 +577,7 @@ extern "C" int pb_affine_act_fwd(const void* x, void* y, int64_t M, int C, pb_dt
   a.a = x; a.out = y; a.M = M; a.C = C; a.scale = scale; a.shift = shift; a.mean = mean; a.act = (int)act; a.slope = slope;
   a.row_scale = row_scale; a.row_shift = row_shift; a.rows_per_group = rows_per_group > 0 ? rows_per_group : 1;
   a.sums = stats; a.dy_mul = 1.f;
+  a.fm_full = fm_full; a.fm_data = fm_data; a.fm_lead = fm_lead; a.a_compact = fm_full > 0;    // x compact -> y full
   launch_ew_dt<1>(a, dtype, (hipStream_t)stream);
   PB_LAUNCH_CHECK();
   return 0;
@@ -558,9 +586,10 @@ extern "C" int pb_affine_act_fwd(const void* x, void* y, int64_t M, int C, pb_dt
 extern "C" int pb_act_bwd_reduce(const void* dy, const void* z, void* g_out, int64_t M, int C, pb_dtype dtype,
                                  const float* scale, const float* shift, pb_act act, float slope,
                                  const float* row_scale, int64_t rows_per_group, int64_t dy_rows_per_group,
-                                 float dy_mul, const float* mean, const float* rstd, float* sums, int device,
-                                 void* stream) {
+                                 float dy_mul, const float* mean, const float* rstd, float* sums, int64_t fm_full,
+                                 int64_t fm_data, int64_t fm_lead, int device, void* stream) {
   PB_CHECK_ARG(dy && z, "pb_act_bwd_reduce: null pointer");
+  if (int rc = check_frame_map(M, fm_full, fm_data, fm_lead, "pb_act_bwd_reduce")) return rc;
   if (int rc = check_mc(M, C, dtype, "pb_act_bwd_reduce")) return rc;
   PB_CHECK_ARG(!row_scale || rows_per_group > 0, "pb_act_bwd_reduce: row_scale needs rows_per_group > 0");
   if (M == 0) return 0;
@@ -569,6 +598,8 @@ extern "C" int pb_act_bwd_reduce(const void* dy, const void* z, void* g_out, int
   a.a = dy; a.b = z; a.out = g_out; a.M = M; a.C = C; a.scale = scale; a.shift = shift; a.act = (int)act;
   a.slope = slope; a.row_scale = row_scale; a.rows_per_group = rows_per_group > 0 ? rows_per_group : 1;
   a.dy_rows_per_group = dy_rows_per_group; a.dy_mul = dy_mul; a.mean = mean; a.rstd = rstd; a.sums = sums;
+  a.fm_full = fm_full; a.fm_data = fm_data; a.fm_lead = fm_lead;      // dy full, z compact -> g compact, sums over all rows
+  a.b_compact = a.out_compact = fm_full > 0;
   launch_ew_dt<2>(a, dtype, (hipStream_t)stream);
   PB_LAUNCH_CHECK();
   return 0;

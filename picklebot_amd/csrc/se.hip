@@ -1,6 +1,7 @@
 // Squeeze-excite gate (SEBlock3D, mobilenet.py:11-26): the two 1x1x1 convolutions on the pooled
 // [N][C] vector are tiny GEMVs - one workgroup per clip, wavefront-shuffle dot products.
 #include "pb_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -128,19 +129,22 @@ struct SeFwdArgs {
   const float* wproj;     // optional fp32 [N][C]: the projection conv's weights ...
   bf16_t* wbs;            // ... scaled per clip for the LDS-DMA GEMM: out bf16 [G][N][C] = wproj[n][c] * scale[g][c]
   int G, C, Cm, N;
+  int assoc;              // slot-sum association (slot_sum_to_lds)
 };
 
 // sum over the slots of part[.][g][c] for c = tid, tid + nthreads, ... -> dst (LDS).  Eight loads in flight per thread:
 // with 4 the loop was a chain of ~50 memory round trips (20 us per launch).
-__device__ __forceinline__ void slot_sum_to_lds(const float* part, int slots, int G, int g, int C, float* dst, int nthreads) {
+// `assoc` selects one of two equally valid associations of the fp32 sum (PB_SE_ASSOC, read per call by the launchers - a test
+// knob: the parity suite runs the train-mode fixtures under both, so no fixture can depend on one summation order).
+__device__ __forceinline__ void slot_sum_to_lds(const float* part, int slots, int G, int g, int C, float* dst, int nthreads, int assoc = 0) {
   const int n8 = slots & ~7;
   for (int c = threadIdx.x; c < C; c += nthreads) {
     const float* p = part + (int64_t)g * C + c;
     const int64_t st = (int64_t)G * C;
-    // Eight chains (chain k adds the slots k, k+8, ... of the full groups of eight, in order), the tail of fewer than eight
-    // slots goes to chain 0, then ((0+1)+(2+3))+((4+5)+(6+7)): the association the goldens were validated with.  Sixteen
-    // loads are in flight per round and the tail's loads are issued together (a tail loop of single loads was one
-    // memory round trip per slot).
+    // Eight chains (chain k adds the slots k, k+8, ... of the full groups of eight, in order); assoc 0: the tail of fewer than
+    // eight slots goes to chain 0, then ((0+1)+(2+3))+((4+5)+(6+7)); assoc 1: the tail goes to chain 7 and the chains are
+    // added left to right.  Sixteen loads are in flight per round and the tail's loads are issued together (a tail loop of
+    // single loads was one memory round trip per slot).
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int sl = 0; sl < n8; sl += 16) {
       float v[16];
@@ -152,9 +156,15 @@ __device__ __forceinline__ void slot_sum_to_lds(const float* part, int slots, in
     float t[7];
 #pragma unroll
     for (int u = 0; u < 7; ++u) t[u] = n8 + u < slots ? p[(n8 + u) * st] : 0.f;
+    if (assoc == 0) {
 #pragma unroll
-    for (int u = 0; u < 7; ++u) acc[0] += t[u];
-    dst[c] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+      for (int u = 0; u < 7; ++u) acc[0] += t[u];
+      dst[c] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    } else {
+#pragma unroll
+      for (int u = 0; u < 7; ++u) acc[7] += t[u];
+      dst[c] = ((((((acc[0] + acc[1]) + acc[2]) + acc[3]) + acc[4]) + acc[5]) + acc[6]) + acc[7];
+    }
   }
 }
 
@@ -166,7 +176,7 @@ __global__ __launch_bounds__(SE_HT) void se_hidden_kernel(SeFwdArgs a) {
   extern __shared__ float sm[];                 // pool[C]
   const int g = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int C = a.C;
-  slot_sum_to_lds(a.part, a.slots, a.G, g, C, sm, SE_HT);
+  slot_sum_to_lds(a.part, a.slots, a.G, g, C, sm, SE_HT, a.assoc);
   __syncthreads();
   if (blockIdx.x == 0)
     for (int c = threadIdx.x; c < C; c += SE_HT) a.pool[(int64_t)g * C + c] = sm[c];
@@ -270,6 +280,7 @@ struct SeBwdArgs {
   float* g_shift;         // out [G][C]
   float* work;            // out [G][C + Cm]: dpre2 | dh (read by the weight-gradient kernel)
   int G, C, Cm;
+  int assoc;
 };
 
 constexpr int SEB_T = 1024, SEB_W = SEB_T / 64;
@@ -282,7 +293,7 @@ __global__ __launch_bounds__(SEB_T) void se_bwd_dh_kernel(SeBwdArgs a) {
   const int C = a.C, Cm = a.Cm;
   float* dpre2 = sm;
   float* red = sm + C;
-  slot_sum_to_lds(a.dpart, a.slots, a.G, g, C, dpre2, SEB_T);
+  slot_sum_to_lds(a.dpart, a.slots, a.G, g, C, dpre2, SEB_T, a.assoc);
   __syncthreads();
   for (int c = tid; c < C; c += SEB_T) {
     const float sc = a.scale[(int64_t)g * C + c];
@@ -356,6 +367,12 @@ __global__ __launch_bounds__(SEB_T) void se_bwd_gshift_kernel(SeBwdArgs a) {
 
 }  // namespace
 
+// PB_SE_ASSOC (test knob, read on every call): which association slot_sum_to_lds uses
+static int se_assoc() {
+  const char* e = getenv("PB_SE_ASSOC");
+  return e && e[0] == '1' ? 1 : 0;
+}
+
 extern "C" int pb_se_fc_fwd(const float* pool, float inv_count, const float* w1, const float* b1, const float* w2,
                             const float* b2, float* scale, float* hidden, int G, int C, int Cm, int device,
                             void* stream) {
@@ -407,7 +424,7 @@ extern "C" int pb_se_fused_fwd(const float* pool_part, int slots, float inv_coun
                "pb_se_fused_fwd: scaled weights need C %% 8 == 0 and 16-byte aligned pointers");
   PB_ENTER(device);
   hipStream_t st = (hipStream_t)stream;
-  SeFwdArgs a = {pool_part, slots, inv_count, w1, b1, w2, b2, pool, scale, hidden, wproj, (bf16_t*)wbs_bf16, G, C, Cm, N};
+  SeFwdArgs a = {pool_part, slots, inv_count, w1, b1, w2, b2, pool, scale, hidden, wproj, (bf16_t*)wbs_bf16, G, C, Cm, N, se_assoc()};
   hipLaunchKernelGGL(se_hidden_kernel, dim3((unsigned)pb_cdiv(Cm, SE_JB), (unsigned)G), dim3(SE_HT), (size_t)C * 4, st, a);
   hipLaunchKernelGGL(se_scale_kernel, dim3((unsigned)pb_cdiv(C, 64), (unsigned)G), dim3(256), ((size_t)Cm + 64) * 4, st, a);
   PB_LAUNCH_CHECK();
@@ -424,7 +441,7 @@ extern "C" int pb_se_fused_bwd(const float* dscale_part, int slots, const float*
   PB_CHECK_ARG(G > 0 && G <= 65535 && C > 0 && Cm > 0 && C <= 8192 && Cm <= 8192, "pb_se_fused_bwd: bad sizes G=%d C=%d Cm=%d", G, C, Cm);
   PB_ENTER(device);
   hipStream_t st = (hipStream_t)stream;
-  SeBwdArgs a = {dscale_part, slots, inv_count, scale, hidden, w1, w2, g_shift, work, G, C, Cm};
+  SeBwdArgs a = {dscale_part, slots, inv_count, scale, hidden, w1, w2, g_shift, work, G, C, Cm, se_assoc()};
   hipLaunchKernelGGL(se_bwd_dh_kernel, dim3((unsigned)pb_cdiv(Cm, 64), (unsigned)G), dim3(SEB_T), ((size_t)C + SEB_T) * 4, st, a);
   hipLaunchKernelGGL(se_bwd_gshift_kernel, dim3((unsigned)pb_cdiv(C, 64), (unsigned)G), dim3(SEB_T), ((size_t)Cm + SEB_T) * 4, st, a);
   const int64_t total = 2LL * C * Cm + C + Cm;

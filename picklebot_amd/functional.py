@@ -140,21 +140,23 @@ class _BnCtx:
     __slots__ = ("scale", "shift", "mean", "rstd", "training", "count", "beta")
 
 
-def _bn_act_backward(dy2, z2, bnc, gamma, act, slope, row_scale, rows_per_group, dy_rows_per_group=0, dy_mul=1.0):
-    """Gradient through [row_scale *] act(BN(z)) -> (dz, dgamma, dbeta)."""
+def _bn_act_backward(dy2, z2, bnc, gamma, act, slope, row_scale, rows_per_group, dy_rows_per_group=0, dy_mul=1.0, frame_map=None):
+    """Gradient through [row_scale *] act(BN(z)) -> (dz, dgamma, dbeta).  frame_map (kernels.affine_act_fwd): z2 and the
+    returned dz are compact (data frames only), dy2 is the full gradient; needs an activation (the g tensor carries the map)."""
     C = z2.shape[1]
+    fmkw = dict(frame_map=frame_map) if frame_map is not None else {}
     if bnc is None:
         g = K.act_bwd_reduce(dy2, z2, act=act, slope=slope, row_scale=row_scale, rows_per_group=rows_per_group,
-                             dy_rows_per_group=dy_rows_per_group, dy_mul=dy_mul)
+                             dy_rows_per_group=dy_rows_per_group, dy_mul=dy_mul, **fmkw)
         return g, None, None
     sums = _zeros((K.REPL, 2, C), z2)
     # Without an activation behind the BatchNorm, g = dy * dropout-mask is not materialised: the reduction keeps only
     # the two sums and the final pass applies the mask itself.  (With an activation, recomputing act' in the final
     # pass was measured slower on MI355X than writing g once - 0.79+0.65 ms vs 0.83+0.46 ms per step - so g stays.)
-    direct = act == "none" and dy_rows_per_group == 0 and dy_mul == 1.0
+    direct = act == "none" and dy_rows_per_group == 0 and dy_mul == 1.0 and frame_map is None
     g = K.act_bwd_reduce(dy2, z2, scale=bnc.scale, shift=bnc.beta, act=act, slope=slope, row_scale=row_scale,
                          rows_per_group=rows_per_group, dy_rows_per_group=dy_rows_per_group, dy_mul=dy_mul,
-                         mean=bnc.mean, rstd=bnc.rstd, sums=sums, want_g=not direct)
+                         mean=bnc.mean, rstd=bnc.rstd, sums=sums, want_g=not direct, **fmkw)
     A, B, Cc, dgamma, dbeta = K.bn_bwd_finalize(sums, bnc.count, gamma, bnc.mean, bnc.rstd, bnc.training,
                                                 gamma is not None)
     if direct:
@@ -193,28 +195,30 @@ class _Bottleneck(torch.autograd.Function):
         training_bn = has_bn and training
         stats = _zeros((K.REPL, 2, Cout), x5) if training_bn else None
         pool = se_scale = hidden = wbs = None
-        # Temporal stride with a (1,k,k) kernel (mobilenet.py:67-75: the scalar stride also strides T): an output frame reads
-        # exactly ONE input frame, so with stride 2 half of the input frames are never read.  The used frames are gathered
-        # first: the expansion conv, the depthwise conv and all their backward passes run on those rows only (the reference
-        # expands every frame), and the depthwise conv sees a temporal stride of 1 with `lead` zero frames in front.
-        tskip = None
-        xs5, dkernel, dstride, dpad, dpad_back = x5, kernel, stride, pad, None
-        if kernel[0] == 1 and stride[0] > 1 and hasattr(K, "frames_gather"):
+        # A (1,k,k) depthwise kernel whose scalar stride / padding also apply to T (mobilenet.py:67-75): an output frame reads
+        # exactly ONE input frame - or none (temporal padding: exact-zero output frames, T grows by 2(k//2) at stride 1), and
+        # with stride 2 half of the input frames are never read.  All EXPANDED-side tensors are therefore kept COMPACT: e, d, dS,
+        # dE hold only the Tu frames that carry data (the reference expands every input frame and drags the zero frames
+        # through the projection conv); only the block's narrow output z gets its zero frames back (frames_scatter) in
+        # front of BatchNorm, whose statistics count them.
+        To = Tu = None
+        compact = None                                # (t0, tstep, Tu, lead): input frames t0 + j * tstep <-> output frame lead + j
+        xs5, dkernel, dstride, dpad = x5, kernel, stride, pad
+        fused = bool(getattr(K, "xdw_supported", None) and K.xdw_enabled() and K.xdw_supported(x5, E, kernel, stride, pad))
+        if kernel[0] == 1 and not fused and hasattr(K, "frames_gather"):
             To_full = (T + 2 * pad[0] - 1) // stride[0] + 1
             used = [to for to in range(To_full) if 0 <= to * stride[0] - pad[0] < T]
-            if used and len(used) < T:
-                lead, Tu = used[0], len(used)
+            if used and (len(used) < To_full or stride[0] > 1):
+                lead, Tu, To = used[0], len(used), To_full
                 t0 = used[0] * stride[0] - pad[0]
-                tskip = (t0, stride[0], Tu)
-                xs5 = K.frames_gather(x5, t0, stride[0], Tu)
+                compact = (t0, stride[0], Tu, lead)
+                if stride[0] > 1 or Tu < T:
+                    xs5 = K.frames_gather(x5, t0, stride[0], Tu)
                 dstride = (1,) + tuple(stride[1:])
-                dpad = (lead,) + tuple(pad[1:])
-                dpad_back = (To_full - lead - Tu,) + tuple(pad[1:])
+                dpad = (0,) + tuple(pad[1:])
         Ts = xs5.shape[1]
         x2 = xs5.view(-1, Cin)
-        # expansion conv -> depthwise conv in ONE kernel where the shape allows (bf16, (1,k,k)): the expanded tensor e never
-        # reaches HBM - not written, not read back, not saved (backward recomputes its tiles from x)
-        fused = bool(tskip is None and getattr(K, "xdw_supported", None) and K.xdw_enabled() and K.xdw_supported(x5, E, kernel, stride, pad))
+        # expansion conv -> depthwise conv in ONE kernel (opt-in, bf16, (1,k,k)): the expanded tensor e never reaches HBM
         e5 = None
         if fused:
             d5, pool_part = K.xdw_fwd(x5, w1.view(E, Cin), wdw.view(E, -1), kernel, stride, pad, pool=has_se)
@@ -224,15 +228,23 @@ class _Bottleneck(torch.autograd.Function):
             if has_se:
                 # squeeze partial sums ride on the depthwise kernel; ONE launch turns them into pool / hidden / scale and the
                 # per-clip scaled bf16 projection weights (the squeeze-excite scale is folded into the GEMM's weights)
-                d5, pool_part = K.dw_fwd_pool(e5, wdw.view(E, -1), dkernel, dstride, dpad, dpad_back)
+                d5, pool_part = K.dw_fwd_pool(e5, wdw.view(E, -1), dkernel, dstride, dpad)
             else:
-                d5 = K.dw_fwd(e5, wdw.view(E, -1), dkernel, dstride, dpad, dpad_back)
-        To, Ho, Wo = d5.shape[1:4]
-        R2 = To * Ho * Wo
+                d5 = K.dw_fwd(e5, wdw.view(E, -1), dkernel, dstride, dpad)
+        Td, Ho, Wo = d5.shape[1:4]                    # Td = frames of d (compact: the data frames only)
+        if To is None:
+            To = Td
+        R2, Rd = To * Ho * Wo, Td * Ho * Wo           # rows per clip: of the block's output / of d
         d2 = d5.view(-1, E)
+
+        def expand(t2, fill=None):                    # [N*Rd, Cout] rows of the data frames -> all To frames
+            if compact is None or Td == To:
+                return t2
+            return K.frames_scatter(t2.view(N, Td, Ho, Wo, Cout), To, compact[3], 1, fill).view(-1, Cout)
+
         if has_se:
             Cm = se_w1.shape[0]
-            want_scaled = d2.dtype == torch.bfloat16 and R2 >= 128
+            want_scaled = d2.dtype == torch.bfloat16 and Rd >= 128
             pool, se_scale, hidden, wbs = K.se_fused_fwd(pool_part, 1.0 / R2, se_w1.view(Cm, E), se_b1, se_w2.view(E, Cm), se_b2,
                                                          wproj=w2.view(Cout, E), want_scaled=want_scaled)
         need_grad = cfg["need_grad"]
@@ -241,23 +253,30 @@ class _Bottleneck(torch.autograd.Function):
             # inference: BatchNorm folds into the projection GEMM's epilogue, z is never materialised
             eps, momentum = cfg["bn"]
             scale, shift, _, _ = _bn_forward(d2, None, 1, gamma, beta, rmean, rvar, eps, momentum, False, infer=True)
-            y2 = K.pw_fwd(d2, w2.view(Cout, E), row_scale=se_scale, rows_per_group=R2, out_scale=scale,
+            y2 = K.pw_fwd(d2, w2.view(Cout, E), row_scale=se_scale, rows_per_group=Rd, out_scale=scale,
                           out_shift=shift, out_act=act, out_slope=slope, scaled_weights=wbs)
+            if compact is not None and Td != To:      # the padded frames: z = 0 there, so y = act(shift) per channel
+                y2 = expand(y2, K.act_row(shift, act, slope, y2.dtype))
             return y2.view(N, To, Ho, Wo, Cout)
-        z2 = K.pw_fwd(d2, w2.view(Cout, E), row_scale=se_scale, rows_per_group=R2, stats=stats, scaled_weights=wbs)
+        # z stays COMPACT too (the data frames only): the BatchNorm-apply and its backward passes walk the full output rows
+        # and read z as 0 on the padded frames (frame map), so the zero frames are never written or read back
+        z2 = K.pw_fwd(d2, w2.view(Cout, E), row_scale=se_scale, rows_per_group=Rd, stats=stats, scaled_weights=wbs)
+        fmap = (R2, Rd, compact[3] * Ho * Wo) if (compact is not None and Td != To) else None
+        rows_full = N * R2
         scale = shift = None
         if has_bn:
             eps, momentum = cfg["bn"]
             bnc = _BnCtx()
-            bnc.scale, bnc.shift, bnc.mean, bnc.rstd = _bn_forward(z2, stats, z2.shape[0], gamma, beta, rmean, rvar,
+            bnc.scale, bnc.shift, bnc.mean, bnc.rstd = _bn_forward(z2, stats, rows_full, gamma, beta, rmean, rvar,
                                                                    eps, momentum, training, cfg.get("nbt"), infer=not training and not cfg["need_grad"])
-            bnc.training, bnc.count, bnc.beta = training, z2.shape[0], beta
+            bnc.training, bnc.count, bnc.beta = training, rows_full, beta
             scale, shift = bnc.scale, beta
+        fmkw = dict(frame_map=fmap) if fmap is not None else {}
         y2 = K.affine_act_fwd(z2, scale, shift, act, slope, row_scale=drop, rows_per_group=R2,
-                              mean=bnc.mean if bnc is not None else None)
+                              mean=bnc.mean if bnc is not None else None, **fmkw)
         if need_grad:
             ctx.cfg, ctx.bnc, ctx.dims = cfg, bnc, (N, T, H, W, Cin, E, Cout, To, Ho, Wo)
-            ctx.fused, ctx.tskip, ctx.dconv = fused, tskip, (dkernel, dstride, dpad)
+            ctx.fused, ctx.compact, ctx.dconv, ctx.fmap = fused, compact, (dkernel, dstride, dpad), fmap
             ctx.save_for_backward(xs5, e5, d5, z2, w1, wdw, w2, se_w1, se_w2, pool, se_scale, hidden, gamma, drop)
         return y2.view(N, To, Ho, Wo, Cout)
 
@@ -267,20 +286,24 @@ class _Bottleneck(torch.autograd.Function):
         cfg, bnc = ctx.cfg, ctx.bnc
         N, T, H, W, Cin, E, Cout, To, Ho, Wo = ctx.dims
         kernel, stride, pad = cfg["kernel"], cfg["stride"], cfg["pad"]
-        R2 = To * Ho * Wo
+        compact = ctx.compact
+        Td, Ts = d5.shape[1], x5.shape[1]             # frames of d / of the (gathered) block input
+        R2, Rd = To * Ho * Wo, Td * Ho * Wo
         has_se = se_w1 is not None
+        # z2 and dz are compact (data frames only): the padded output frames reach no input frame and d is zero there, so their
+        # dz rows are never needed - only their share of the BatchNorm sums, which the frame-mapped reduction includes
         rows, rpg = _split_broadcast_grad(dy5)
         if rows is not None:
-            dz, dgamma, dbeta = _bn_act_backward(rows, z2, bnc, gamma, cfg["act"], cfg["slope"], drop, R2, rpg, 1.0)
+            dz, dgamma, dbeta = _bn_act_backward(rows, z2, bnc, gamma, cfg["act"], cfg["slope"], drop, R2, rpg, 1.0, frame_map=ctx.fmap)
         else:
             dy2 = _contig5(dy5).view(-1, Cout)
-            dz, dgamma, dbeta = _bn_act_backward(dy2, z2, bnc, gamma, cfg["act"], cfg["slope"], drop, R2)
+            dz, dgamma, dbeta = _bn_act_backward(dy2, z2, bnc, gamma, cfg["act"], cfg["slope"], drop, R2, frame_map=ctx.fmap)
         d2 = d5.view(-1, E)
         dw2, dwdw, dw1 = _zeros_many(x5, (Cout, E), (E, wdw[0].numel()), (E, Cin))
         g_scale = g_shift = dse_w1 = dse_b1 = dse_w2 = dse_b2 = None
         with K.deferred_reductions():      # the three weight gradients' partial tiles are added up by ONE launch
             # projection conv: weight gradient sees the SE-scaled input, data gradient is w.r.t. it
-            K.pw_bwd_weight(dz, d2, dw2, row_scale=se_scale, rows_per_group=R2)
+            K.pw_bwd_weight(dz, d2, dw2, row_scale=se_scale, rows_per_group=Rd)
             dS2 = K.pw_fwd(dz, w2.view(Cout, E), w_transposed=True)
             if has_se:
                 Cm = se_w1.shape[0]
@@ -289,9 +312,8 @@ class _Bottleneck(torch.autograd.Function):
                                                                          se_w1.view(Cm, E), se_w2.view(E, Cm))
                 g_scale = se_scale
                 dse_w1, dse_w2 = dse_w1.view_as(se_w1), dse_w2.view_as(se_w2)
-            dS5 = dS2.view(N, To, Ho, Wo, E)
-            dkernel, dstride, dpad = ctx.dconv       # (x5 here = the gathered frames when the block strides T)
-            Ts = x5.shape[1]
+            dS5 = dS2.view(N, Td, Ho, Wo, E)
+            dkernel, dstride, dpad = ctx.dconv       # (x5 here = the gathered frames when the block skips input frames)
             if ctx.fused:
                 K.xdw_bwd_weight(dS5, x5, w1.view(E, Cin), dwdw, kernel, stride, pad, g_scale, g_shift)
             else:
@@ -302,8 +324,8 @@ class _Bottleneck(torch.autograd.Function):
             dx5 = None
             if ctx.needs_input_grad[0]:
                 dx5 = K.pw_fwd(dE2, w1.view(E, Cin), w_transposed=True).view(N, Ts, H, W, Cin)
-                if ctx.tskip is not None:                 # exact zeros in the frames the block never read
-                    dx5 = K.frames_scatter(dx5, T, ctx.tskip[0], ctx.tskip[1])
+                if compact is not None and Ts != T:       # exact zeros in the input frames the block never read
+                    dx5 = K.frames_scatter(dx5, T, compact[0], compact[1])
         return (dx5, dw1.view_as(w1), dwdw.view_as(wdw), dw2.view_as(w2), dse_w1, dse_b1, dse_w2, dse_b2, dgamma,
                 dbeta, None, None, None, None)
 

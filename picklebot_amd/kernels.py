@@ -725,22 +725,26 @@ def frames_gather(x, t0, tstep, count):
         raise ValueError(f"frames_gather: frames {t0}+{tstep}*[0,{count}) of {tuple(x.shape)}")
     out = torch.empty((N, count) + tuple(x.shape[2:]), dtype=x.dtype, device=x.device)
     dev, st = _dev_stream(x)
-    _launch("frames_kernel", _nb(out) * 2, "pb_frames_gather", _p(x), _p(out), N, T, count, fb, int(t0), int(tstep), 0, dev, st,
+    _launch("frames_kernel", _nb(out) * 2, "pb_frames_gather", _p(x), _p(out), N, T, count, fb, int(t0), int(tstep), 0, None, 0, dev, st,
             detail=f"gather {tuple(x.shape)} -> T{count}")
     return out
 
 
-def frames_scatter(xs, T, t0, tstep):
-    """xs [N,Tu,H,W,C] -> [N,T,H,W,C] with xs[:, j] at frame t0 + j*tstep and exact zeros in all other frames."""
+def frames_scatter(xs, T, t0, tstep, fill=None):
+    """xs [N,Tu,H,W,C] -> [N,T,H,W,C] with xs[:, j] at frame t0 + j*tstep; every other frame holds exact zeros, or the
+    per-channel row `fill` [C] (same dtype as xs) repeated over its pixels."""
     _ndhwc(xs, "xs")
     N, Tu = xs.shape[:2]
+    C = xs.shape[4]
     fb = xs[0, 0].numel() * xs.element_size()
     if fb % 16:
         raise ValueError("frames_scatter: frame size must be a multiple of 16 bytes")
+    if fill is not None and (fill.dtype != xs.dtype or tuple(fill.shape) != (C,) or not fill.is_contiguous() or (C * xs.element_size()) % 16):
+        raise ValueError("frames_scatter: fill must be a contiguous [C] row of the activations' dtype (C * itemsize a multiple of 16)")
     out = torch.empty((N, T) + tuple(xs.shape[2:]), dtype=xs.dtype, device=xs.device)
     dev, st = _dev_stream(xs)
-    _launch("frames_kernel", _nb(out, xs), "pb_frames_gather", _p(xs), _p(out), N, Tu, T, fb, int(t0), int(tstep), 1, dev, st,
-            detail=f"scatter T{Tu} -> {tuple(out.shape)}")
+    _launch("frames_kernel", _nb(out, xs), "pb_frames_gather", _p(xs), _p(out), N, Tu, T, fb, int(t0), int(tstep), 1, _p(fill),
+            C * xs.element_size() if fill is not None else 0, dev, st, detail=f"scatter T{Tu} -> {tuple(out.shape)}")
     return out
 
 
@@ -828,29 +832,58 @@ def bn_finalize(stats, count, gamma, beta, eps, momentum, running_mean, running_
     return out[0], out[1], out[2], out[3]
 
 
+def _frame_map(frame_map, rows_compact, who):
+    """frame_map = (rows per clip of the full tensor, data rows per clip, first data row) -> (clips, full M, map args)."""
+    if frame_map is None:
+        return None
+    full, data, lead = (int(v) for v in frame_map)
+    if full <= 0 or data <= 0 or lead < 0 or lead + data > full or rows_compact % data:
+        raise ValueError(f"{who}: bad frame map {frame_map} for {rows_compact} compact rows")
+    return rows_compact // data * full, full, data, lead
+
+
 def affine_act_fwd(x, scale=None, shift=None, act="none", slope=0.0, row_scale=None, rows_per_group=0, stats=None,
-                   row_shift=None, mean=None):
-    """y = act((x-mean)*scale+shift) * row_scale[g] + row_shift[g]; stats[REPL,2,C] += (sum y, sum y^2)."""
+                   row_shift=None, mean=None, frame_map=None):
+    """y = act((x-mean)*scale+shift) * row_scale[g] + row_shift[g]; stats[REPL,2,C] += (sum y, sum y^2).
+    frame_map (rows per clip, data rows per clip, first data row): x is COMPACT (the data rows only, exact zeros elsewhere:
+    the frames a (1,k,k) depthwise conv pads in time), y is the full tensor; rows_per_group counts full rows."""
     _rows(x, "x")
     M, C = x.shape
+    fm = _frame_map(frame_map, M, "affine_act_fwd")
+    if fm is not None:
+        M = fm[0]
     _f32(scale, (C,), "scale"); _f32(shift, (C,), "shift"); _f32(stats, (REPL, 2, C), "stats"); _f32(mean, (C,), "mean")
     if row_scale is not None or row_shift is not None:
         if rows_per_group <= 0 or M % rows_per_group:
             raise ValueError("affine_act_fwd: rows_per_group must divide M")
         _f32(row_scale, (M // rows_per_group, C), "row_scale")
         _f32(row_shift, (M // rows_per_group, C), "row_shift")
-    y = torch.empty_like(x)
+    y = torch.empty((M, C), dtype=x.dtype, device=x.device)
     dev, st = _dev_stream(x)
+    f1, f2, f3 = fm[1:] if fm is not None else (0, 0, 0)
     _launch("ew_kernel<affine_act>", _nb(x, y), "pb_affine_act_fwd", _p(x), _p(y), M, C, _dt(x), _p(scale), _p(shift), _p(mean), ACT[act], float(slope),
-            _p(row_scale), _p(row_shift), int(rows_per_group), _p(stats), dev, st, detail=f"M{M} C{C}")
+            _p(row_scale), _p(row_shift), int(rows_per_group), _p(stats), f1, f2, f3, dev, st, detail=f"M{M} C{C}")
     return y
 
 
+def act_row(shift, act, slope, dtype):
+    """act(shift) per channel as a [C] row of `dtype`: what a folded inference BatchNorm + activation makes of an exact-zero
+    pre-activation (the frames a (1,k,k) depthwise conv pads in time); the fill row of frames_scatter."""
+    _f32(shift, name="shift")
+    C = shift.shape[0]
+    return affine_act_fwd(shift.view(1, C), act=act, slope=slope).to(dtype).view(C)      # (the cast of C values: host-side glue)
+
+
 def act_bwd_reduce(dy, z, *, scale=None, shift=None, act="none", slope=0.0, row_scale=None, rows_per_group=0,
-                   dy_rows_per_group=0, dy_mul=1.0, mean=None, rstd=None, sums=None, want_g=True):
-    """g = dy*row_scale*act'(z*scale+shift) (returned when want_g); sums[2,C] += (sum g, sum g*xhat)."""
+                   dy_rows_per_group=0, dy_mul=1.0, mean=None, rstd=None, sums=None, want_g=True, frame_map=None):
+    """g = dy*row_scale*act'(z*scale+shift) (returned when want_g); sums[2,C] += (sum g, sum g*xhat).
+    frame_map (see affine_act_fwd): z and the returned g are COMPACT, dy is the full tensor, the sums run over all full rows
+    (z = 0 on the padded ones)."""
     _rows(z, "z"); _rows(dy, "dy")
     M, C = z.shape
+    fm = _frame_map(frame_map, M, "act_bwd_reduce")
+    if fm is not None:
+        M = fm[0]
     if dy_rows_per_group > 0:
         if M % dy_rows_per_group or tuple(dy.shape) != (M // dy_rows_per_group, C):
             raise ValueError("act_bwd_reduce: broadcast dy shape mismatch")
@@ -867,9 +900,10 @@ def act_bwd_reduce(dy, z, *, scale=None, shift=None, act="none", slope=0.0, row_
         _f32(row_scale, (M // rows_per_group, C), "row_scale")
     g = torch.empty_like(z) if want_g else None
     dev, st = _dev_stream(z)
+    f1, f2, f3 = fm[1:] if fm is not None else (0, 0, 0)
     _launch("ew_kernel<act_bwd>", _nb(dy, z, g), "pb_act_bwd_reduce", _p(dy), _p(z), _p(g), M, C, _dt(z), _p(scale), _p(shift), ACT[act], float(slope),
             _p(row_scale), int(rows_per_group), int(dy_rows_per_group), float(dy_mul), _p(mean), _p(rstd), _p(sums),
-            dev, st, detail=f"M{M} C{C}")
+            f1, f2, f3, dev, st, detail=f"M{M} C{C}")
     return g
 
 

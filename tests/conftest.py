@@ -113,6 +113,6 @@ def golden():
 
 
 def golden_mode(gold, mode):
-    """Sub-dictionary of a grad_<case>.npz fixture for one protocol mode ("evalgrad" / "train8"), prefix stripped."""
+    """Sub-dictionary of a grad_<case>.npz fixture for one protocol mode ("evalgrad" / "train"), prefix stripped."""
     p = mode + "/"
     return {k[len(p):]: v for k, v in gold.items() if k.startswith(p)}

@@ -707,3 +707,32 @@ def test_frames_gather_scatter(K, N, T, frame, t0, step, dtype):
     assert torch.equal(back.cpu(), R.frames_scatter(R.frames_gather(x, t0, step, count), T, t0, step))
     unread = [t for t in range(T) if t < t0 or (t - t0) % step]
     assert all(float(back[:, t].abs().max()) == 0.0 for t in unread)
+    fill = rnd((frame[-1],), dtype, 62)
+    filled = K.frames_scatter(got, T, t0, step, fill=dev(fill))
+    assert torch.equal(filled.cpu(), R.frames_scatter(R.frames_gather(x, t0, step, count), T, t0, step, fill=fill))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("G,full,data,lead,C", [(3, 40, 24, 8, 16), (2, 90, 54, 18, 72), (4, 35, 21, 0, 24), (2, 33, 11, 22, 160), (1, 12, 12, 0, 8)])
+def test_norm_act_frame_map(K, G, full, data, lead, C, dtype):
+    """BatchNorm-apply and its backward reduction on a COMPACT pre-activation (the data frames only; the frames a (1,k,k)
+    depthwise conv pads in time read as exact zeros): full output rows, sums over all rows, compact g."""
+    z = rnd((G * data, C), dtype, 71)
+    dy = rnd((G * full, C), dtype, 72)
+    scale, shift, mean = rnd((C,), seed=73) * 0.2 + 1, rnd((C,), seed=74) * 0.3, rnd((C,), seed=75) * 0.1
+    rstd = torch.rand(C) + 0.5
+    drop = (torch.rand(G, C) > 0.3).float() * 1.4
+    fm = (full, data, lead)
+    want = R.affine_act_fwd(z, scale, shift, "hardswish", 0.0, row_scale=drop, rows_per_group=full, mean=mean, frame_map=fm)
+    got = K.affine_act_fwd(dev(z), dev(scale), dev(shift), "hardswish", 0.0, row_scale=dev(drop), rows_per_group=full, mean=dev(mean), frame_map=fm)
+    assert tuple(got.shape) == (G * full, C)
+    check("affine_act_fm", got, want, dtype)
+    s_ref = torch.zeros(R.REPL, 2, C)
+    g_ref = R.act_bwd_reduce(dy, z, scale=scale, shift=shift, act="relu", row_scale=drop, rows_per_group=full, mean=mean, rstd=rstd,
+                             sums=s_ref, frame_map=fm)
+    s = torch.zeros(K.REPL, 2, C, device=DEV)
+    g = K.act_bwd_reduce(dev(dy), dev(z), scale=dev(scale), shift=dev(shift), act="relu", row_scale=dev(drop), rows_per_group=full,
+                         mean=dev(mean), rstd=dev(rstd), sums=s, frame_map=fm)
+    assert tuple(g.shape) == (G * data, C)
+    check("act_bwd_fm_g", g, g_ref, dtype)
+    check("act_bwd_fm_sums", s.sum(0), s_ref.sum(0), dtype, tol_scale=3.0)

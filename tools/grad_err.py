@@ -19,7 +19,7 @@ args = [a for a in sys.argv[1:] if not a.startswith("--")]
 bf16 = "--bf16" in sys.argv
 for case in (args or list(protocol.GRAD_CASES)):
     gold_all = load_golden("grad_" + case)
-    for mode in ("evalgrad", "train8"):
+    for mode in ("evalgrad", "train"):
         gold = golden_mode(gold_all, mode)
         with contextlib.redirect_stdout(io.StringIO()):
             res = protocol.run_grad_case(picklebot_amd, case, mode, device="cuda:0", autocast=bf16)

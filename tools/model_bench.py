@@ -24,6 +24,50 @@ CFG = {  # reference config/*.json
 }
 
 
+def movinet_a2_stream(batch, chunk, steps):
+    """BASELINE config 3, streaming variant: the 26 depthwise convs of MoViNet-A2 at their true shapes in a 50-frame
+    172x172 clip, each as a causal stream-buffer layer (picklebot_amd.CausalConv3d.forward_stream, the (kt-1)-frame
+    history carried in a caller-owned state), fed `chunk` frames at a time: us per frame and achieved HBM rate."""
+    import picklebot_amd as pb
+    from picklebot_amd import arch
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    layers = arch.movinet_a2_depthwise_layers(172, 172)
+    print(f"# MoViNet-A2 depthwise stack, streaming: batch {batch}, chunks of {chunk} frame(s) of a 50-frame 172x172 clip, bf16")
+    print("%-42s %10s %10s %10s" % ("layer (E, kernel, stride, HxW in)", "us/frame", "GB/s", "full us/fr"))
+    tot_stream = tot_full = tot_bytes = 0.0
+    for E, kernel, stride, hw in layers:
+        layer = pb.CausalConv3d(E, E, kernel, stride=stride, padding=(0, kernel[1] // 2, kernel[2] // 2), groups=E, bias=False).to(dev).eval()
+        x = torch.randn(batch, E, 50, hw[0], hw[1], device=dev).to(torch.bfloat16).to(memory_format=torch.channels_last_3d)
+
+        def run_stream():
+            state = None
+            for t0 in range(0, 50, chunk):
+                y, state = layer.forward_stream(x[:, :, t0:t0 + chunk], state)
+            return y
+
+        def timed(fn):
+            with torch.no_grad():
+                fn()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(steps):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / steps * 1e3          # us per clip batch
+        with torch.no_grad():
+            yfull = layer(x)
+        us_s, us_f = timed(run_stream), timed(lambda: layer(x))
+        nbytes = (x.numel() + yfull.numel()) * 2
+        tot_stream += us_s; tot_full += us_f; tot_bytes += nbytes
+        print("%-42s %10.2f %10.1f %10.2f" % (f"{E} {kernel} {stride[1:]} {hw[0]}x{hw[1]}", us_s / 50, nbytes / us_s / 1e3, us_f / 50))
+    print("%-42s %10.2f %10.1f %10.2f" % ("all 26 layers", tot_stream / 50, tot_bytes / tot_stream / 1e3, tot_full / 50))
+    print(json.dumps({"workload": "movinet_a2_stream", "batch": batch, "chunk": chunk, "us_per_frame_stream": round(tot_stream / 50, 2),
+                      "us_per_frame_full_clip": round(tot_full / 50, 2), "GBps_stream": round(tot_bytes / tot_stream / 1e3, 1)}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("workload")
@@ -33,7 +77,10 @@ def main():
     ap.add_argument("--fp32", action="store_true")
     ap.add_argument("--graph", action="store_true", help="also time the step replayed from one HIP graph (as bench.py does)")
     ap.add_argument("--fp8", action="store_true", help="inference: patch attention with fp8 MFMA operands (BASELINE config 5)")
+    ap.add_argument("--chunk", type=int, default=1, help="movinet_a2_stream: frames per chunk")
     args = ap.parse_args()
+    if args.workload == "movinet_a2_stream":
+        return movinet_a2_stream(args.batch, args.chunk, args.steps)
 
     import picklebot_amd as pb
     from picklebot_amd import kernels as K
