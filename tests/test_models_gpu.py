@@ -144,16 +144,27 @@ def test_train_gradients_do_not_depend_on_the_summation_order(case, golden, monk
     assert moved, "the two associations gave identical bits: the knob is not reaching the kernels"
 
 
+BF16_GRAD_FACTOR = 3.0
+
+
 @pytest.mark.parametrize("mode", ["evalgrad", "train"])
 @pytest.mark.parametrize("case", GRADS)
 def test_gradients_bf16_per_tensor(case, mode, golden):
-    """bf16 autocast (train.py:264), PER TENSOR (norm and every full-tensor projection of every parameter gradient): within
-    the noise bound of the reference's OWN bf16-autocast path, measured over four arithmetic variants of it
-    (oracle/make_golden.py: mean + 3 sigma of its deviation from fp64 per tensor, floor = the north_star's 1e-2)."""
+    """bf16 autocast (train.py:264), PER TENSOR (norm and every full-tensor projection of every parameter gradient), against
+    the reference's OWN bf16-autocast deviation from fp64 for that tensor (mean over four arithmetic variants of the real
+    reference, oracle/make_golden.py; floor = the north_star's 1e-2).
+
+    Why a factor, and why 3: the reference's deviation is its full-tensor error norm (exact); ours is measured through 8
+    random-sign projections, i.e. sqrt(chi2_8 / 8) x our true error - above 2.0 with probability 1e-4 and above 2.2 with 6e-6
+    per tensor at EQUAL accuracy (~1200 tensors are checked over the ten cases).  Measured on MI355X (tools/grad_err.py --bf16,
+    gpurun_out/r3i): ours / reference = median 0.4-1.06, p99 1.1-1.9, max 2.7 over all ten cases - the same accuracy as the
+    reference's bf16 path, up to ~1.35x on single tensors (this path keeps one more intermediate, g = dy * act', in bf16).
+    3.0 = 2.2 x 1.35.  (Round 2 used 5x one draw; the four variants' draws turned out identical in eval mode - the
+    reference's bf16 error is systematic rounding, not noise - so no sigma exists to build a bound from.)"""
     with contextlib.redirect_stdout(io.StringIO()):
         res = protocol.run_grad_case(picklebot_amd, case, mode, device=DEV, autocast=True)
     res = {k: v for k, v in res.items() if not k.startswith("gsamp/")}
-    bad, worst = check_model_result(res, golden_mode(golden("grad_" + case), mode), 1e-2, 1e-2, dev="refbf16_bound", factor=1.0)
+    bad, worst = check_model_result(res, golden_mode(golden("grad_" + case), mode), 1e-2, 1e-2, dev="refbf16_mean", factor=BF16_GRAD_FACTOR)
     assert not bad, f"{len(bad)} keys off, first {bad[:5]}, worst {worst}"
 
 
@@ -168,7 +179,7 @@ def test_fused_expand_depthwise_path_on_a_whole_model(golden, monkeypatch):
     prof = K.stop_profile()
     assert prof.get("xdw_fwd_kernel", {}).get("launches", 0) >= 11 and prof.get("xdw_wgrad_kernel", {}).get("launches", 0) >= 11
     res = {k: v for k, v in res.items() if not k.startswith("gsamp/")}
-    bad, worst = check_model_result(res, golden_mode(golden("grad_large3d"), "train"), 1e-2, 1e-2, dev="refbf16_bound", factor=1.0)
+    bad, worst = check_model_result(res, golden_mode(golden("grad_large3d"), "train"), 1e-2, 1e-2, dev="refbf16_mean", factor=BF16_GRAD_FACTOR)
     assert not bad, f"{len(bad)} keys off, first {bad[:5]}, worst {worst}"
 
 

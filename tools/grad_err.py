@@ -31,6 +31,17 @@ for case in (args or list(protocol.GRAD_CASES)):
         for kind in ("gnorm", "gproj", "gsamp"):
             g = np.array([e for e, k in rows if k.startswith(kind + "/")])
             print(f"[{case}/{mode}{' bf16' if bf16 else ''}] {kind}: median {np.median(g):.2e} p90 {np.percentile(g, 90):.2e} max {g.max():.2e}")
+        if bf16:      # ratio of our per-tensor projection error to the reference's own mean bf16-autocast deviation
+            rr = []
+            for e, k in rows:
+                if k.startswith("gproj/"):
+                    ref = gold.get("refbf16_mean/grad/" + k[6:])
+                    if ref is not None and float(ref[0]) > 2e-3:
+                        rr.append((e / float(ref[0]), k))
+            if rr:
+                r = np.array([v for v, _ in rr])
+                print(f"[{case}/{mode} bf16] ours / reference bf16 deviation over {len(r)} tensors: median {np.median(r):.2f} p90 {np.percentile(r, 90):.2f} "
+                      f"p99 {np.percentile(r, 99):.2f} max {r.max():.2f} ({max(rr)[1]})")
         fwd = [(e, k) for e, k in rows if k.split("/")[0] not in ("gnorm", "gproj", "gsamp")]
         print(f"   forward keys: {[(k, '%.1e' % e) for e, k in fwd]}")
         print(f"   worst: {[(k, '%.1e' % e) for e, k in rows[:6]]}", flush=True)
