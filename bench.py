@@ -308,7 +308,7 @@ def main():
         try:
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             from pmc_summary import csrc_digest
-            pmc = json.load(open(os.environ.get("PB_PMC_TRAFFIC", os.path.join(ROOT, "profiles", "r02_pmc_traffic.json"))))
+            pmc = json.load(open(os.environ.get("PB_PMC_TRAFFIC", os.path.join(ROOT, "profiles", "r03_pmc_traffic.json"))))
             if pmc.get("meta", {}).get("csrc_digest") == csrc_digest():
                 key = dom.split("<")[0]
                 if key in pmc["kernels"]:
