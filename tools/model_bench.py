@@ -64,8 +64,48 @@ def movinet_a2_stream(batch, chunk, steps):
         tot_stream += us_s; tot_full += us_f; tot_bytes += nbytes
         print("%-42s %10.2f %10.1f %10.2f" % (f"{E} {kernel} {stride[1:]} {hw[0]}x{hw[1]}", us_s / 50, nbytes / us_s / 1e3, us_f / 50))
     print("%-42s %10.2f %10.1f %10.2f" % ("all 26 layers", tot_stream / 50, tot_bytes / tot_stream / 1e3, tot_full / 50))
+    # the same streaming step - one chunk through all 26 layers, each carrying its own history - replayed from ONE HIP graph:
+    # what a deployed stream costs on the GPU once the ~30 us of Python + ctypes per launch are out of the way
+    from picklebot_amd import kernels as K
+    pairs = []
+    for E, kernel, stride, hw in layers:
+        layer = pb.CausalConv3d(E, E, kernel, stride=stride, padding=(0, kernel[1] // 2, kernel[2] // 2), groups=E, bias=False).to(dev).eval()
+        xc = torch.randn(batch, E, chunk, hw[0], hw[1], device=dev).to(torch.bfloat16).to(memory_format=torch.channels_last_3d)
+        nh = kernel[0] - 1
+        st = torch.zeros(batch, nh, hw[0], hw[1], E, device=dev, dtype=torch.bfloat16) if nh else None
+        pairs.append((layer, xc, st))
+
+    def chunk_step():
+        for layer, xc, st in pairs:
+            layer.forward_stream(xc, st)
+    with torch.no_grad():
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            chunk_step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        K.reset_zero_arena()
+        with torch.cuda.graph(g):
+            chunk_step()
+        K.reset_zero_arena()
+        nrep = (50 + chunk - 1) // chunk
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(steps * nrep):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+    us_clip = e0.elapsed_time(e1) / steps * 1e3
+    print("%-42s %10.2f %10.1f   (one HIP graph per %d-frame chunk, %d replays per clip)" % (
+        "all 26 layers, graph replay", us_clip / 50, tot_bytes / us_clip / 1e3, chunk, nrep))
     print(json.dumps({"workload": "movinet_a2_stream", "batch": batch, "chunk": chunk, "us_per_frame_stream": round(tot_stream / 50, 2),
-                      "us_per_frame_full_clip": round(tot_full / 50, 2), "GBps_stream": round(tot_bytes / tot_stream / 1e3, 1)}))
+                      "us_per_frame_stream_hipgraph": round(us_clip / 50, 2), "us_per_frame_full_clip": round(tot_full / 50, 2),
+                      "GBps_stream": round(tot_bytes / tot_stream / 1e3, 1), "GBps_stream_hipgraph": round(tot_bytes / us_clip / 1e3, 1)}))
 
 
 def main():
