@@ -41,7 +41,9 @@ def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, require_asm=False):
+    """require_asm: also rebuild sources whose kept assembly (lib/asm/*.s, not shipped to the GPU box) is missing - the ISA
+    lint test asks for it; an ordinary build never recompiles just for that."""
     os.makedirs(OBJDIR, exist_ok=True)
     os.makedirs(ASMDIR, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
@@ -55,7 +57,7 @@ def build(force=False, verbose=True):
         objs.append(obj)
         asm = os.path.join(ASMDIR, os.path.basename(src)[:-4] + ".s")
         if (force or not os.path.exists(obj) or not os.path.exists(stamp) or open(stamp).read() != dig
-                or (not os.path.exists(asm) and os.access(ASMDIR, os.W_OK) and not os.environ.get("PB_BUILD_NO_ASM"))):
+                or (require_asm and not os.path.exists(asm) and os.access(ASMDIR, os.W_OK))):
             jobs.append((src, obj, stamp, dig))
 
     def compile_one(job):

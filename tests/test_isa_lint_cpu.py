@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 def test_no_vector_copies_ahead_of_exec_restore_in_join_blocks():
     from picklebot_amd import build
     import lint_isa
-    build.build(verbose=False)
+    build.build(verbose=False, require_asm=True)
     srcs = [os.path.basename(s)[:-4] for s in build.sources()]
     asms = [os.path.join(build.ASMDIR, b + ".s") for b in srcs]
     missing = [a for a in asms if not os.path.exists(a)]
