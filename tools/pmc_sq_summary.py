@@ -23,9 +23,11 @@ for r in csv.DictReader(open(sys.argv[1])):
         cnt[n] += 1
 rows = sorted(((c.get("SQ_WAVE_CYCLES", 0), n, c) for n, c in d.items() if c.get("SQ_WAVE_CYCLES", 0) > 0), reverse=True)
 print("# bench.py --steps 2 --warmup 1 --no-graph, one PMC pass; ratios relative to SQ_WAVE_CYCLES (x1e-2), MFMA busy relative to SQ_BUSY_CYCLES")
-print("%-48s %6s %12s %8s %8s %8s %8s %8s %10s" % ("kernel", "calls", "wave_cycles", "valu", "lds", "vmem", "wait", "mfma", "lds_conf"))
+print("# flat = global_* / flat_* memory instructions (SQ_ACTIVE_INST_FLAT: on gfx950 the VMEM counter only sees buffer_* ops, which is why")
+print("# round 2's vmem column read 0.00); parked = SQ_WAIT_ANY (s_waitcnt / barrier), stall = SQ_WAIT_INST_ANY (issue stalls)")
+print("%-48s %6s %12s %8s %8s %8s %8s %8s %8s" % ("kernel", "calls", "wave_cycles", "valu", "lds", "flat", "parked", "stall", "mfma"))
 for wc, n, c in rows[:40]:
-    print("%-48s %6d %12.3e %8.2f %8.2f %8.2f %8.2f %8.2f %10.2f" % (
-        n, cnt[n], wc, 100 * c["SQ_ACTIVE_INST_VALU"] / wc, 100 * c["SQ_ACTIVE_INST_LDS"] / wc, 100 * c["SQ_ACTIVE_INST_VMEM"] / wc,
-        100 * c["SQ_WAIT_INST_ANY"] / wc, 100 * c["SQ_VALU_MFMA_BUSY_CYCLES"] / max(c.get("SQ_BUSY_CYCLES", 1), 1),
-        100 * c["SQ_LDS_BANK_CONFLICT"] / max(c["SQ_ACTIVE_INST_LDS"], 1)))
+    print("%-48s %6d %12.3e %8.2f %8.2f %8.2f %8.2f %8.2f %8.2f" % (
+        n, cnt[n], wc, 100 * c["SQ_ACTIVE_INST_VALU"] / wc, 100 * c["SQ_ACTIVE_INST_LDS"] / wc, 100 * c["SQ_ACTIVE_INST_FLAT"] / wc,
+        100 * c["SQ_WAIT_ANY"] / wc, 100 * c["SQ_WAIT_INST_ANY"] / wc,
+        100 * c["SQ_VALU_MFMA_BUSY_CYCLES"] / max(c.get("SQ_BUSY_CYCLES", 1), 1)))
