@@ -10,10 +10,14 @@
 //   * products that contract over queries (dV^T = dO^T P, dK^T = Q^T dS) use the un-transposed S = Q K^T
 //     in a second kernel where waves own key tiles, so no gradient needs atomics;
 //   * softmax statistics are lane-local (registers of one query column) + two shuffles;
-//   * forward is two passes over the keys (online max/sum, then normalised P V); backward recomputes P
-//     from the saved log-sum-exp.
-// bf16: v_mfma_f32_16x16x32_bf16 (the d = 16 contraction zero-pads half the k slots; the key/query
-// contractions use all 32: slot (g,j) <-> index 4g+j (j<4) / 16+4g+(j-4) of a 32-wide pair of tiles).
+//   * fp32 forward is two passes over the keys (online max/sum, then normalised P V), bf16 forward one pass;
+//     backward recomputes P from the saved log-sum-exp.
+// bf16: v_mfma_f32_16x16x32_bf16.  The d = 16 contractions fill only k-slots 0..15 of that instruction; the
+// other half repeats the streamed operand against the LOW half of the pre-scaled register operand (the multiplier
+// scale * log2 e with 16 mantissa bits, no multiply on the VALU), and the accumulator input carries the softmax's
+// per-query constants (forward: minus the running maximum and the padding mask; backward: minus log-sum-exp and minus
+// delta), so the subtractions, masks and clamps leave the VALU too - which is what bounds these kernels.  The key/query contractions use all 32
+// slots: slot (g,j) <-> index 4g+j (j<4) / 16+4g+(j-4) of a 32-wide pair of tiles.
 // fp32 (parity path): exact-f32 v_mfma_f32_16x16x4_f32, slot g of step r <-> index 4g+r of a tile.
 #include "pb_common.h"
 #include <stdlib.h>
@@ -193,12 +197,137 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnArgs a) {
 // ------------------------------------------------------------------------------------------ forward, one pass
 // bf16 activations, ONE pass over the keys with an online softmax (the two-pass kernel above computed every score and
 // every exp twice: 153 us at n = 768, batch 8 - 3-5 % of the dense MFMA peak).  Per wave: a tile of 16 queries; per
-// step a PAIR of 16-key tiles: two S^T = K Q^T MFMAs, the running max is raised (two shuffles across the four lane
-// groups that share a query column), the accumulators are rescaled, and the eight probabilities a lane holds ARE its
-// slots of the B operand of O^T += V^T P^T (slot (g, r) <-> key 4g + r of the first tile, (g, 4 + r) <-> the second).
-// P never leaves registers.  FP8 (BASELINE config 5, "CDNA4 fp8 MFMA attn"): the operands of both products are OCP
+// step a PAIR of 16-key tiles: two S^T = K Q^T MFMAs, and the eight probabilities a lane holds ARE its slots of the B
+// operand of O^T += V^T P^T (slot (g, r) <-> key 4g + r of the first tile, (g, 4 + r) <-> the second).  P never leaves
+// registers.
+//
+// The loop is VALU-issue bound (per step and lane: 8 scores against 3 MFMAs), so the work per score is what counts,
+// and the MFMA has two things to give away.  (1) d = 16 fills only k-slots 0..15 of the 16x16x32 contraction: slots
+// 16..31 repeat the key values (the lanes of those slots re-read the row's two chunks) against the LOW half of the
+// pre-scaled query, q * scale * log2(e) = hi + lo in bf16 - the scores arrive in the log2 domain with 16 mantissa
+// bits of the multiplier instead of 8, and no multiply is left on the VALU.  (2) The accumulator input C: with
+// C = -m[q] (the running maximum of the lane's query column, fp32) the MFMA returns x - m directly, and in the last
+// step C also carries -1e30 for the padding keys - no subtraction and no mask selects.  The maximum is tracked lazily:
+// a lane only asks whether any of its eight new scores is positive, i.e. above the reference (4 v_max3 + a compare);
+// when some lane of the wave says yes - after the first few key tiles it rarely does - the column maximum is gathered
+// (two shuffles), the accumulators and this step's scores are rescaled and C rewritten.  Per step: 56 -> 26 VALU
+// instructions; 115 -> 84 us at n = 768, batch 8.
+__device__ __forceinline__ void split_bf16(float x, bf16_t& hi, bf16_t& lo) {
+  hi = (bf16_t)x;
+  lo = (bf16_t)(x - (float)hi);
+}
+
+// B operand [hi | lo] of x * mult for a row of 16 bf16 values: lane group g holds elements 8 (g & 1) .. + 7 - the high
+// halves for g < 2, the low halves for g >= 2 (null row -> zeros)
+__device__ __forceinline__ bf16x8 load_scaled_hilo(const bf16_t* row, int g, float mult) {
+  bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (row) v = *reinterpret_cast<const bf16x8*>(row + 8 * (g & 1));
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    bf16_t hi, lo;
+    split_bf16((float)v[e] * mult, hi, lo);
+    v[e] = g < 2 ? hi : lo;
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(1024) void attn_fwd_onepass_bf16_kernel(AttnArgs a) {
+  typedef bf16_t T;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int n = a.n, npad = a.npad;
+  const int gh = blockIdx.x / a.split, sp = blockIdx.x - gh * a.split, nwv = blockDim.x >> 6;
+  const int grp = gh / NH, h = gh - grp * NH;
+  const T* base = (const T*)a.qkv + (int64_t)grp * n * QKV_LD + h * HD;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  // LDS: K [npad][16] | V^T [16][npad + 8]
+  const int ldt = npad + 8;
+  T* Ks = (T*)smem;
+  T* Vs = Ks + npad * HD;
+  stage_head<T>(base + NH * HD, QKV_LD, n, npad, Ks, nullptr, 0);
+  stage_head<T>(base + 2 * NH * HD, QKV_LD, n, npad, nullptr, Vs, ldt);
+  __syncthreads();
+  const int npairs = npad >> 5;
+  const float sl0 = a.scale * 1.44269504088896340736f;
+  const T* krow = Ks + li * HD + 8 * (g & 1);                  // this lane's chunk of key row li of a tile
+  // query tile t belongs to workgroup t % split, and within it to wave (t / split) % waves: every workgroup gets the same
+  // number of tiles (+-1), and the waves with one tile more are spread evenly over the four SIMDs
+  for (int qt = sp + a.split * wave; qt * 16 < n; qt += nwv * a.split) {
+    const int q = qt * 16 + li;
+    const bool qok = q < n;
+    const bf16x8 qv = load_scaled_hilo(qok ? base + (int64_t)q * QKV_LD : nullptr, g, sl0);
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    f32x4 cm = {0.f, 0.f, 0.f, 0.f};                           // -m, the C operand of the score products
+    float m = 0.f, l = 0.f;                                    // l: this lane's share (its 8 keys per pair) of the row sum
+    auto step = [&](int kp, auto first, auto last) {
+      const bf16x8 ka = *reinterpret_cast<const bf16x8*>(krow + kp * 32 * HD);
+      const bf16x8 kb = *reinterpret_cast<const bf16x8*>(krow + kp * 32 * HD + 16 * HD);
+      f32x4 ca = cm, cb = cm;
+      if constexpr (decltype(last)::value) {                   // the pair that can hold keys >= n
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          ca[r] = kp * 32 + 4 * g + r < n ? cm[r] : -1.0e30f;
+          cb[r] = kp * 32 + 16 + 4 * g + r < n ? cm[r] : -1.0e30f;
+        }
+      }
+      f32x4 sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qv, ca, 0, 0, 0);             // x - m  (S^T[key][q])
+      f32x4 sb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kb, qv, cb, 0, 0, 0);
+      float mx = fmaxf(fmaxf(sa[0], sa[1]), sa[2]);
+      mx = fmaxf(fmaxf(mx, sa[3]), sb[0]);
+      mx = fmaxf(fmaxf(mx, sb[1]), sb[2]);
+      mx = fmaxf(mx, sb[3]);
+      if (decltype(first)::value || __any(mx > 0.f)) {
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));                // the four lane groups of a query column
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float delta = decltype(first)::value ? mx : fmaxf(mx, 0.f);   // the first reference may be negative
+        if constexpr (!decltype(first)::value) {
+          const float alpha = __builtin_amdgcn_exp2f(-delta);
+          l *= alpha;
+          o *= alpha;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { sa[r] -= delta; sb[r] -= delta; }
+        m += delta;
+        cm[0] = cm[1] = cm[2] = cm[3] = -m;
+      }
+      float p[8];
+      bf16x8 pb;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        p[r] = __builtin_amdgcn_exp2f(sa[r]);
+        p[4 + r] = __builtin_amdgcn_exp2f(sb[r]);
+      }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) pb[r] = (bf16_t)p[r];
+      l += ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+      const bf16x4 v0 = *reinterpret_cast<const bf16x4*>(Vs + li * ldt + kp * 32 + 4 * g);
+      const bf16x4 v1 = *reinterpret_cast<const bf16x4*>(Vs + li * ldt + kp * 32 + 16 + 4 * g);
+      const bf16x8 va = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+      o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, pb, o, 0, 0, 0);
+    };
+    if (npairs == 1) {
+      step(0, std::true_type{}, std::true_type{});
+    } else {
+      step(0, std::true_type{}, std::false_type{});
+      for (int kp = 1; kp < npairs - 1; ++kp) step(kp, std::false_type{}, std::false_type{});
+      step(npairs - 1, std::false_type{}, std::true_type{});
+    }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.f / l;
+    if (qok) {
+      // O^T tile: column = q (this lane), rows d = 4g + r: 8 bytes per lane
+      const bf16x4 ov = {(bf16_t)(o[0] * inv), (bf16_t)(o[1] * inv), (bf16_t)(o[2] * inv), (bf16_t)(o[3] * inv)};
+      *reinterpret_cast<bf16x4*>((T*)a.out + ((int64_t)grp * n + q) * OUT_LD + h * HD + 4 * g) = ov;
+      if (g == 0) a.lse[((int64_t)grp * n + q) * NH + h] = (m + __log2f(l)) * 0.69314718055994530942f;
+    }
+  }
+}
+
+// FP8 (BASELINE config 5, "CDNA4 fp8 MFMA attn"): the same one-pass scheme with the operands of both products in OCP
 // e4m3 - K and V quantised per (group, head) with one scale each (amax over the head slice, found while staging), Q
-// per query tile, P as p * 256 - fed to v_mfma_f32_16x16x32_fp8_fp8; softmax statistics stay fp32.
+// per query tile, P as p * 256 - fed to v_mfma_f32_16x16x32_fp8_fp8; softmax statistics stay fp32, the running maximum
+// is kept the plain way (max, subtract and mask on the VALU).
 typedef long fp8x8_t;
 
 __device__ __forceinline__ fp8x8_t pack_fp8x8(const float (&v)[8]) {
@@ -222,8 +351,7 @@ __device__ __forceinline__ float block_max(float v, float* red) {       // max o
   return m;
 }
 
-template <bool FP8>
-__global__ __launch_bounds__(1024) void attn_fwd_onepass_kernel(AttnArgs a) {
+__global__ __launch_bounds__(1024) void attn_fwd_onepass_fp8_kernel(AttnArgs a) {
   typedef bf16_t T;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int n = a.n, npad = a.npad;
@@ -232,18 +360,12 @@ __global__ __launch_bounds__(1024) void attn_fwd_onepass_kernel(AttnArgs a) {
   const T* base = (const T*)a.qkv + (int64_t)grp * n * QKV_LD + h * HD;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, g = lane >> 4;
-  // LDS: bf16: K [npad][16] (32 B rows) | V^T [16][npad + 8];  fp8: K [npad][16] (16 B rows) | V^T [16][npad + 16] | 8 floats
-  const int ldt = FP8 ? npad + 16 : npad + 8;
-  T* Ks = (T*)smem;
-  T* Vs = Ks + npad * HD;
+  // LDS: K [npad][16] (16 B rows) | V^T [16][npad + 16] | 16 floats
+  const int ldt = npad + 16;
   unsigned char* K8 = smem;
   unsigned char* V8 = smem + (size_t)npad * HD;
   float inv_sk = 1.f, inv_sv = 1.f;
-  if constexpr (!FP8) {
-    stage_head<T>(base + NH * HD, QKV_LD, n, npad, Ks, nullptr, 0);
-    stage_head<T>(base + 2 * NH * HD, QKV_LD, n, npad, nullptr, Vs, ldt);
-    __syncthreads();
-  } else {
+  {
     // K and V head slices: registers -> amax -> one scale each -> e4m3 in LDS (rows >= n are zeros)
     constexpr int MAXC = 4;                                    // 16-byte chunks per thread and tensor: npad * 2 <= 4 * 512
     float* red = (float*)(smem + (size_t)npad * HD + (size_t)HD * ldt);
@@ -285,55 +407,35 @@ __global__ __launch_bounds__(1024) void attn_fwd_onepass_kernel(AttnArgs a) {
   }
   const float NEG = -3.0e38f;
   const int npairs = npad >> 5, pfull = n >> 5;               // key-tile pairs; pairs without padding keys
-  for (int qt = sp * nwv + wave; qt * 16 < n; qt += nwv * a.split) {
+  for (int qt = sp + a.split * wave; qt * 16 < n; qt += nwv * a.split) {
     const int q = qt * 16 + li;
     const bool qok = q < n;
-    // B operand of the score products: lane (query = li, g) holds Q[q][8g .. 8g+7] for g < 2, zeros above (d = 16)
     bf16x8 qv = {0, 0, 0, 0, 0, 0, 0, 0};
     if (qok && g < 2) qv = *reinterpret_cast<const bf16x8*>(base + (int64_t)q * QKV_LD + 8 * g);
-    fp8x8_t q8 = 0;
-    // scores in the log2 domain: the multiplier scale * log2(e) is folded into Q once per query tile (bf16: Q is
-    // re-rounded after the multiplication, the same 2^-9 relative error as the unscaled operand; fp8: into Q's scale)
-    const float sl0 = a.scale * 1.44269504088896340736f;
-    if constexpr (!FP8) {
+    // per query tile: amax -> scale -> e4m3; scale * log2(e) and the de-quantisation go into one score multiplier
+    float aq = 0.f, qf[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) qv[e] = (bf16_t)((float)qv[e] * sl0);
-    }
-    float sl = 1.f;                                            // fp8: de-quantisation factor of the scores; bf16: already in Q
-    if constexpr (FP8) {
-      float aq = 0.f, qf[8];
+    for (int e = 0; e < 8; ++e) aq = fmaxf(aq, fabsf((float)qv[e]));
 #pragma unroll
-      for (int e = 0; e < 8; ++e) aq = fmaxf(aq, fabsf((float)qv[e]));
+    for (int o = 32; o > 0; o >>= 1) aq = fmaxf(aq, __shfl_xor(aq, o, 64));
+    const float sq = aq > 0.f ? 448.f / aq : 1.f;
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) aq = fmaxf(aq, __shfl_xor(aq, o, 64));
-      const float sq = aq > 0.f ? 448.f / aq : 1.f;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) qf[e] = (float)qv[e] * sq;
-      q8 = pack_fp8x8(qf);
-      sl = sl0 * inv_sk / sq;
-    }
+    for (int e = 0; e < 8; ++e) qf[e] = (float)qv[e] * sq;
+    const fp8x8_t q8 = pack_fp8x8(qf);
+    const float sl = a.scale * 1.44269504088896340736f * inv_sk / sq;
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
     float m = NEG, l = 0.f;                                    // l: this lane's share (its 8 keys per pair) of the row sum
     auto step = [&](int kp, auto masked) {
       f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = sa;
-      if constexpr (FP8) {
-        const fp8x8_t ka = g < 2 ? *reinterpret_cast<const fp8x8_t*>(K8 + (size_t)(kp * 32 + li) * HD + 8 * g) : 0;
-        const fp8x8_t kb = g < 2 ? *reinterpret_cast<const fp8x8_t*>(K8 + (size_t)(kp * 32 + 16 + li) * HD + 8 * g) : 0;
-        sa = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(ka, q8, sa, 0, 0, 0);
-        sb = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(kb, q8, sb, 0, 0, 0);
-      } else {
-        bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-        const bf16x8 ka = g < 2 ? *reinterpret_cast<const bf16x8*>(Ks + (kp * 32 + li) * HD + 8 * g) : z;
-        const bf16x8 kb = g < 2 ? *reinterpret_cast<const bf16x8*>(Ks + (kp * 32 + 16 + li) * HD + 8 * g) : z;
-        sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qv, sa, 0, 0, 0);
-        sb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kb, qv, sb, 0, 0, 0);
-      }
+      const fp8x8_t ka = g < 2 ? *reinterpret_cast<const fp8x8_t*>(K8 + (size_t)(kp * 32 + li) * HD + 8 * g) : 0;
+      const fp8x8_t kb = g < 2 ? *reinterpret_cast<const fp8x8_t*>(K8 + (size_t)(kp * 32 + 16 + li) * HD + 8 * g) : 0;
+      sa = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(ka, q8, sa, 0, 0, 0);
+      sb = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(kb, q8, sb, 0, 0, 0);
       float sv8[8], mx = NEG;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float xa = FP8 ? sa[r] * sl : sa[r], xb = FP8 ? sb[r] * sl : sb[r];
-        sv8[r] = (!decltype(masked)::value || kp * 32 + 4 * g + r < n) ? xa : NEG;
-        sv8[4 + r] = (!decltype(masked)::value || kp * 32 + 16 + 4 * g + r < n) ? xb : NEG;
+        sv8[r] = (!decltype(masked)::value || kp * 32 + 4 * g + r < n) ? sa[r] * sl : NEG;
+        sv8[4 + r] = (!decltype(masked)::value || kp * 32 + 16 + 4 * g + r < n) ? sb[r] * sl : NEG;
       }
 #pragma unroll
       for (int r = 0; r < 8; ++r) mx = fmaxf(mx, sv8[r]);
@@ -348,39 +450,26 @@ __global__ __launch_bounds__(1024) void attn_fwd_onepass_kernel(AttnArgs a) {
         l *= alpha;
         o *= alpha;
       }
-      float p[8], ps = 0.f;
+      float p8[8], ps = 0.f;
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
-        p[r] = __builtin_amdgcn_exp2f(sv8[r] - m);
-        ps += p[r];
+        const float p = __builtin_amdgcn_exp2f(sv8[r] - m);
+        ps += p;
+        p8[r] = p * 256.f;
       }
       l += ps;
-      if constexpr (FP8) {
-        float p8[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) p8[r] = p[r] * 256.f;
-        const fp8x8_t pb = pack_fp8x8(p8);
-        const unsigned v0 = *reinterpret_cast<const unsigned*>(V8 + (size_t)li * ldt + kp * 32 + 4 * g);
-        const unsigned v1 = *reinterpret_cast<const unsigned*>(V8 + (size_t)li * ldt + kp * 32 + 16 + 4 * g);
-        const fp8x8_t va = (fp8x8_t)(((unsigned long)v1 << 32) | v0);
-        o = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(va, pb, o, 0, 0, 0);
-      } else {
-        bf16x8 pb;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) pb[r] = (bf16_t)p[r];
-        const bf16x4 v0 = *reinterpret_cast<const bf16x4*>(Vs + li * ldt + kp * 32 + 4 * g);
-        const bf16x4 v1 = *reinterpret_cast<const bf16x4*>(Vs + li * ldt + kp * 32 + 16 + 4 * g);
-        const bf16x8 va = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-        o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, pb, o, 0, 0, 0);
-      }
+      const fp8x8_t pb = pack_fp8x8(p8);
+      const unsigned v0 = *reinterpret_cast<const unsigned*>(V8 + (size_t)li * ldt + kp * 32 + 4 * g);
+      const unsigned v1 = *reinterpret_cast<const unsigned*>(V8 + (size_t)li * ldt + kp * 32 + 16 + 4 * g);
+      const fp8x8_t va = (fp8x8_t)(((unsigned long)v1 << 32) | v0);
+      o = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(va, pb, o, 0, 0, 0);
     };
     for (int kp = 0; kp < pfull; ++kp) step(kp, std::false_type{});
     for (int kp = pfull; kp < npairs; ++kp) step(kp, std::true_type{});
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
-    const float inv = (FP8 ? inv_sv * (1.f / 256.f) : 1.f) / l;
+    const float inv = inv_sv * (1.f / 256.f) / l;
     if (qok) {
-      // O^T tile: column = q (this lane), rows d = 4g + r: 8 bytes per lane
       const bf16x4 ov = {(bf16_t)(o[0] * inv), (bf16_t)(o[1] * inv), (bf16_t)(o[2] * inv), (bf16_t)(o[3] * inv)};
       *reinterpret_cast<bf16x4*>((T*)a.out + ((int64_t)grp * n + q) * OUT_LD + h * HD + 4 * g) = ov;
       if (g == 0) a.lse[((int64_t)grp * n + q) * NH + h] = (m + __log2f(l)) * 0.69314718055994530942f;
@@ -401,20 +490,19 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const T* dout, const T*
   delta[i] = s;
 }
 
-// ------------------------------------------------------------------------------------------ backward: dQ
-// waves own query tiles; S^T orientation (key on the accumulator row): dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q]
-template <typename T>
+// ------------------------------------------------------------------------------------------ backward, fp32
+// (the parity path: exact-f32 MFMAs, masks and subtractions spelled out; the bf16 kernels follow)
+// dQ: waves own query tiles; S^T orientation (key on the accumulator row): dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q]
 __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnArgs a) {
+  typedef float T;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr bool BF = sizeof(T) == 2;
-  const int n = a.n, npad = a.npad, ldt = npad + 8;
+  const int n = a.n, npad = a.npad;
   T* Ks = (T*)smem;                 // [npad][16]
   T* Vs = Ks + npad * HD;           // [npad][16]
-  T* Kt = Vs + npad * HD;           // bf16 only: K^T [16][ldt]
   const int gh = blockIdx.x / a.split, sp = blockIdx.x - gh * a.split, nwv = blockDim.x >> 6;
   const int grp = gh / NH, h = gh - grp * NH;
   const T* base = (const T*)a.qkv + (int64_t)grp * n * QKV_LD + h * HD;
-  stage_head<T>(base + NH * HD, QKV_LD, n, npad, Ks, BF ? Kt : nullptr, ldt);
+  stage_head<T>(base + NH * HD, QKV_LD, n, npad, Ks, nullptr, 0);
   stage_head<T>(base + 2 * NH * HD, QKV_LD, n, npad, Vs, nullptr, 0);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -427,75 +515,45 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnArgs a) {
     const Frag<T> dof = load_rowfrag<T>(qok ? (const T*)a.dout + row * OUT_LD + h * HD : nullptr, g);
     const float L = qok ? a.lse[row * NH + h] : 0.f;
     const float dl = qok ? a.delta[row * NH + h] : 0.f;
-    const float sl = a.scale * 1.44269504088896340736f, L2 = L * 1.44269504088896340736f;
     f32x4 dq = {0.f, 0.f, 0.f, 0.f};
-    if constexpr (BF) {
-      for (int kp = 0; kp * 32 < npad; ++kp) {
-        bf16x8 dsb;
+    for (int kt = 0; kt * 16 < npad; ++kt) {
+      const Frag<T> kf = load_rowfrag<T>(Ks + (kt * 16 + li) * HD, g);
+      const Frag<T> vf = load_rowfrag<T>(Vs + (kt * 16 + li) * HD, g);
+      const f32x4 s = mma_d16<T>(kf, qf);        // S^T[key][q]
+      const f32x4 dp = mma_d16<T>(vf, dof);      // dP^T[key][q] = sum_d V[key][d] dO[q][d]
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-          const int kt = 2 * kp + half;
-          const Frag<T> kf = load_rowfrag<T>(Ks + (kt * 16 + li) * HD, g);
-          const Frag<T> vf = load_rowfrag<T>(Vs + (kt * 16 + li) * HD, g);
-          const f32x4 s = mma_d16<T>(kf, qf);        // S^T[key][q]
-          const f32x4 dp = mma_d16<T>(vf, dof);      // dP^T[key][q] = sum_d V[key][d] dO[q][d]
-          // no masks: a padded key has K = V = 0, so its (finite) dS meets a zero K^T column; a padded query has
-          // Q = dO = 0 and is never stored.  Scores in the log2 domain (v_exp_f32 is exp2).
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float p = __builtin_amdgcn_exp2f(fminf(s[r] * sl - L2, 0.f));   // (<= 0 for real keys; bounds the padded ones)
-            dsb[4 * half + r] = (bf16_t)(p * (dp[r] - dl) * a.scale);
-          }
-        }
-        const bf16x4 k0 = *reinterpret_cast<const bf16x4*>(Kt + li * ldt + kp * 32 + 4 * g);
-        const bf16x4 k1 = *reinterpret_cast<const bf16x4*>(Kt + li * ldt + kp * 32 + 16 + 4 * g);
-        const bf16x8 ka = {k0[0], k0[1], k0[2], k0[3], k1[0], k1[1], k1[2], k1[3]};
-        dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, dsb, dq, 0, 0, 0);
-      }
-    } else {
-      for (int kt = 0; kt * 16 < npad; ++kt) {
-        const Frag<T> kf = load_rowfrag<T>(Ks + (kt * 16 + li) * HD, g);
-        const Frag<T> vf = load_rowfrag<T>(Vs + (kt * 16 + li) * HD, g);
-        const f32x4 s = mma_d16<T>(kf, qf);
-        const f32x4 dp = mma_d16<T>(vf, dof);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = kt * 16 + 4 * g + r;
-          const bool ok = qok && key < n;
-          const float p = ok ? __expf(s[r] * a.scale - L) : 0.f;
-          const float ds = p * (dp[r] - dl) * a.scale;
-          dq = __builtin_amdgcn_mfma_f32_16x16x4f32(Ks[key * HD + li], ds, dq, 0, 0, 0);
-        }
+      for (int r = 0; r < 4; ++r) {
+        const int key = kt * 16 + 4 * g + r;
+        const bool ok = qok && key < n;
+        const float p = ok ? __expf(s[r] * a.scale - L) : 0.f;
+        const float ds = p * (dp[r] - dl) * a.scale;
+        dq = __builtin_amdgcn_mfma_f32_16x16x4f32(Ks[key * HD + li], ds, dq, 0, 0, 0);
       }
     }
     if (qok) {
       T* op = (T*)a.dqkv + row * QKV_LD + h * HD + 4 * g;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) op[r] = from_f32<T>(dq[r]);
+      for (int r = 0; r < 4; ++r) op[r] = dq[r];
     }
   }
 }
 
-// ------------------------------------------------------------------------------------------ backward: dK, dV
-// waves own key tiles; S orientation (query on the accumulator row, key on the lane):
+// dK, dV: waves own key tiles; S orientation (query on the accumulator row, key on the lane):
 //   dV^T[d][key] = sum_q dO^T[d][q] P[q][key],   dK^T[d][key] = sum_q Q^T[d][q] dS[q][key]
-template <typename T>
 __global__ __launch_bounds__(1024) void attn_bwd_dkv_kernel(AttnArgs a) {
+  typedef float T;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr bool BF = sizeof(T) == 2;
-  const int n = a.n, npad = a.npad, ldt = npad + 8;
+  const int n = a.n, npad = a.npad;
   T* Qs = (T*)smem;                      // [npad][16]
   T* Os = Qs + npad * HD;                // dO [npad][16]
-  T* Qt = Os + npad * HD;                // bf16 only: Q^T, dO^T [16][ldt]
-  T* Ot = Qt + (BF ? HD * ldt : 0);
-  float* Ls = (float*)(Ot + (BF ? HD * ldt : 0));   // lse [npad], delta [npad]
+  float* Ls = Os + npad * HD;            // lse [npad], delta [npad]
   float* Ds = Ls + npad;
   const int gh = blockIdx.x / a.split, sp = blockIdx.x - gh * a.split, nwv = blockDim.x >> 6;
   const int grp = gh / NH, h = gh - grp * NH;
   const T* base = (const T*)a.qkv + (int64_t)grp * n * QKV_LD + h * HD;
   const T* dob = (const T*)a.dout + (int64_t)grp * n * OUT_LD + h * HD;
-  stage_head<T>(base, QKV_LD, n, npad, Qs, BF ? Qt : nullptr, ldt);
-  stage_head<T>(dob, OUT_LD, n, npad, Os, BF ? Ot : nullptr, ldt);
+  stage_head<T>(base, QKV_LD, n, npad, Qs, nullptr, 0);
+  stage_head<T>(dob, OUT_LD, n, npad, Os, nullptr, 0);
   for (int i = threadIdx.x; i < npad; i += blockDim.x) {
     Ls[i] = i < n ? a.lse[((int64_t)grp * n + i) * NH + h] : 0.f;
     Ds[i] = i < n ? a.delta[((int64_t)grp * n + i) * NH + h] : 0.f;
@@ -509,51 +567,19 @@ __global__ __launch_bounds__(1024) void attn_bwd_dkv_kernel(AttnArgs a) {
     const Frag<T> kf = load_rowfrag<T>(kok ? base + NH * HD + (int64_t)key * QKV_LD : nullptr, g);
     const Frag<T> vf = load_rowfrag<T>(kok ? base + 2 * NH * HD + (int64_t)key * QKV_LD : nullptr, g);
     f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
-    const float sl = a.scale * 1.44269504088896340736f;
-    if constexpr (BF) {
-      for (int qp = 0; qp * 32 < npad; ++qp) {
-        bf16x8 pb, dsb;
+    for (int qt = 0; qt * 16 < npad; ++qt) {
+      const Frag<T> qf = load_rowfrag<T>(Qs + (qt * 16 + li) * HD, g);
+      const Frag<T> dof = load_rowfrag<T>(Os + (qt * 16 + li) * HD, g);
+      const f32x4 s = mma_d16<T>(qf, kf);        // S[q][key]: rows q = 4g + r, column = key
+      const f32x4 dp = mma_d16<T>(dof, vf);      // dP[q][key]
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-          const int qt = 2 * qp + half;
-          const Frag<T> qf = load_rowfrag<T>(Qs + (qt * 16 + li) * HD, g);
-          const Frag<T> dof = load_rowfrag<T>(Os + (qt * 16 + li) * HD, g);
-          const f32x4 s = mma_d16<T>(qf, kf);        // S[q][key]: rows q = 4g + r, column = key
-          const f32x4 dp = mma_d16<T>(dof, vf);      // dP[q][key]
-          // no masks (see the dQ kernel): padded queries have Q = dO = 0 and lse = delta = 0, padded keys are not stored
-          const f32x4 l4 = *reinterpret_cast<const f32x4*>(Ls + qt * 16 + 4 * g);
-          const f32x4 d4 = *reinterpret_cast<const f32x4*>(Ds + qt * 16 + 4 * g);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float p = __builtin_amdgcn_exp2f(fminf(s[r] * sl - l4[r] * 1.44269504088896340736f, 0.f));
-            pb[4 * half + r] = (bf16_t)p;
-            dsb[4 * half + r] = (bf16_t)(p * (dp[r] - d4[r]) * a.scale);
-          }
-        }
-        const bf16x4 o0 = *reinterpret_cast<const bf16x4*>(Ot + li * ldt + qp * 32 + 4 * g);
-        const bf16x4 o1 = *reinterpret_cast<const bf16x4*>(Ot + li * ldt + qp * 32 + 16 + 4 * g);
-        const bf16x8 oa = {o0[0], o0[1], o0[2], o0[3], o1[0], o1[1], o1[2], o1[3]};
-        dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(oa, pb, dv, 0, 0, 0);
-        const bf16x4 q0 = *reinterpret_cast<const bf16x4*>(Qt + li * ldt + qp * 32 + 4 * g);
-        const bf16x4 q1 = *reinterpret_cast<const bf16x4*>(Qt + li * ldt + qp * 32 + 16 + 4 * g);
-        const bf16x8 qa = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
-        dk = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, dsb, dk, 0, 0, 0);
-      }
-    } else {
-      for (int qt = 0; qt * 16 < npad; ++qt) {
-        const Frag<T> qf = load_rowfrag<T>(Qs + (qt * 16 + li) * HD, g);
-        const Frag<T> dof = load_rowfrag<T>(Os + (qt * 16 + li) * HD, g);
-        const f32x4 s = mma_d16<T>(qf, kf);
-        const f32x4 dp = mma_d16<T>(dof, vf);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int q = qt * 16 + 4 * g + r;
-          const bool ok = kok && q < n;
-          const float p = ok ? __expf(s[r] * a.scale - Ls[q]) : 0.f;
-          const float ds = p * (dp[r] - Ds[q]) * a.scale;
-          dv = __builtin_amdgcn_mfma_f32_16x16x4f32(Os[q * HD + li], p, dv, 0, 0, 0);
-          dk = __builtin_amdgcn_mfma_f32_16x16x4f32(Qs[q * HD + li], ds, dk, 0, 0, 0);
-        }
+      for (int r = 0; r < 4; ++r) {
+        const int q = qt * 16 + 4 * g + r;
+        const bool ok = kok && q < n;
+        const float p = ok ? __expf(s[r] * a.scale - Ls[q]) : 0.f;
+        const float ds = p * (dp[r] - Ds[q]) * a.scale;
+        dv = __builtin_amdgcn_mfma_f32_16x16x4f32(Os[q * HD + li], p, dv, 0, 0, 0);
+        dk = __builtin_amdgcn_mfma_f32_16x16x4f32(Qs[q * HD + li], ds, dk, 0, 0, 0);
       }
     }
     if (kok) {
@@ -561,9 +587,163 @@ __global__ __launch_bounds__(1024) void attn_bwd_dkv_kernel(AttnArgs a) {
       T* vp_ = kp_ + NH * HD;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        kp_[r] = from_f32<T>(dk[r]);
-        vp_[r] = from_f32<T>(dv[r]);
+        kp_[r] = dk[r];
+        vp_[r] = dv[r];
       }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ backward, bf16
+// The same two gifts of the MFMA as in the forward.  The scores are rebuilt with the forward's 16-bit multiplier
+// (whichever operand of S = Q K^T sits in registers carries x * scale * log2(e) as [hi | lo]; the streamed operand's
+// lanes of k-slots 16..31 re-read the row), and the per-query constants enter through the accumulator input:
+//   S' = Q K^T - L2        (C = -lse * log2 e)         P  = exp2(S')
+//   dP' = dO V^T - delta   (C = -delta)                dS = P * dP' * scale, `* scale` applied to the 16x16 result
+// One exp and one multiply per score are left on the VALU (six operations before: scale, subtract, clamp, exp,
+// subtract, two multiplies).  Both kernels were VALU-issue bound: 343 -> 214 us for the pair at n = 768, batch 8.
+
+// dQ: waves own query tiles; S^T orientation (key on the accumulator row, the lane's own query on the column, so C is
+// one value per lane).  A operands (K, V rows) stream from LDS, B operands (q' = [hi | lo], dO = [dO | 0]) are registers.
+__global__ __launch_bounds__(512) void attn_bwd_dq_bf16_kernel(AttnArgs a) {
+  typedef bf16_t T;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int n = a.n, npad = a.npad, ldt = npad + 8;
+  T* Ks = (T*)smem;                 // [npad][16]
+  T* Vs = Ks + npad * HD;           // [npad][16]
+  T* Kt = Vs + npad * HD;           // K^T [16][ldt]
+  const int gh = blockIdx.x / a.split, sp = blockIdx.x - gh * a.split, nwv = blockDim.x >> 6;
+  const int grp = gh / NH, h = gh - grp * NH;
+  const T* base = (const T*)a.qkv + (int64_t)grp * n * QKV_LD + h * HD;
+  stage_head<T>(base + NH * HD, QKV_LD, n, npad, Ks, Kt, ldt);
+  stage_head<T>(base + 2 * NH * HD, QKV_LD, n, npad, Vs, nullptr, 0);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const T* krow = Ks + li * HD + 8 * (g & 1);
+  const T* vrow = Vs + li * HD + 8 * (g & 1);
+  const int npairs = npad >> 5, pfull = n >> 5;
+  const float sl0 = a.scale * 1.44269504088896340736f;
+  for (int qt = sp + a.split * wave; qt * 16 < n; qt += nwv * a.split) {
+    const int q = qt * 16 + li;
+    const bool qok = q < n;
+    const int64_t row = (int64_t)grp * n + q;
+    const bf16x8 qv = load_scaled_hilo(qok ? base + (int64_t)q * QKV_LD : nullptr, g, sl0);
+    bf16x8 dov = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (qok && g < 2) dov = *reinterpret_cast<const bf16x8*>((const T*)a.dout + row * OUT_LD + h * HD + 8 * g);
+    const float nl2 = qok ? -a.lse[row * NH + h] * 1.44269504088896340736f : 0.f;
+    const float ndl = qok ? -a.delta[row * NH + h] : 0.f;
+    const f32x4 cl = {nl2, nl2, nl2, nl2}, cd = {ndl, ndl, ndl, ndl};
+    f32x4 dq = {0.f, 0.f, 0.f, 0.f};
+    auto step = [&](int kp, auto masked) {
+      const bf16x8 ka = *reinterpret_cast<const bf16x8*>(krow + kp * 32 * HD);
+      const bf16x8 kb = *reinterpret_cast<const bf16x8*>(krow + kp * 32 * HD + 16 * HD);
+      const bf16x8 va = *reinterpret_cast<const bf16x8*>(vrow + kp * 32 * HD);
+      const bf16x8 vb = *reinterpret_cast<const bf16x8*>(vrow + kp * 32 * HD + 16 * HD);
+      const f32x4 sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qv, cl, 0, 0, 0);       // S'^T[key][q]
+      const f32x4 sb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kb, qv, cl, 0, 0, 0);
+      const f32x4 da = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, dov, cd, 0, 0, 0);      // dP'^T[key][q]
+      const f32x4 db = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vb, dov, cd, 0, 0, 0);
+      bf16x8 dsb;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float xa = __builtin_amdgcn_exp2f(sa[r]) * da[r], xb = __builtin_amdgcn_exp2f(sb[r]) * db[r];
+        if constexpr (decltype(masked)::value) {
+          // a padding key has K = V = 0, so S' = -L2: its weight is dropped here rather than trusted to stay finite
+          xa = kp * 32 + 4 * g + r < n ? xa : 0.f;
+          xb = kp * 32 + 16 + 4 * g + r < n ? xb : 0.f;
+        }
+        dsb[r] = (bf16_t)xa;
+        dsb[4 + r] = (bf16_t)xb;
+      }
+      const bf16x4 k0 = *reinterpret_cast<const bf16x4*>(Kt + li * ldt + kp * 32 + 4 * g);
+      const bf16x4 k1 = *reinterpret_cast<const bf16x4*>(Kt + li * ldt + kp * 32 + 16 + 4 * g);
+      const bf16x8 kt8 = {k0[0], k0[1], k0[2], k0[3], k1[0], k1[1], k1[2], k1[3]};
+      dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt8, dsb, dq, 0, 0, 0);
+    };
+    for (int kp = 0; kp < pfull; ++kp) step(kp, std::false_type{});
+    for (int kp = pfull; kp < npairs; ++kp) step(kp, std::true_type{});
+    if (qok) {
+      const bf16x4 ov = {(bf16_t)(dq[0] * a.scale), (bf16_t)(dq[1] * a.scale), (bf16_t)(dq[2] * a.scale), (bf16_t)(dq[3] * a.scale)};
+      *reinterpret_cast<bf16x4*>((T*)a.dqkv + row * QKV_LD + h * HD + 4 * g) = ov;
+    }
+  }
+}
+
+// dK, dV: waves own key tiles; S orientation (query on the accumulator row: C is four values per lane and step, read
+// from LDS, where -L2 and -delta are staged once).  A operands (Q, dO rows) stream from LDS, B operands
+// (k' = [hi | lo], V = [V | 0]) are registers.
+__global__ __launch_bounds__(1024) void attn_bwd_dkv_bf16_kernel(AttnArgs a) {
+  typedef bf16_t T;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int n = a.n, npad = a.npad, ldt = npad + 8;
+  T* Qs = (T*)smem;                      // [npad][16]
+  T* Os = Qs + npad * HD;                // dO [npad][16]
+  T* Qt = Os + npad * HD;                // Q^T, dO^T [16][ldt]
+  T* Ot = Qt + HD * ldt;
+  float* Ls = (float*)(Ot + HD * ldt);   // -lse * log2 e [npad], -delta [npad]
+  float* Ds = Ls + npad;
+  const int gh = blockIdx.x / a.split, sp = blockIdx.x - gh * a.split, nwv = blockDim.x >> 6;
+  const int grp = gh / NH, h = gh - grp * NH;
+  const T* base = (const T*)a.qkv + (int64_t)grp * n * QKV_LD + h * HD;
+  const T* dob = (const T*)a.dout + (int64_t)grp * n * OUT_LD + h * HD;
+  stage_head<T>(base, QKV_LD, n, npad, Qs, Qt, ldt);
+  stage_head<T>(dob, OUT_LD, n, npad, Os, Ot, ldt);
+  for (int i = threadIdx.x; i < npad; i += blockDim.x) {
+    Ls[i] = i < n ? -a.lse[((int64_t)grp * n + i) * NH + h] * 1.44269504088896340736f : 0.f;
+    Ds[i] = i < n ? -a.delta[((int64_t)grp * n + i) * NH + h] : 0.f;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const T* qrow = Qs + li * HD + 8 * (g & 1);
+  const T* orow = Os + li * HD + 8 * (g & 1);
+  const int npairs = npad >> 5;
+  const float sl0 = a.scale * 1.44269504088896340736f;
+  for (int kt = sp + a.split * wave; kt * 16 < n; kt += nwv * a.split) {
+    const int key = kt * 16 + li;
+    const bool kok = key < n;
+    const bf16x8 kf = load_scaled_hilo(kok ? base + NH * HD + (int64_t)key * QKV_LD : nullptr, g, sl0);
+    bf16x8 vf = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (kok && g < 2) vf = *reinterpret_cast<const bf16x8*>(base + 2 * NH * HD + (int64_t)key * QKV_LD + 8 * g);
+    f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dv = dk;
+    // no masks: a padding query has Q = dO = 0 and L2 = delta = 0 (P = 1, dS = 0) and meets zero dO^T / Q^T columns; a
+    // padding key's column is never stored
+    for (int qp = 0; qp < npairs; ++qp) {
+      const bf16x8 qa = *reinterpret_cast<const bf16x8*>(qrow + qp * 32 * HD);
+      const bf16x8 qb = *reinterpret_cast<const bf16x8*>(qrow + qp * 32 * HD + 16 * HD);
+      const bf16x8 oa = *reinterpret_cast<const bf16x8*>(orow + qp * 32 * HD);
+      const bf16x8 ob = *reinterpret_cast<const bf16x8*>(orow + qp * 32 * HD + 16 * HD);
+      const f32x4 la = *reinterpret_cast<const f32x4*>(Ls + qp * 32 + 4 * g), lb = *reinterpret_cast<const f32x4*>(Ls + qp * 32 + 16 + 4 * g);
+      const f32x4 ea = *reinterpret_cast<const f32x4*>(Ds + qp * 32 + 4 * g), eb = *reinterpret_cast<const f32x4*>(Ds + qp * 32 + 16 + 4 * g);
+      const f32x4 sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf, la, 0, 0, 0);       // S'[q][key]: rows q = 4g + r
+      const f32x4 sb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qb, kf, lb, 0, 0, 0);
+      const f32x4 da = __builtin_amdgcn_mfma_f32_16x16x32_bf16(oa, vf, ea, 0, 0, 0);       // dP'[q][key]
+      const f32x4 db = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ob, vf, eb, 0, 0, 0);
+      bf16x8 pb, dsb;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p0 = __builtin_amdgcn_exp2f(sa[r]), p1 = __builtin_amdgcn_exp2f(sb[r]);
+        pb[r] = (bf16_t)p0;
+        pb[4 + r] = (bf16_t)p1;
+        dsb[r] = (bf16_t)(p0 * da[r]);
+        dsb[4 + r] = (bf16_t)(p1 * db[r]);
+      }
+      const bf16x4 o0 = *reinterpret_cast<const bf16x4*>(Ot + li * ldt + qp * 32 + 4 * g);
+      const bf16x4 o1 = *reinterpret_cast<const bf16x4*>(Ot + li * ldt + qp * 32 + 16 + 4 * g);
+      const bf16x8 ot8 = {o0[0], o0[1], o0[2], o0[3], o1[0], o1[1], o1[2], o1[3]};
+      dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ot8, pb, dv, 0, 0, 0);
+      const bf16x4 q0 = *reinterpret_cast<const bf16x4*>(Qt + li * ldt + qp * 32 + 4 * g);
+      const bf16x4 q1 = *reinterpret_cast<const bf16x4*>(Qt + li * ldt + qp * 32 + 16 + 4 * g);
+      const bf16x8 qt8 = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
+      dk = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt8, dsb, dk, 0, 0, 0);
+    }
+    if (kok) {
+      T* kp_ = (T*)a.dqkv + ((int64_t)grp * n + key) * QKV_LD + NH * HD + h * HD + 4 * g;
+      const bf16x4 kv = {(bf16_t)(dk[0] * a.scale), (bf16_t)(dk[1] * a.scale), (bf16_t)(dk[2] * a.scale), (bf16_t)(dk[3] * a.scale)};
+      const bf16x4 vv = {(bf16_t)dv[0], (bf16_t)dv[1], (bf16_t)dv[2], (bf16_t)dv[3]};
+      *reinterpret_cast<bf16x4*>(kp_) = kv;
+      *reinterpret_cast<bf16x4*>(kp_ + NH * HD) = vv;
     }
   }
 }
@@ -619,8 +799,8 @@ extern "C" int pb_attention_fwd(const void* qkv, void* out, float* lse, int64_t 
     // round of workgroups fills the chip (512-thread workgroups at 3 per CU left a third of the second round empty)
     const int threads = onepass_threads(n);
     a.split = attn_split(G, n, threads);
-    if (int rc = set_lds(attn_fwd_onepass_kernel<false>, lds)) return rc;
-    hipLaunchKernelGGL(attn_fwd_onepass_kernel<false>, dim3((unsigned)(G * NH * a.split)), dim3(threads), lds, (hipStream_t)stream, a);
+    if (int rc = set_lds(attn_fwd_onepass_bf16_kernel, lds)) return rc;
+    hipLaunchKernelGGL(attn_fwd_onepass_bf16_kernel, dim3((unsigned)(G * NH * a.split)), dim3(threads), lds, (hipStream_t)stream, a);
   } else if (dtype == PB_BF16) {
     if (int rc = set_lds(attn_fwd_kernel<bf16_t>, lds)) return rc;
     hipLaunchKernelGGL(attn_fwd_kernel<bf16_t>, grid, dim3(ATT_THREADS), lds, (hipStream_t)stream, a);
@@ -645,8 +825,8 @@ extern "C" int pb_attention_fwd_fp8(const void* qkv, void* out, float* lse, int6
   const int threads = onepass_threads(n);
   a.split = attn_split(G, n, threads);
   const size_t lds = (size_t)a.npad * HD + (size_t)HD * (a.npad + 16) + 64;
-  if (int rc = set_lds(attn_fwd_onepass_kernel<true>, lds)) return rc;
-  hipLaunchKernelGGL(attn_fwd_onepass_kernel<true>, dim3((unsigned)(G * NH * a.split)), dim3(threads), lds, (hipStream_t)stream, a);
+  if (int rc = set_lds(attn_fwd_onepass_fp8_kernel, lds)) return rc;
+  hipLaunchKernelGGL(attn_fwd_onepass_fp8_kernel, dim3((unsigned)(G * NH * a.split)), dim3(threads), lds, (hipStream_t)stream, a);
   PB_LAUNCH_CHECK();
   return 0;
 }
@@ -663,25 +843,26 @@ extern "C" int pb_attention_bwd(const void* qkv, const void* out, const void* do
   const int64_t R = G * n;
   const bool bf = dtype == PB_BF16;
   const size_t es = bf ? 2 : 4;
-  const size_t rm = (size_t)a.npad * HD * es, tr = bf ? (size_t)HD * (a.npad + 8) * es : 0;
-  const size_t lds_dq = 2 * rm + tr;
-  const size_t lds_dkv = 2 * rm + 2 * tr + 2 * (size_t)a.npad * 4;
+  const size_t rm = (size_t)a.npad * HD * es;                                              // one row-major slice
   dim3 grid((unsigned)(G * NH * a.split));
   AttnArgs akv = a;
   akv.split = attn_split(G, n, ATT_THREADS_DKV);
   dim3 grid_kv((unsigned)(G * NH * akv.split));
   if (bf) {
     hipLaunchKernelGGL(attn_delta_kernel<bf16_t>, dim3((unsigned)pb_cdiv(R * NH, 256)), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)out, delta, R);
-    if (int rc = set_lds(attn_bwd_dkv_kernel<bf16_t>, lds_dkv)) return rc;
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<bf16_t>, grid_kv, dim3(ATT_THREADS_DKV), lds_dkv, st, akv);
-    if (int rc = set_lds(attn_bwd_dq_kernel<bf16_t>, lds_dq)) return rc;
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<bf16_t>, grid, dim3(ATT_THREADS), lds_dq, st, a);
+    const size_t tr = (size_t)HD * (a.npad + 8) * es;                                      // one transposed slice
+    const size_t lds_dkv = 2 * rm + 2 * tr + 2 * (size_t)a.npad * 4, lds_dq = 2 * rm + tr;
+    if (int rc = set_lds(attn_bwd_dkv_bf16_kernel, lds_dkv)) return rc;
+    hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel, grid_kv, dim3(ATT_THREADS_DKV), lds_dkv, st, akv);
+    if (int rc = set_lds(attn_bwd_dq_bf16_kernel, lds_dq)) return rc;
+    hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel, grid, dim3(ATT_THREADS), lds_dq, st, a);
   } else {
     hipLaunchKernelGGL(attn_delta_kernel<float>, dim3((unsigned)pb_cdiv(R * NH, 256)), dim3(256), 0, st, (const float*)dout, (const float*)out, delta, R);
-    if (int rc = set_lds(attn_bwd_dkv_kernel<float>, lds_dkv)) return rc;
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<float>, grid_kv, dim3(ATT_THREADS_DKV), lds_dkv, st, akv);
-    if (int rc = set_lds(attn_bwd_dq_kernel<float>, lds_dq)) return rc;
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<float>, grid, dim3(ATT_THREADS), lds_dq, st, a);
+    const size_t lds_dq = 2 * rm, lds_dkv = 2 * rm + 2 * (size_t)a.npad * 4;
+    if (int rc = set_lds(attn_bwd_dkv_kernel, lds_dkv)) return rc;
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid_kv, dim3(ATT_THREADS_DKV), lds_dkv, st, akv);
+    if (int rc = set_lds(attn_bwd_dq_kernel, lds_dq)) return rc;
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(ATT_THREADS), lds_dq, st, a);
   }
   PB_LAUNCH_CHECK();
   return 0;

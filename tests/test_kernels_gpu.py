@@ -488,6 +488,37 @@ def test_attention(K, G, n, dtype):
     check("attn_dqkv", dq, dq_ref, dtype, 1.5)
 
 
+@pytest.mark.parametrize("G,n", [(3, 32), (2, 147), (2, 768), (1, 784)])
+@pytest.mark.parametrize("amp", [0.5, 1.5, 6.0, "mixed", "outlier", "rising", "negative"])
+def test_attention_lazy_running_maximum(K, G, n, amp):
+    """bf16 one-pass forward: the running maximum rides in a spare k-slot of the score MFMA (as minus a bf16 value) and
+    is only raised when some score exceeds it.  Against the oracle on inputs that exercise the update path: large
+    amplitudes, every third query scaled by 8, one huge key per group, keys whose scores keep RISING along the sequence
+    (an update in nearly every step), and all-negative scores (first reference below zero); the padding keys of the
+    ragged sizes must come out as exact zeros whatever the reference is."""
+    bf = torch.bfloat16
+    qkv = rnd((G * n, 384), torch.float32, 62, scale=amp if isinstance(amp, float) else 1.0)
+    if amp == "mixed":
+        qkv[::3, :128] *= 8.0
+    elif amp == "outlier":
+        qkv[5::n, 128:256] *= 5.0
+    elif amp == "rising":
+        ramp = torch.linspace(0.2, 6.0, n).repeat(G)[:, None]
+        qkv[:, :128] = qkv[:, :128].abs()
+        qkv[:, 128:256] = qkv[:, 128:256].abs() * ramp
+    elif amp == "negative":
+        qkv[:, :128] = qkv[:, :128].abs() * 3.0
+        qkv[:, 128:256] = -qkv[:, 128:256].abs() * 3.0
+    qkv = qkv.to(bf)
+    out_ref, lse_ref = R.attention_fwd(qkv, G, n, 0.25)
+    out, lse = K.attention_fwd(dev(qkv), G, n, 0.25)
+    assert torch.isfinite(out.float()).all() and torch.isfinite(lse).all()
+    check("attn_out", out, out_ref, bf)
+    # the log-sum-exp moves with the re-rounded, pre-scaled Q operand: 2^-9 of the largest score, absolute
+    tol = 1e-3 * max(1.0, float(lse_ref.abs().max())) + 2.0 ** -8 * float(lse_ref.abs().max())
+    assert float((lse.cpu() - lse_ref).abs().max()) <= tol
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("G,n,D", [(16, 12, 16), (3, 1, 40), (8, 147, 64), (5, 300, 96), (2, 784, 144), (1, 1000, 240), (7, 33, 256)])
 def test_linear_attention(K, G, n, D, dtype):

@@ -42,6 +42,13 @@ for case in (args or list(protocol.GRAD_CASES)):
                 r = np.array([v for v, _ in rr])
                 print(f"[{case}/{mode} bf16] ours / reference bf16 deviation over {len(r)} tensors: median {np.median(r):.2f} p90 {np.percentile(r, 90):.2f} "
                       f"p99 {np.percentile(r, 99):.2f} max {r.max():.2f} ({max(rr)[1]})")
+            if "--by-depth" in sys.argv:      # in parameter order (input side first): our error, the reference's, the ratio
+                order = [k for k in res if k.startswith("gproj/")]
+                d = {k: e for e, k in rows}
+                for k in order:
+                    ref = gold.get("refbf16_mean/grad/" + k[6:])
+                    if ref is not None:
+                        print("      %-58s ours %.2e  ref %.2e  ratio %5.2f" % (k[6:], d[k], float(ref[0]), d[k] / max(float(ref[0]), 1e-12)))
         fwd = [(e, k) for e, k in rows if k.split("/")[0] not in ("gnorm", "gproj", "gsamp")]
         print(f"   forward keys: {[(k, '%.1e' % e) for e, k in fwd]}")
         print(f"   worst: {[(k, '%.1e' % e) for e, k in rows[:6]]}", flush=True)
