@@ -137,6 +137,11 @@ def main():
         for _ in range(3):
             fn()
         torch.cuda.synchronize()
+        if dp_path:
+            # RCCL's watchdog thread still holds the warm-up steps' work objects until its next poll (every 100 ms) and
+            # queries their end events; on ROCm that query fails with hipErrorCapturedEvent once RCCL's stream has joined a
+            # capture - and the watchdog takes the process down.  Seen once in ~10 runs; let it retire them first.
+            time.sleep(0.5)
         g = torch.cuda.CUDAGraph()
         K.reset_zero_arena()              # the zero-filled scratch must be allocated AND filled inside the graph
         with torch.cuda.graph(g, stream=run_stream):
@@ -281,10 +286,14 @@ def main():
                     loss.backward()
                 opt_step_reduced()
                 return loss
+        # (in line: with the weight gradients on their side stream - kernels.weight_grad_branch, how the timed steps ran -
+        # two kernels share the chip and an event pair brackets both; the per-kernel numbers are about each kernel alone)
+        overlap, K._WGRAD_OVERLAP = K._WGRAD_OVERLAP, False
         K.start_profile()
         for _ in range(args.steps):
             prof_step()
         prof = K.stop_profile()
+        K._WGRAD_OVERLAP = overlap
         detail = {k: v for k, v in prof.items() if " | " in k}
         prof = {k: v for k, v in prof.items() if " | " not in k}
         if os.environ.get("PB_BENCH_DETAIL"):
@@ -318,7 +327,8 @@ def main():
         roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "bytes_per_launch": int(d["bytes"] / d["launches"]), "avg_launch_us": round(d["ms"] / d["launches"] * 1e3, 2),
-                    "launches": d["launches"], "measured_over": f"{args.steps} steps re-run with HIP events around every launch"}
+                    "launches": d["launches"],
+                    "measured_over": f"{args.steps} steps re-run in line (weight-gradient side stream off) with HIP events around every launch"}
     if dp_path:
         dist.barrier()
 
@@ -332,6 +342,9 @@ def main():
                        "precision": "fp32 params, bf16 activations (autocast)", "parallelism": f"dp{world}",
                        "step": "fwd + CE loss + bwd + RCCL grad all-reduce (n>1) + fused AdamW (%s)" % ("picklebot_amd.FlatAdamW" if flat_opt else "torch fused"),
                        "launch": launch_mode,
+                       "streams": ("each block's weight gradients on a second HIP stream beside the next block's data-gradient chain, "
+                                   "joined when backward ends (kernels.weight_grad_branch)") if K._WGRAD_OVERLAP else "one",
+
                        "weights": "random init (seed 1234)", "loss": round(float(loss.item()), 4)},
             "roofline": roofline,
             "host_enqueue_ms_per_step": round(host_enqueue_ms, 3),

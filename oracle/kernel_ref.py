@@ -25,6 +25,17 @@ class deferred_reductions:
         return False
 
 
+def weight_grad_branch(ref, params, thunks, keep, tag=""):
+    """Mirror of kernels.weight_grad_branch (the product may run a block's weight-gradient launches on a side stream and
+    join later; the mirror runs them in place)."""
+    for t in thunks:
+        t()
+
+
+def join_weight_grads():
+    pass
+
+
 def zeros(shape, device):
     """Mirror of kernels.zeros (the product carves these from a pre-zeroed arena)."""
     return torch.zeros(shape, dtype=torch.float32, device=device)

@@ -301,31 +301,35 @@ class _Bottleneck(torch.autograd.Function):
         d2 = d5.view(-1, E)
         dw2, dwdw, dw1 = _zeros_many(x5, (Cout, E), (E, wdw[0].numel()), (E, Cin))
         g_scale = g_shift = dse_w1 = dse_b1 = dse_w2 = dse_b2 = None
-        with K.deferred_reductions():      # the three weight gradients' partial tiles are added up by ONE launch
-            # projection conv: weight gradient sees the SE-scaled input, data gradient is w.r.t. it
-            K.pw_bwd_weight(dz, d2, dw2, row_scale=se_scale, rows_per_group=Rd)
-            dS2 = K.pw_fwd(dz, w2.view(Cout, E), w_transposed=True)
-            if has_se:
-                Cm = se_w1.shape[0]
-                dpart = K.rowgroup_partials(dS2, d2, N)
-                g_shift, dse_w1, dse_b1, dse_w2, dse_b2 = K.se_fused_bwd(dpart, pool, 1.0 / R2, se_scale, hidden,
-                                                                         se_w1.view(Cm, E), se_w2.view(E, Cm))
-                g_scale = se_scale
-                dse_w1, dse_w2 = dse_w1.view_as(se_w1), dse_w2.view_as(se_w2)
-            dS5 = dS2.view(N, Td, Ho, Wo, E)
-            dkernel, dstride, dpad = ctx.dconv       # (x5 here = the gathered frames when the block skips input frames)
-            if ctx.fused:
-                K.xdw_bwd_weight(dS5, x5, w1.view(E, Cin), dwdw, kernel, stride, pad, g_scale, g_shift)
-            else:
-                K.dw_bwd_weight(dS5, e5, dwdw, dkernel, dstride, dpad, g_scale, g_shift)
-            dE5 = K.dw_bwd_data(dS5, wdw.view(E, -1), (Ts, H, W), dkernel, dstride, dpad, g_scale, g_shift)
-            dE2 = dE5.view(-1, E)
-            K.pw_bwd_weight(dE2, x5.view(-1, Cin), dw1)
-            dx5 = None
-            if ctx.needs_input_grad[0]:
-                dx5 = K.pw_fwd(dE2, w1.view(E, Cin), w_transposed=True).view(N, Ts, H, W, Cin)
-                if compact is not None and Ts != T:       # exact zeros in the input frames the block never read
-                    dx5 = K.frames_scatter(dx5, T, compact[0], compact[1])
+        # The chain (data gradients) runs here; the three weight gradients are collected and issued as one branch at the
+        # end (K.weight_grad_branch: their partial tiles are added up by ONE launch; on a side stream when that is safe).
+        wgrads = []
+        # projection conv: weight gradient sees the SE-scaled input, data gradient is w.r.t. it
+        wgrads.append(lambda: K.pw_bwd_weight(dz, d2, dw2, row_scale=se_scale, rows_per_group=Rd))
+        dS2 = K.pw_fwd(dz, w2.view(Cout, E), w_transposed=True)
+        if has_se:
+            Cm = se_w1.shape[0]
+            dpart = K.rowgroup_partials(dS2, d2, N)
+            g_shift, dse_w1, dse_b1, dse_w2, dse_b2 = K.se_fused_bwd(dpart, pool, 1.0 / R2, se_scale, hidden,
+                                                                     se_w1.view(Cm, E), se_w2.view(E, Cm))
+            g_scale = se_scale
+            dse_w1, dse_w2 = dse_w1.view_as(se_w1), dse_w2.view_as(se_w2)
+        dS5 = dS2.view(N, Td, Ho, Wo, E)
+        dkernel, dstride, dpad = ctx.dconv       # (x5 here = the gathered frames when the block skips input frames)
+        if ctx.fused:
+            wgrads.append(lambda: K.xdw_bwd_weight(dS5, x5, w1.view(E, Cin), dwdw, kernel, stride, pad, g_scale, g_shift))
+        else:
+            wgrads.append(lambda: K.dw_bwd_weight(dS5, e5, dwdw, dkernel, dstride, dpad, g_scale, g_shift))
+        dE5 = K.dw_bwd_data(dS5, wdw.view(E, -1), (Ts, H, W), dkernel, dstride, dpad, g_scale, g_shift)
+        dE2 = dE5.view(-1, E)
+        wgrads.append(lambda: K.pw_bwd_weight(dE2, x5.view(-1, Cin), dw1))
+        dx5 = None
+        if ctx.needs_input_grad[0]:
+            dx5 = K.pw_fwd(dE2, w1.view(E, Cin), w_transposed=True).view(N, Ts, H, W, Cin)
+            if compact is not None and Ts != T:       # exact zeros in the input frames the block never read
+                dx5 = K.frames_scatter(dx5, T, compact[0], compact[1])
+        K.weight_grad_branch(dE2, (w1, wdw, w2), wgrads,
+                             (dz, d2, dS2, e5, x5, dE2, w1, se_scale, g_scale, g_shift, dw2, dwdw, dw1), "bneck")
         return (dx5, dw1.view_as(w1), dwdw.view_as(wdw), dw2.view_as(w2), dse_w1, dse_b1, dse_w2, dse_b2, dgamma,
                 dbeta, None, None, None, None)
 
@@ -466,7 +470,6 @@ class _PwBnAct(torch.autograd.Function):
             dse_w1, dse_w2 = dse_w1.view_as(se_w1), dse_w2.view_as(se_w2)
             dz = K.affine_act_fwd(du, row_scale=se_scale, row_shift=g_shift, rows_per_group=R)
         dw = _zeros((Cout, Cin), x5)
-        K.pw_bwd_weight(dz, x2, dw)
         dbias = None
         if ctx.has_bias:
             st = _zeros((K.REPL, 2, Cout), x5)
@@ -475,6 +478,7 @@ class _PwBnAct(torch.autograd.Function):
         dx5 = None
         if ctx.needs_input_grad[0]:
             dx5 = K.pw_fwd(dz, w.view(Cout, Cin), w_transposed=True).view(x5.shape)
+        K.weight_grad_branch(dz, (w,), [lambda: K.pw_bwd_weight(dz, x2, dw)], (dz, x2, x5, dw), "pw")
         return dx5, dw.view_as(w), dbias, dse_w1, dse_b1, dse_w2, dse_b2, dgamma, dbeta, None, None, None, None
 
 
@@ -569,7 +573,6 @@ class _Depthwise(torch.autograd.Function):
         C = x5.shape[-1]
         dy5 = _contig5(dy5)
         dw = _zeros((C, w[0].numel()), x5)
-        K.dw_bwd_weight(dy5, x5, dw, cfg["kernel"], cfg["stride"], cfg["pad_front"])
         dx5 = None
         if ctx.needs_input_grad[0]:
             dx5 = K.dw_bwd_data(dy5, w.view(C, -1), tuple(x5.shape[1:4]), cfg["kernel"], cfg["stride"], cfg["pad_front"])
@@ -578,6 +581,8 @@ class _Depthwise(torch.autograd.Function):
             st = _zeros((K.REPL, 2, C), x5)
             K.chan_stats(dy5.view(-1, C), st)
             dbias = st[:, 0].sum(0)
+        K.weight_grad_branch(dy5, (w,), [lambda: K.dw_bwd_weight(dy5, x5, dw, cfg["kernel"], cfg["stride"], cfg["pad_front"])],
+                             (dy5, x5, dw), "dw")
         return dx5, dw.view_as(w), dbias, None
 
 
@@ -636,8 +641,11 @@ class _ConvBnAct(torch.autograd.Function):
         else:
             dz, dgamma, dbeta = _bn_act_backward(dy2, z2, ctx.bnc, gamma, cfg["act"], cfg["slope"], None, 0)
         dz5 = dz.view(z5.shape)
-        dwp = K.conv3d_bwd_weight(dz5, x5, kernel, stride, pf)
-        dw = K.conv_weight_prep(dwp, 2, Cout, Cin, taps).view_as(w)
+        wg = {}
+
+        def weight_gradient():
+            wg["dwp"] = K.conv3d_bwd_weight(dz5, x5, kernel, stride, pf)
+            wg["dw"] = K.conv_weight_prep(wg["dwp"], 2, Cout, Cin, taps).view_as(w)
         dbias = None
         if ctx.has_bias:
             st = _zeros((K.REPL, 2, Cout), x5)
@@ -650,7 +658,10 @@ class _ConvBnAct(torch.autograd.Function):
             wt = K.conv_weight_prep(w.reshape(-1), 1, Cout, Cin, taps)            # [Cin][taps reversed][Cout]
             pad_t = tuple(k - 1 - p for k, p in zip(kernel, pf))
             dx5 = K.conv3d_fwd(dz5, wt, Cin, kernel, (1, 1, 1), pad_t, (T, H, W))
-        return dx5, dw, dbias, dgamma, dbeta, None, None, None
+        K.weight_grad_branch(dz5, (w,), [weight_gradient], (dz5, x5, wg), "conv")
+        # (a fresh view: autograd adopts a gradient tensor only when nobody else holds the OBJECT - the branch keeps `wg` -
+        # and would otherwise clone it on this stream at once, before the side stream has written it)
+        return dx5, wg["dw"].view_as(w), dbias, dgamma, dbeta, None, None, None
 
 
 def conv_bn_act(x5, conv_weight, conv_bias, bn, *, stride, pad_front, pad_back=None, act="none", slope=0.0, training=False):
@@ -734,15 +745,15 @@ class _AttnBlock(torch.autograd.Function):
         D = x.shape[1]
         dy = dy if dy.is_contiguous() else dy.contiguous()
         dw_out, dw_qkv = _zeros_many(x, tuple(w_out.shape), tuple(w_qkv.shape))
-        K.pw_bwd_weight(dy, o, dw_out)
         do = K.pw_fwd(dy, w_out, w_transposed=True)
         dqkv = K.attention_bwd(qkv, o, do, lse, G, n, scale)
-        K.pw_bwd_weight(dqkv, xn, dw_qkv)
         dxn = K.pw_fwd(dqkv, w_qkv, w_transposed=True)
         dx = K.layernorm_bwd(x, dxn, stat, eps)
         if residual:
             K.copy_cols(dy, 0, dx, 0, D, accumulate=True)
-        return dx, dw_qkv, dw_out, None, None, None, None, None
+        K.weight_grad_branch(dy, (w_qkv, w_out), [lambda: K.pw_bwd_weight(dy, o, dw_out), lambda: K.pw_bwd_weight(dqkv, xn, dw_qkv)],
+                             (dy, o, dqkv, xn, dw_out, dw_qkv), "attn")
+        return dx, dw_qkv.view_as(w_qkv), dw_out.view_as(w_out), None, None, None, None, None    # (fresh views, see _ConvBnAct)
 
 
 class _FFBlock(torch.autograd.Function):
@@ -766,12 +777,12 @@ class _FFBlock(torch.autograd.Function):
         D = x.shape[1]
         dy = dy if dy.is_contiguous() else dy.contiguous()
         dw1, dw2 = _zeros_many(x, tuple(w1.shape), tuple(w2.shape))
-        K.pw_bwd_weight(dy, h, dw2)
         dh = K.pw_fwd(dy, w2, w_transposed=True)
         dhpre = K.act_bwd_reduce(dh, hpre, act="silu")
-        K.pw_bwd_weight(dhpre, x, dw1)
         dx = K.pw_fwd(dhpre, w1, w_transposed=True, residual=dy if ctx.residual else None)
-        return dx, dw1, dw2, None
+        K.weight_grad_branch(dy, (w1, w2), [lambda: K.pw_bwd_weight(dy, h, dw2), lambda: K.pw_bwd_weight(dhpre, x, dw1)],
+                             (dy, h, dhpre, x, dw1, dw2), "ff")
+        return dx, dw1.view_as(w1), dw2.view_as(w2), None                                          # (fresh views, see _ConvBnAct)
 
 
 _fp8_attention = False

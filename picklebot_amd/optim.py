@@ -83,6 +83,7 @@ class FlatAdamW(torch.optim.Optimizer):
 
     def pack_grads(self):
         """One multi-tensor copy per bucket of whatever backward left in .grad (missing gradients count as zeros)."""
+        K.join_weight_grads()              # (a no-op unless a weight-gradient branch is still in flight)
         if self._reducer is not None:
             self._reducer.pack_grads()
         else:

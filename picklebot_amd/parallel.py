@@ -40,6 +40,11 @@ def bucket_layout(plist, align=16):
     return offs, off
 
 
+def _join_weight_grads():
+    from . import kernels          # (late: this module also serves CPU / gloo processes that never launch a kernel)
+    kernels.join_weight_grads()
+
+
 class GradReducer:
     def __init__(self, module, process_group=None, bucket_bytes=8 << 20, average=True, broadcast_from=0):
         if not dist.is_initialized():
@@ -77,6 +82,7 @@ class GradReducer:
                 views.append(flat[off:off + p.numel()].view_as(p))
                 p.grad = views[-1]
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
+                p._pb_join_aware = True          # (kernels.weight_grad_branch: this hook joins before it reads a gradient)
             self.flat.append(flat)
             self.views.append(views)
             self._need.append(len(plist))
@@ -95,6 +101,7 @@ class GradReducer:
         return hook
 
     def _pack_bucket(self, bi):
+        _join_weight_grads()                     # weight-gradient branches still on the side stream (kernels.py)
         srcs = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.buckets[bi]]
         torch._foreach_copy_(self.views[bi], srcs)
 
@@ -148,6 +155,7 @@ class GradReducer:
         """Gather the .grad tensors a hooks-off backward left behind into the flat buckets (one multi-tensor copy per
         bucket); parameters without a gradient contribute zeros.  Follow with attach_grads() once (after a HIP-graph
         capture: the views stay valid for every replay) so that the optimiser reads the reduced buckets."""
+        _join_weight_grads()
         for views, plist in zip(self.views, self.buckets):
             srcs = [p.grad if p.grad is not None else torch.zeros_like(p) for p in plist]
             torch._foreach_copy_(views, srcs)
@@ -190,6 +198,9 @@ class GradReducer:
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        for plist in self.buckets:
+            for p in plist:
+                p._pb_join_aware = False
 
 
 def setup_distributed(backend=None):

@@ -642,3 +642,73 @@ def test_movinet_a2_depthwise_streaming_at_scale(E, kernel, stride, hw, dtype):
                 assert torch.equal(stream, full), f"chunk {chunk}"
             else:
                 assert rel_err(stream.float().cpu().numpy(), full.float().cpu().numpy()) <= 1e-6, f"chunk {chunk}"
+
+
+def _large3d_train_grads(steps=1, hook=False):
+    torch.manual_seed(3)
+    model = picklebot_amd.MobileNetLarge3D(num_classes=13).to(DEV).train()
+    for m in model.modules():
+        if isinstance(m, (torch.nn.Dropout, torch.nn.Dropout3d)):
+            m.p = 0.0
+    if hook:
+        model.block3[0].pointwise_conv1.weight.register_post_accumulate_grad_hook(lambda p: None)
+    x = torch.randn(4, 3, 8, 64, 64, device=DEV)
+    y = torch.arange(4, device=DEV) % 13
+    for _ in range(steps):
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss = torch.nn.functional.cross_entropy(model(x).float(), y)
+        loss.backward()
+    torch.cuda.synchronize()
+    return {k: p.grad.clone() for k, p in model.named_parameters()}
+
+
+def test_weight_gradient_side_branch_is_bit_identical(monkeypatch):
+    """kernels.weight_grad_branch: a block's weight gradients run on a second HIP stream and are joined when the backward
+    pass ends.  Same kernels in the same order - the gradients must be bit-identical to the in-line schedule; a second
+    backward into existing `.grad` tensors (autograd then ADDS, reading the new gradient on the calling stream at once) and
+    a block whose parameter carries a foreign hook must fall back to the in-line schedule and still be exact."""
+    from picklebot_amd import kernels as K
+    monkeypatch.setattr(K, "_WGRAD_OVERLAP", False)
+    ref = _large3d_train_grads()
+    monkeypatch.setattr(K, "_WGRAD_OVERLAP", True)
+    K.branch_counts.update(side=0, inline=0)
+    got = _large3d_train_grads()
+    nb = K.branch_counts["side"]          # 15 bottlenecks + the 1x1x1 conv / classifier layers around them
+    assert nb >= 15 and K.branch_counts["inline"] == 0, K.branch_counts
+    assert not K._lag, "a weight-gradient branch was left unjoined after backward() returned"
+    assert all(torch.equal(ref[k], got[k]) for k in ref), [k for k in ref if not torch.equal(ref[k], got[k])][:5]
+    # accumulation: the second backward adds into .grad - every block in line, result = the first gradient twice... no:
+    # BatchNorm's running statistics moved in between, so compare against the in-line schedule doing the same thing
+    K.branch_counts.update(side=0, inline=0)
+    acc = _large3d_train_grads(steps=2)
+    assert K.branch_counts["side"] == nb and K.branch_counts["inline"] == nb, K.branch_counts
+    monkeypatch.setattr(K, "_WGRAD_OVERLAP", False)
+    acc_ref = _large3d_train_grads(steps=2)
+    assert all(torch.equal(acc_ref[k], acc[k]) for k in acc_ref)
+    monkeypatch.setattr(K, "_WGRAD_OVERLAP", True)
+    K.branch_counts.update(side=0, inline=0)
+    hooked = _large3d_train_grads(hook=True)
+    assert K.branch_counts["side"] == nb - 1 and K.branch_counts["inline"] == 1, K.branch_counts
+    assert all(torch.equal(ref[k], hooked[k]) for k in ref)
+
+
+@pytest.mark.parametrize("case", ["large3d", "movinet_a2", "mobilevit_s"])
+def test_weight_gradient_side_branch_on_whole_models(case, monkeypatch):
+    """Every block kind that defers its weight gradients (bottleneck, 1x1x1 conv, depthwise, dense conv, attention and
+    feed-forward blocks): the protocol's train-mode gradients with the side stream on are bit-identical to the in-line
+    schedule, every branch ran on the side stream, and none is left unjoined when backward() has returned.  (This is also the
+    guard for the adoption rule: a gradient tensor that autograd CLONES instead of adopting is read on the calling stream
+    before the side stream has written it - it came out as zeros / partial sums before the backward functions returned
+    fresh views.)"""
+    from picklebot_amd import kernels as K
+    res = {}
+    for on in (False, True):
+        monkeypatch.setattr(K, "_WGRAD_OVERLAP", on)
+        K.branch_counts.update(side=0, inline=0)
+        with contextlib.redirect_stdout(io.StringIO()):
+            res[on] = protocol.collect_model_case(picklebot_amd, case, device=DEV, do_eval=False)
+        assert not K._lag
+        if on:
+            assert K.branch_counts["side"] > 0 and K.branch_counts["inline"] == 0, K.branch_counts
+    keys = [k for k in res[False] if k.startswith("grad/")]
+    assert keys and all(torch.equal(res[False][k], res[True][k]) for k in keys), [k for k in keys if not torch.equal(res[False][k], res[True][k])][:5]
