@@ -200,10 +200,12 @@ def main():
         graph_ms = (time.perf_counter() - t0) / (4 * args.steps) * 1e3
         print(f"{w} batch {args.batch}: {graph_ms:.3f} ms/step replayed from a HIP graph ({args.batch / graph_ms * 1e3:.1f} clips/s)")
 
+    overlap, K._WGRAD_OVERLAP = K._WGRAD_OVERLAP, False      # per-kernel numbers in line (one kernel at a time), as in bench.py
     K.start_profile()
     for _ in range(args.steps):
         step()
     prof = K.stop_profile()
+    K._WGRAD_OVERLAP = overlap
     detail = {k: v for k, v in prof.items() if " | " in k}
     prof = {k: v for k, v in prof.items() if " | " not in k}
     tot = sum(d["ms"] for d in prof.values())

@@ -18,7 +18,16 @@ def main():
     shutil.copy(os.path.join(src, "bench.jsonl"), os.path.join(dst, f"{tag}_bench_b32.jsonl"))
     shutil.copy(os.path.join(src, "per_shape.txt"), os.path.join(dst, f"{tag}_per_shape_bench_b32.txt"))
     shutil.copy(os.path.join(src, "pmc_traffic.json"), os.path.join(dst, tag.split("_")[0] + "_pmc_traffic.json"))
-    rows = list(csv.DictReader(open(os.path.join(src, "kernel_stats.csv"))))
+    families(tag, os.path.join(src, "kernel_stats.csv"), os.path.join(dst, f"{tag}_kernel_families_bench_b32.txt"),
+             "PB_WGRAD_OVERLAP=0 (every kernel alone on the chip)")
+    if os.path.exists(os.path.join(src, "kernel_stats_overlap.csv")):
+        shutil.copy(os.path.join(src, "kernel_stats_overlap.csv"), os.path.join(dst, f"{tag}_kernel_stats_overlap_bench_b32.csv"))
+        families(tag, os.path.join(src, "kernel_stats_overlap.csv"), os.path.join(dst, f"{tag}_kernel_families_overlap_bench_b32.txt"),
+                 "default schedule (each block's weight gradients on a second HIP stream: kernels overlap, single durations stretch)")
+
+
+def families(tag, stats_csv, out_path, how):
+    rows = list(csv.DictReader(open(stats_csv)))
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in rows:
         b = base_name(r["Name"])
@@ -26,14 +35,14 @@ def main():
         agg[b][1] += float(r["TotalDurationNs"])
     tot = sum(v[1] for v in agg.values())
     steps = 12   # bench.py --steps 5 --warmup 2: 2 warm-up + 5 timed + the 5 re-run with HIP events
-    out = ["# rocprofv3 --kernel-trace --stats of `python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-graph`",
+    out = ["# rocprofv3 --kernel-trace --stats of `python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-graph`, " + how,
            "# (12 eager steps: 2 warm-up + 5 timed + the 5 re-run with HIP events); template instantiations of a kernel added up",
            f"# (tools/pmc_summary.base_name); full rows: {tag}_kernel_stats_bench_b32.csv",
            "%-34s %10s %12s %10s %7s" % ("kernel", "calls/step", "avg us", "ms/step", "share")]
     for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         out.append("%-34s %10.1f %12.2f %10.3f %6.1f%%" % (k, v[0] / steps, v[1] / v[0] / 1e3, v[1] / steps / 1e6, 100 * v[1] / tot))
     out.append("total kernel time per step: %.3f ms, %d launches per step" % (tot / steps / 1e6, sum(v[0] for v in agg.values()) / steps))
-    open(os.path.join(dst, f"{tag}_kernel_families_bench_b32.txt"), "w").write("\n".join(out) + "\n")
+    open(out_path, "w").write("\n".join(out) + "\n")
     print("\n".join(out[3:9]))
     print(out[-1])
 
