@@ -387,9 +387,11 @@ __global__ __launch_bounds__(256) void dw_strip_wgrad_kernel(StripArgs a) {
 // and the whole block reads one NRxNR patch of dy (2x2 for k=3, 3x3 for k=5): 1-2.25 loads per
 // output instead of k*k masked ones.  dx frames that no output frame reads (t+pt not a multiple of
 // the temporal stride) are written as zeros.
-template <typename T, int K, int CH>
+// KT > 1: (kt,3,3) kernels with temporal stride 1 (MoViNet's stride-2 blocks, movinet.py:98-137): the same 2x2 block sums
+// the patches of the KT output frames td + pt - dt that reach it, each against its own temporal slice of the filter.
+template <typename T, int K, int CH, int KT = 1>
 __global__ __launch_bounds__(256) void dw_strip_bwd_s2_kernel(StripArgs a) {
-  __shared__ __attribute__((aligned(16))) float wl[K * K * 32 * CH];
+  __shared__ __attribute__((aligned(16))) float wl[KT * K * K * 32 * CH];
   constexpr int P = K / 2;
   constexpr int LO = (P - (K - 1)) / 2;       // ceil of a non-positive half (C++ truncates toward zero): 0 for k=3, -1 for k=5
   constexpr int HI = (1 + P) / 2;
@@ -404,9 +406,9 @@ __global__ __launch_bounds__(256) void dw_strip_bwd_s2_kernel(StripArgs a) {
   T* dx = (T*)a.dst;                  // [N, Tdst, Hd, Wd, C]  (gradient of the conv input)
   {
     const int cbase = blockIdx.y * CW;
-    for (int i = tid; i < CW * K * K; i += 256) {
-      const int cl = i / (K * K), tap = i - cl * (K * K);
-      wl[tap * CW + cl] = (cbase + cl < a.C) ? a.w[(int64_t)(cbase + cl) * (K * K) + tap] : 0.f;
+    for (int i = tid; i < CW * KT * K * K; i += 256) {
+      const int cl = i / (KT * K * K), tap = i - cl * (KT * K * K);
+      wl[tap * CW + cl] = (cbase + cl < a.C) ? a.w[(int64_t)(cbase + cl) * (KT * K * K) + tap] : 0.f;
     }
   }
   __syncthreads();
@@ -416,10 +418,6 @@ __global__ __launch_bounds__(256) void dw_strip_bwd_s2_kernel(StripArgs a) {
     const int z = (int)(it / a.xblocks);
     const int xb = (int)(it - (int64_t)z * a.xblocks);
     const int n = z / a.Tdst, td = z - n * a.Tdst;
-    // temporal map of the forward conv: t_in = t_out*t_mul - t_off  =>  t_out = (t_in + t_off)/t_mul
-    const int tn = td + a.t_off;
-    const bool frame_ok = tn >= 0 && (tn % a.t_mul) == 0 && (tn / a.t_mul) < a.Tsrc;
-    const int ts = frame_ok ? tn / a.t_mul : 0;
     const int blk = xb * a.P + p;
     const bool active = lane_ok && blk < nblk;
     const int blkc = min(blk, nblk - 1);
@@ -448,7 +446,14 @@ __global__ __launch_bounds__(256) void dw_strip_bwd_s2_kernel(StripArgs a) {
       for (int v = 0; v < 2; ++v)
 #pragma unroll
         for (int i = 0; i < CH; ++i) out[u][v][i] = 0.f;
-    if (frame_ok) {
+#pragma unroll
+    for (int dt = 0; dt < KT; ++dt) {
+      // temporal map of the forward conv: t_in = t_out*t_mul - t_off + dt  =>  t_out = (t_in + t_off - dt)/t_mul
+      // (KT > 1 is only dispatched with t_mul = 1)
+      const int tn = td + a.t_off - dt;
+      const bool frame_ok = tn >= 0 && (tn % a.t_mul) == 0 && (tn / a.t_mul) < a.Tsrc;
+      if (!frame_ok) continue;
+      const int ts = tn / a.t_mul;
       const T* fbase = dy + ((int64_t)n * a.Tsrc + ts) * a.Hs * a.Ws * a.C + c0;
       RawVec<T, CH> raw[NR][NR];
 #pragma unroll
@@ -484,7 +489,7 @@ __global__ __launch_bounds__(256) void dw_strip_bwd_s2_kernel(StripArgs a) {
               float wv[CH];
 #pragma unroll
               for (int q = 0; q < CH / 4; ++q) {
-                const f32x4 t = *reinterpret_cast<const f32x4*>(&wl[(kh * K + kw) * CW + cvl * CH + 4 * q]);
+                const f32x4 t = *reinterpret_cast<const f32x4*>(&wl[((dt * K + kh) * K + kw) * CW + cvl * CH + 4 * q]);
                 wv[4 * q] = t[0]; wv[4 * q + 1] = t[1]; wv[4 * q + 2] = t[2]; wv[4 * q + 3] = t[3];
               }
 #pragma unroll
@@ -716,6 +721,12 @@ int pick_cvb(int CV) {
   return 1;
 }
 
+// (kt,3,3), spatial stride 2, temporal stride 1, padding 1 in space: backward-data on the 2x2-block kernel with KT frames
+bool bwd_is_kt_s2(const pb_dwconv_shape& s) {
+  return (s.kt == 3 || s.kt == 5) && s.kh == 3 && s.kw == 3 && s.st == 1 && s.sh == 2 && s.sw == 2 && s.ph == 1 && s.pw == 1 &&
+         s.C % 4 == 0;
+}
+
 bool strip_ok(const pb_dwconv_shape& s) {
   return s.kt == 1 && s.kh == s.kw && (s.kh == 3 || s.kh == 5) && s.sh == s.sw && (s.sh == 1 || s.sh == 2) &&
          s.ph == s.pw && s.C % 4 == 0;
@@ -847,7 +858,7 @@ extern "C" const char* pb_dwconv3d_kernel_name(const pb_dwconv_shape* s, pb_dtyp
       if (pb_dw_rows_eligible(&c, false)) return "dw_rows_fwd_kernel";
       return pb_dw_tile_eligible(&c, dtype, false) ? "dw_tile_fwd_kernel" : "dw_strip_fwd_kernel";
     }
-    if (strip_ok(*s) && s->sh == 2 && s->ph == s->kh / 2) return "dw_strip_bwd_s2_kernel";
+    if ((strip_ok(*s) && s->sh == 2 && s->ph == s->kh / 2) || bwd_is_kt_s2(*s)) return "dw_strip_bwd_s2_kernel";
     return "dw_gen_bwd_data_kernel";
   }
   if (pb_dw7_eligible(s)) return "dw7_wgrad_kernel";
@@ -1003,7 +1014,7 @@ extern "C" int pb_dwconv3d_bwd_data(const void* dy, const float* w, void* dx, co
     a.g_scale = g_scale; a.g_shift = g_shift;
     int rc = dtype == PB_BF16 ? dispatch_strip<bf16_t, false>(a, s->kh, 1, st) : dispatch_strip<float, false>(a, s->kh, 1, st);
     if (rc) return rc;
-  } else if (strip_ok(*s) && s->sh == 2 && s->ph == s->kh / 2) {
+  } else if ((strip_ok(*s) && s->sh == 2 && s->ph == s->kh / 2) || bwd_is_kt_s2(*s)) {
     StripArgs a = {};
     a.src = dy; a.w = w; a.dst = dx; a.N = s->N; a.C = s->C;
     a.Tsrc = s->To; a.Hs = s->Ho; a.Ws = s->Wo; a.Tdst = s->Ti; a.Hd = s->Hi; a.Wd = s->Wi;
@@ -1020,7 +1031,15 @@ extern "C" int pb_dwconv3d_bwd_data(const void* dy, const float* w, void* dx, co
     int64_t gx = pb_cdiv(2048, chunks);
     if (gx > a.items) gx = a.items;
     dim3 grid((unsigned)gx, (unsigned)chunks);
-    if (bf) {
+    if (s->kt == 3) {
+      if (bf && ch == 8) hipLaunchKernelGGL((dw_strip_bwd_s2_kernel<bf16_t, 3, 8, 3>), grid, dim3(256), 0, st, a);
+      else if (bf) hipLaunchKernelGGL((dw_strip_bwd_s2_kernel<bf16_t, 3, 4, 3>), grid, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((dw_strip_bwd_s2_kernel<float, 3, 4, 3>), grid, dim3(256), 0, st, a);
+    } else if (s->kt == 5) {
+      if (bf && ch == 8) hipLaunchKernelGGL((dw_strip_bwd_s2_kernel<bf16_t, 3, 8, 5>), grid, dim3(256), 0, st, a);
+      else if (bf) hipLaunchKernelGGL((dw_strip_bwd_s2_kernel<bf16_t, 3, 4, 5>), grid, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((dw_strip_bwd_s2_kernel<float, 3, 4, 5>), grid, dim3(256), 0, st, a);
+    } else if (bf) {
       if (s->kh == 3 && ch == 8) hipLaunchKernelGGL((dw_strip_bwd_s2_kernel<bf16_t, 3, 8>), grid, dim3(256), 0, st, a);
       else if (s->kh == 3) hipLaunchKernelGGL((dw_strip_bwd_s2_kernel<bf16_t, 3, 4>), grid, dim3(256), 0, st, a);
       else hipLaunchKernelGGL((dw_strip_bwd_s2_kernel<bf16_t, 5, 4>), grid, dim3(256), 0, st, a);
