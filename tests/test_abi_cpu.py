@@ -50,3 +50,29 @@ def test_product_never_imports_the_oracle():
         if fn.endswith(".py"):
             txt = open(os.path.join(pkg, fn)).read()
             assert not re.search(r"^\s*(from|import)\s+oracle", txt, flags=re.M), fn
+
+
+def test_weight_gradient_branch_only_defers_when_autograd_adopts():
+    """kernels.weight_grad_branch runs a block's weight gradients on a second stream and joins later - safe only when nothing
+    reads the gradient tensor when the backward node returns.  The rule (no GPU needed): a leaf parameter without .grad and
+    without hooks (the GradReducer's own hook, marked join-aware, excepted); and CPU tensors always run in line."""
+    from picklebot_amd import kernels as K
+    p = torch.nn.Parameter(torch.zeros(4, 4))
+    assert K._adopting(p) and K._adopting(None)
+    p.grad = torch.zeros(4, 4)
+    assert not K._adopting(p)                     # autograd would ADD into it on the calling stream
+    p.grad = None
+    assert not K._adopting(p * 2)                 # non-leaf: the producing node consumes the gradient
+    h = p.register_hook(lambda g: g)
+    assert not K._adopting(p)
+    h.remove()
+    h = p.register_post_accumulate_grad_hook(lambda q: None)
+    assert not K._adopting(p)
+    p._pb_join_aware = True
+    assert K._adopting(p)
+    h.remove()
+    ran = []
+    K.branch_counts.update(side=0, inline=0)
+    K.weight_grad_branch(torch.zeros(1), (p,), [lambda: ran.append(1)], ())
+    assert ran == [1] and K.branch_counts == {"side": 0, "inline": 1}
+    K.join_weight_grads()                         # nothing in flight: a no-op
