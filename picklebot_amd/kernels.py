@@ -243,15 +243,17 @@ def weight_grad_branch(ref, params, thunks, keep, tag=""):
         return
     idx = ref.device.index if ref.device.index is not None else torch.cuda.current_device()
     main, side = torch.cuda.current_stream(idx), _side_stream(idx)
-    if idx not in _lag:
-        try:                              # joins when this backward pass ends, before backward() returns
-            torch.autograd.Variable._execution_engine.queue_callback(join_weight_grads)
-        except RuntimeError:              # not inside a backward pass of the engine: nobody would join
-            branch_counts["inline"] += 1
-            with deferred_reductions():
-                for t in thunks:
-                    t()
-            return
+    try:
+        # joins when this backward pass ends, before backward() returns.  Queued by EVERY branch (the later ones find nothing
+        # left to join): a pass that died half-way leaves a stale entry behind, and "first branch of the pass" cannot be told
+        # from it
+        torch.autograd.Variable._execution_engine.queue_callback(join_weight_grads)
+    except RuntimeError:                  # not inside a backward pass of the engine: nobody would join
+        branch_counts["inline"] += 1
+        with deferred_reductions():
+            for t in thunks:
+                t()
+        return
     prev = _lag.pop(idx, None)
     if prev is not None:
         main.wait_event(prev[0])          # the previous block's branch (normally long finished); its tensors may go now
