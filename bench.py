@@ -72,18 +72,31 @@ def main():
     ap.add_argument("--torch-adamw", action="store_true", help="torch.optim.AdamW(fused=True) instead of picklebot_amd.FlatAdamW")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # `python bench.py --gpus N` by itself: one process per GPU (train.py:24-36 reads torchrun's environment) - start the
+        # launcher as a CHILD process, relay its output (rank 0's one JSON line) and its exit code.  Nothing has touched the
+        # GPU in this process, and nothing is exec'ed.
+        import socket
+        import subprocess
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
     import picklebot_amd
     from picklebot_amd import kernels as K
-    from picklebot_amd.parallel import GradReducer, setup_distributed
+    from picklebot_amd.parallel import GradReducer, collectives_retired, setup_distributed
 
     if os.environ.get("PB_BENCH_FORCE_DP") and "RANK" not in os.environ:
         # exercise the data-parallel code path (process group, bucketed reducer, graph + eager all-reduce) on one GPU
         os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29517")
     dp_path = "RANK" in os.environ and ("PB_BENCH_FORCE_DP" in os.environ or int(os.environ.get("WORLD_SIZE", "1")) > 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    if world != args.gpus and not os.environ.get("PB_BENCH_FORCE_DP"):
+        raise SystemExit("--gpus %d but the launcher started %d ranks" % (args.gpus, world))
     local_rank, rank, _ = setup_distributed("nccl") if dp_path else (0, 0, 1)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
@@ -101,6 +114,10 @@ def main():
         opt = picklebot_amd.FlatAdamW(reducer if reducer is not None else model.parameters(), lr=3e-4, weight_decay=5e-4)
     else:
         opt = torch.optim.AdamW(model.parameters(), lr=3e-4, weight_decay=5e-4, fused=True, capturable=use_graph)
+        if not dp_path:
+            # this loop reads no gradient before backward() has returned: opt in to the weight-gradient side stream
+            # (FlatAdamW / GradReducer opt their parameters in themselves; the library's default is in line)
+            K.weight_grad_overlap().__enter__()
     x, y = synthetic_batch(args.batch, device, 1234 + rank)
 
     def opt_step_reduced():
@@ -132,16 +149,19 @@ def main():
     run_stream = torch.cuda.Stream(device)      # warm-up, capture, replay and the profiling pass all run on this ONE stream:
     torch.cuda.set_stream(run_stream)           # autograd's AccumulateGrad nodes are created under the stream they later run on
 
-    def capture(fn):
+    def capture(fn, has_collective=False):
         """Warm up, then capture fn() into a HIP graph on the same stream; returns (graph, fn's result)."""
         for _ in range(3):
             fn()
         torch.cuda.synchronize()
-        if dp_path:
-            # RCCL's watchdog thread still holds the warm-up steps' work objects until its next poll (every 100 ms) and
-            # queries their end events; on ROCm that query fails with hipErrorCapturedEvent once RCCL's stream has joined a
-            # capture - and the watchdog takes the process down.  Seen once in ~10 runs; let it retire them first.
-            time.sleep(0.5)
+        if dp_path and has_collective:
+            # RCCL's watchdog thread polls the end events of the eager warm-up collectives; on ROCm that query fails with
+            # hipErrorCapturedEvent once RCCL's stream has joined a capture and the watchdog takes the process down (round 3,
+            # 1 run in ~10).  Hand-off by ORDER (parallel.collectives_retired): the device is idle, so the watchdog's next poll
+            # retires every work it holds; capture starts only after the flight recorder shows it HAS.  Otherwise: no
+            # collective inside a graph (the caller falls back, all ranks together).
+            if collectives_retired() is not True:
+                raise RuntimeError("RCCL watchdog still holds eager work objects (or cannot be asked): not capturing a collective")
         g = torch.cuda.CUDAGraph()
         K.reset_zero_arena()              # the zero-filled scratch must be allocated AND filled inside the graph
         with torch.cuda.graph(g, stream=run_stream):
@@ -215,7 +235,7 @@ def main():
         if flat_opt and not os.environ.get("PB_BENCH_NO_OVERLAP_GRAPH"):
             ok, graph = True, None
             try:
-                graph, graph_loss = capture(overlapped_step)
+                graph, graph_loss = capture(overlapped_step, has_collective=True)
             except Exception as e:
                 ok = False
                 recover("capture with in-graph all-reduce", e)
@@ -269,6 +289,7 @@ def main():
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
     value = args.batch * world * args.steps / elapsed
+    side_branches = K.branch_counts["side"]       # > 0: the captured / submitted steps used the second stream
 
     # ---- per-kernel roofline: the same K steps again with HIP events around every launch --------
     roofline, families = None, {}
@@ -343,7 +364,7 @@ def main():
                        "step": "fwd + CE loss + bwd + RCCL grad all-reduce (n>1) + fused AdamW (%s)" % ("picklebot_amd.FlatAdamW" if flat_opt else "torch fused"),
                        "launch": launch_mode,
                        "streams": ("each block's weight gradients on a second HIP stream beside the next block's data-gradient chain, "
-                                   "joined when backward ends (kernels.weight_grad_branch)") if K._WGRAD_OVERLAP else "one",
+                                   "joined when backward ends (kernels.weight_grad_branch; opted in by FlatAdamW / GradReducer)") if side_branches else "one",
 
                        "weights": "random init (seed 1234)", "loss": round(float(loss.item()), 4)},
             "roofline": roofline,

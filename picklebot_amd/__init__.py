@@ -12,6 +12,7 @@ from .mobilevit import Attention, FeedForward, MobileViT, MobileViTBlock, Transf
 from .mobilevitv2 import LinearSelfAttention  # noqa: F401
 from .optim import FlatAdamW  # noqa: F401
 from .functional import fp8_attention  # noqa: F401
+from .kernels import weight_grad_overlap  # noqa: F401
 from .harness import (DevicePrefetcher, calculate_accuracy, calculate_accuracy_bce, custom_collate, estimate_loss,  # noqa: F401
                       extract_features_labels, strip_compile_prefix)
 

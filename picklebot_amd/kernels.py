@@ -201,14 +201,43 @@ def partials_reduce(jobs, device):
 #     `loss.backward()` returns; FlatAdamW / GradReducer join before they read a gradient (bucket packing inside hooks);
 #   * the caller returns FRESH VIEWS of the gradient buffers, not the tensor objects it lists in `keep`: autograd adopts a
 #     gradient only when nobody else holds the object, otherwise it clones it - on the calling stream, at once;
-#   * a block only defers when autograd will merely ADOPT its gradient tensors - `.grad is None` and no foreign hooks on
-#     the parameters (accumulation into an existing `.grad`, or a user hook, would read them on the calling stream
-#     straight away); otherwise the kernels run in line as before.
-# PB_WGRAD_OVERLAP=0 switches it off.  Works under HIP-graph capture (event fork / join inside the captured region).
+#   * a block only defers when autograd will merely ADOPT its gradient tensors - `.grad is None`, no Python hooks - AND
+#     the consumer of the gradients has OPTED IN (round 4).  Whoever reads `.grad` DURING backward must know about the
+#     branch, and the hooks that do so cannot all be seen from here: stock DistributedDataParallel (train.py:203-204) and
+#     anything else that hooks the AccumulateGrad NODE (`grad_acc.register_hook`) lives in C++ and leaves `p._backward_hooks`
+#     / `p._post_accumulate_grad_hooks` empty - DDP's `mark_variable_ready` would copy `.grad` into its bucket on the
+#     calling stream before the side stream has written it.  So the default is IN LINE, and deferral is switched on
+#       - per parameter, by a consumer that joins before it reads: `FlatAdamW` and `GradReducer` mark their parameters
+#         `_pb_join_aware` (their pack / hooks call `join_weight_grads()` first), or
+#       - for a region of code, by `with picklebot_amd.weight_grad_overlap():` - the caller's promise that nothing reads a
+#         gradient before `backward()` has returned (plain `loss.backward(); optimizer.step()` loops qualify; a model
+#         wrapped in stock DDP does NOT);
+#   * a parameter that reaches a second weight-gradient node in the same backward pass (a module called twice, tied
+#     weights): autograd's input buffer ADDS the two gradients on the calling stream when the second arrives, so the
+#     second block joins every branch in flight first and runs in line.
+# PB_WGRAD_OVERLAP=0 switches it off altogether.  Works under HIP-graph capture (event fork / join inside the captured
+# region).
 _WGRAD_OVERLAP = os.environ.get("PB_WGRAD_OVERLAP", "1") != "0"
 _side = {}
 _lag = {}        # device index -> (done event, tensors kept alive) of the branch not yet joined
+_seen = {}       # graph-task id -> ids of the parameters whose gradient a branch of this pass has deferred
 branch_counts = {"side": 0, "inline": 0}      # how the blocks' weight gradients were issued (tests read this)
+
+
+class weight_grad_overlap:
+    """`with picklebot_amd.weight_grad_overlap():` around a training loop (or just around `loss.backward()`): the caller
+    promises that nothing reads a parameter's `.grad` before `backward()` has returned - no stock DistributedDataParallel,
+    no hooks on AccumulateGrad nodes - so every block may run its weight gradients on the second stream.  `FlatAdamW` and
+    `GradReducer` opt their own parameters in and need no such region."""
+    _depth = 0
+
+    def __enter__(self):
+        weight_grad_overlap._depth += 1
+        return self
+
+    def __exit__(self, *exc):
+        weight_grad_overlap._depth -= 1
+        return False
 
 
 def _side_stream(idx):
@@ -218,42 +247,53 @@ def _side_stream(idx):
     return st
 
 
-def _adopting(p):
-    """autograd will adopt this parameter's gradient tensor as it is (no kernel reads it when the backward node returns)"""
+def _adopting(p, region):
+    """autograd will adopt this parameter's gradient tensor as it is AND whoever reads it later joins first"""
     if p is None:
         return True
     if not p.is_leaf or p.grad is not None or getattr(p, "_backward_hooks", None):
         return False          # (a non-leaf weight: the node that produced it consumes the gradient on the calling stream)
-    hooks = getattr(p, "_post_accumulate_grad_hooks", None)
-    return not hooks or getattr(p, "_pb_join_aware", False)
+    aware = getattr(p, "_pb_join_aware", False)
+    if getattr(p, "_post_accumulate_grad_hooks", None) and not aware:
+        return False
+    return aware or region
 
 
 _WGRAD_TAGS = set(filter(None, os.environ.get("PB_WGRAD_TAGS", "").split(",")))     # debugging: only these block kinds defer
 
 
+def _run_inline(thunks):
+    branch_counts["inline"] += 1
+    with deferred_reductions():
+        for t in thunks:
+            t()
+
+
 def weight_grad_branch(ref, params, thunks, keep, tag=""):
     """Run `thunks` (the weight-gradient launches of one block; their partial-tile reductions are issued as one launch at
     the end) - on the side stream without joining when that is safe (see above), in line otherwise."""
-    defer = _WGRAD_OVERLAP and ref.is_cuda and all(_adopting(p) for p in params) and (not _WGRAD_TAGS or tag in _WGRAD_TAGS)
+    region = weight_grad_overlap._depth > 0          # (process-wide: backward runs on autograd's device thread)
+    defer = _WGRAD_OVERLAP and ref.is_cuda and all(_adopting(p, region) for p in params) and (not _WGRAD_TAGS or tag in _WGRAD_TAGS)
     if not defer:
-        branch_counts["inline"] += 1
-        with deferred_reductions():
-            for t in thunks:
-                t()
-        return
+        return _run_inline(thunks)
+    task = torch._C._current_graph_task_id()
+    seen = _seen.setdefault(task, set())
+    ids = [id(p) for p in params if p is not None]
+    if any(i in seen for i in ids):
+        # second gradient for a parameter in this pass: autograd's input buffer is about to ADD it to the first one on the
+        # calling stream - order that stream behind the branch that is still writing the first
+        join_weight_grads()
+        return _run_inline(thunks)
     idx = ref.device.index if ref.device.index is not None else torch.cuda.current_device()
     main, side = torch.cuda.current_stream(idx), _side_stream(idx)
     try:
         # joins when this backward pass ends, before backward() returns.  Queued by EVERY branch (the later ones find nothing
         # left to join): a pass that died half-way leaves a stale entry behind, and "first branch of the pass" cannot be told
         # from it
-        torch.autograd.Variable._execution_engine.queue_callback(join_weight_grads)
+        torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward)
     except RuntimeError:                  # not inside a backward pass of the engine: nobody would join
-        branch_counts["inline"] += 1
-        with deferred_reductions():
-            for t in thunks:
-                t()
-        return
+        return _run_inline(thunks)
+    seen.update(ids)
     prev = _lag.pop(idx, None)
     if prev is not None:
         main.wait_event(prev[0])          # the previous block's branch (normally long finished); its tensors may go now
@@ -275,6 +315,11 @@ def join_weight_grads():
     for idx in list(_lag):
         done, _ = _lag.pop(idx)
         torch.cuda.current_stream(idx).wait_event(done)
+
+
+def _end_of_backward():
+    join_weight_grads()
+    _seen.clear()
 
 
 # A block's backward computes several weight gradients; each leaves per-workgroup partial tiles in a workspace.

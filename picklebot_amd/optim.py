@@ -11,6 +11,11 @@ rule.  State (exp_avg, exp_avg_sq) is fp32.
     loss.backward()
     opt.step()                      # gathers the gradients into the flat bucket (one multi-tensor copy) and updates
 
+`overlap_weight_grads` (default: on, except in a process group without a `GradReducer`): `pack_grads()` joins the
+weight-gradient side stream before it reads a gradient, so the blocks of these parameters may run their weight gradients
+there (`kernels.weight_grad_branch`).  Pass False when anything else reads `.grad` while backward is still running -
+stock DistributedDataParallel does (train.py:203-204).
+
 Construct it after the model is on its device (parameters are re-pointed into the flat buffer; `state_dict` keys and values are
 unchanged).  With a `GradReducer` the reducer's buckets are adopted (its flat gradient buffers are what the all-reduce fills).
 Everything is stream-ordered and allocation-free after construction, so a whole step can be captured into a HIP graph:
@@ -25,9 +30,13 @@ from .parallel import bucket_layout
 
 
 class FlatAdamW(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, overlap_weight_grads=None):
         reducer = params if hasattr(params, "buckets") and hasattr(params, "flat") else None
         self._reducer = reducer
+        if overlap_weight_grads is None:
+            # a process group without a GradReducer: the gradients are most likely exchanged by stock DistributedDataParallel,
+            # whose C++ hooks read `.grad` DURING backward on the calling stream - keep every weight gradient in line then
+            overlap_weight_grads = reducer is not None or not (torch.distributed.is_available() and torch.distributed.is_initialized())
         if reducer is not None:
             buckets, gflat, gviews = reducer.buckets, reducer.flat, reducer.views
         else:
@@ -51,6 +60,10 @@ class FlatAdamW(torch.optim.Optimizer):
                 n = p.numel()
                 flat[off:off + n].copy_(p.data.reshape(-1))
                 p.data = flat[off:off + n].view_as(p)        # the parameter now lives in the bucket
+                # this optimiser joins the weight-gradient side stream before it reads a gradient (pack_grads), so its
+                # parameters' blocks may defer their weight gradients (kernels.weight_grad_branch: opt-in per consumer)
+                if reducer is None:                           # (a GradReducer has marked its parameters itself)
+                    p._pb_join_aware = bool(overlap_weight_grads)
             self.pflat.append(flat)
             self.exp_avg.append(torch.zeros_like(flat))
             self.exp_avg_sq.append(torch.zeros_like(flat))

@@ -213,6 +213,9 @@ def setup_distributed(backend=None):
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # the process group's flight recorder (read when the group is created): collectives_retired() asks it whether RCCL's
+    # watchdog thread still holds work objects
+    os.environ.setdefault("TORCH_NCCL_TRACE_BUFFER_SIZE", "4096")
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"     # "nccl" is RCCL on ROCm
     if backend == "nccl":
@@ -225,3 +228,41 @@ def setup_distributed(backend=None):
         else:
             dist.init_process_group(backend)
     return local_rank, rank, world
+
+
+def collectives_retired(timeout_s=20.0, poll_s=0.02):
+    """Wait until the process group's watchdog thread has RETIRED every collective it was given; -> True / False (timeout) /
+    None (cannot tell: flight recorder off or not a RCCL group).
+
+    Why: ProcessGroupNCCL's watchdog polls the end events of the work objects on its list (every 100 ms) and drops a work
+    once its event has completed.  On ROCm `hipEventQuery` fails with hipErrorCapturedEvent while RCCL's stream is part of a
+    HIP-graph capture, the watchdog rethrows, and the process dies in C++ `terminate` (seen in round 3:
+    WorkNCCL::isCompleted -> finishedGPUExecutionInternal, gpurun_out/ws/dp.err).  Work issued DURING a capture is never put on
+    that list, so the only works that can be polled during a capture are eager ones from before it.  The hand-off is
+    therefore an ORDER, not a delay: (1) the caller synchronises the device - every eager collective has finished, so the
+    watchdog's next poll retires it; (2) this function returns True only after the flight recorder shows no active entry,
+    i.e. after the watchdog HAS retired them (`retire_id` runs in the same loop iteration that erases the work from the
+    list); (3) only then may a capture that includes a collective begin.  A caller that gets False / None must not capture
+    collectives (bench.py then takes the no-collective-in-graph fallback, on all ranks together)."""
+    import pickle
+    import time
+    try:
+        from torch._C._distributed_c10d import _dump_nccl_trace
+    except ImportError:
+        return None
+    if int(__import__("os").environ.get("TORCH_NCCL_TRACE_BUFFER_SIZE", "0") or 0) <= 0:
+        return None
+    t_end = time.monotonic() + timeout_s
+    while True:
+        try:
+            dump = pickle.loads(_dump_nccl_trace(includeCollectives=True, includeStackTraces=False, onlyActive=True))
+        except Exception:
+            return None
+        entries = dump.get("entries", []) if isinstance(dump, dict) else None
+        if entries is None:
+            return None
+        if not entries:
+            return True
+        if time.monotonic() > t_end:
+            return False
+        time.sleep(poll_s)

@@ -52,27 +52,56 @@ def test_product_never_imports_the_oracle():
             assert not re.search(r"^\s*(from|import)\s+oracle", txt, flags=re.M), fn
 
 
-def test_weight_gradient_branch_only_defers_when_autograd_adopts():
+def test_weight_gradient_branch_only_defers_when_the_consumer_opted_in():
     """kernels.weight_grad_branch runs a block's weight gradients on a second stream and joins later - safe only when nothing
-    reads the gradient tensor when the backward node returns.  The rule (no GPU needed): a leaf parameter without .grad and
-    without hooks (the GradReducer's own hook, marked join-aware, excepted); and CPU tensors always run in line."""
+    reads the gradient tensor before the join.  The rule (no GPU needed): the DEFAULT is in line; a leaf parameter without
+    .grad and without hooks defers only when its consumer opted in - per parameter (`_pb_join_aware`: FlatAdamW, GradReducer)
+    or for a region (`weight_grad_overlap()`); CPU tensors always run in line."""
     from picklebot_amd import kernels as K
+    import picklebot_amd
     p = torch.nn.Parameter(torch.zeros(4, 4))
-    assert K._adopting(p) and K._adopting(None)
+    assert not K._adopting(p, False)              # nobody opted in: a C++ hook on the AccumulateGrad node could be reading
+    assert K._adopting(p, True) and K._adopting(None, False)
     p.grad = torch.zeros(4, 4)
-    assert not K._adopting(p)                     # autograd would ADD into it on the calling stream
+    assert not K._adopting(p, True)               # autograd would ADD into it on the calling stream
     p.grad = None
-    assert not K._adopting(p * 2)                 # non-leaf: the producing node consumes the gradient
+    assert not K._adopting(p * 2, True)           # non-leaf: the producing node consumes the gradient
     h = p.register_hook(lambda g: g)
-    assert not K._adopting(p)
+    assert not K._adopting(p, True)
     h.remove()
     h = p.register_post_accumulate_grad_hook(lambda q: None)
-    assert not K._adopting(p)
+    assert not K._adopting(p, True)               # a foreign hook reads .grad during backward, region or not
     p._pb_join_aware = True
-    assert K._adopting(p)
+    assert K._adopting(p, False)
     h.remove()
+    assert K.weight_grad_overlap._depth == 0
+    with picklebot_amd.weight_grad_overlap():
+        assert K.weight_grad_overlap._depth == 1
+    assert K.weight_grad_overlap._depth == 0
     ran = []
     K.branch_counts.update(side=0, inline=0)
     K.weight_grad_branch(torch.zeros(1), (p,), [lambda: ran.append(1)], ())
     assert ran == [1] and K.branch_counts == {"side": 0, "inline": 1}
     K.join_weight_grads()                         # nothing in flight: a no-op
+
+
+def test_stock_ddp_parameters_are_not_opted_in(tmp_path):
+    """DistributedDataParallel (train.py:203-204) hooks the AccumulateGrad node in C++; nothing on the
+    parameter shows it.  So a DDP-wrapped model must find every parameter NOT opted in (weight gradients in line), and a
+    FlatAdamW built in a process group without a GradReducer must not opt them in either."""
+    import torch.distributed as dist
+    from picklebot_amd import kernels as K
+    import picklebot_amd
+    dist.init_process_group("gloo", init_method=f"file://{tmp_path}/pg", rank=0, world_size=1)
+    try:
+        m = torch.nn.Linear(16, 16)
+        ddp = torch.nn.parallel.DistributedDataParallel(m)
+        assert all(not K._adopting(p, False) for p in ddp.parameters())
+        opt = picklebot_amd.FlatAdamW(m.parameters(), lr=1e-3)
+        assert all(not getattr(p, "_pb_join_aware", False) for p in m.parameters())
+        assert all(not K._adopting(p, False) for p in m.parameters())
+        del opt, ddp
+    finally:
+        dist.destroy_process_group()
+    opt = picklebot_amd.FlatAdamW(torch.nn.Linear(16, 16).parameters(), lr=1e-3)      # no process group: opted in
+    assert all(p._pb_join_aware for p in opt.param_groups[0]["params"])

@@ -8,6 +8,7 @@ larger (conftest.check_model_result) - the reference's bf16-autocast gradients a
 reference meets against itself.  Also: size-independent properties at larger batch."""
 import contextlib
 import io
+import os
 
 import numpy as np
 import pytest
@@ -644,7 +645,11 @@ def test_movinet_a2_depthwise_streaming_at_scale(E, kernel, stride, hw, dtype):
                 assert rel_err(stream.float().cpu().numpy(), full.float().cpu().numpy()) <= 1e-6, f"chunk {chunk}"
 
 
-def _large3d_train_grads(steps=1, hook=False):
+def _large3d_train_grads(steps=1, hook=False, region=True, wrap=None, set_to_none=False, node_hook=None):
+    """Train-mode gradients of a small MobileNetLarge3D clip.  region: run inside `weight_grad_overlap()` (the caller's
+    promise that nothing reads .grad during backward); wrap: e.g. stock DistributedDataParallel; set_to_none: zero_grad
+    between the steps like train.py:289; node_hook(model): registers hooks before the first step."""
+    from picklebot_amd import kernels as K
     torch.manual_seed(3)
     model = picklebot_amd.MobileNetLarge3D(num_classes=13).to(DEV).train()
     for m in model.modules():
@@ -652,12 +657,18 @@ def _large3d_train_grads(steps=1, hook=False):
             m.p = 0.0
     if hook:
         model.block3[0].pointwise_conv1.weight.register_post_accumulate_grad_hook(lambda p: None)
+    if node_hook is not None:
+        node_hook(model)
+    net = wrap(model) if wrap is not None else model
     x = torch.randn(4, 3, 8, 64, 64, device=DEV)
     y = torch.arange(4, device=DEV) % 13
-    for _ in range(steps):
-        with torch.autocast("cuda", dtype=torch.bfloat16):
-            loss = torch.nn.functional.cross_entropy(model(x).float(), y)
-        loss.backward()
+    with (K.weight_grad_overlap() if region else contextlib.nullcontext()):
+        for i in range(steps):
+            if set_to_none and i:
+                net.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                loss = torch.nn.functional.cross_entropy(net(x).float(), y)
+            loss.backward()
     torch.cuda.synchronize()
     return {k: p.grad.clone() for k, p in model.named_parameters()}
 
@@ -671,6 +682,10 @@ def test_weight_gradient_side_branch_is_bit_identical(monkeypatch):
     monkeypatch.setattr(K, "_WGRAD_OVERLAP", False)
     ref = _large3d_train_grads()
     monkeypatch.setattr(K, "_WGRAD_OVERLAP", True)
+    K.branch_counts.update(side=0, inline=0)
+    plain = _large3d_train_grads(region=False)       # nobody opted in: every block in line (the DEFAULT, round 4)
+    assert K.branch_counts["side"] == 0 and K.branch_counts["inline"] >= 15, K.branch_counts
+    assert all(torch.equal(ref[k], plain[k]) for k in ref)
     K.branch_counts.update(side=0, inline=0)
     got = _large3d_train_grads()
     nb = K.branch_counts["side"]          # 15 bottlenecks + the 1x1x1 conv / classifier layers around them
@@ -705,10 +720,76 @@ def test_weight_gradient_side_branch_on_whole_models(case, monkeypatch):
     for on in (False, True):
         monkeypatch.setattr(K, "_WGRAD_OVERLAP", on)
         K.branch_counts.update(side=0, inline=0)
-        with contextlib.redirect_stdout(io.StringIO()):
+        with contextlib.redirect_stdout(io.StringIO()), K.weight_grad_overlap():
             res[on] = protocol.collect_model_case(picklebot_amd, case, device=DEV, do_eval=False)
         assert not K._lag
         if on:
             assert K.branch_counts["side"] > 0 and K.branch_counts["inline"] == 0, K.branch_counts
     keys = [k for k in res[False] if k.startswith("grad/")]
     assert keys and all(torch.equal(res[False][k], res[True][k]) for k in keys), [k for k in keys if not torch.equal(res[False][k], res[True][k])][:5]
+
+
+def test_stock_ddp_gradients_equal_the_unwrapped_models(tmp_path):
+    """VERDICT r3 #1 / train.py:203-204, 269, 289: the reference wraps the model in stock DistributedDataParallel and calls
+    zero_grad(set_to_none=True).  DDP's C++ hook on each AccumulateGrad node copies `.grad` into its bucket on the calling
+    stream DURING backward; with a weight gradient still in flight on the side stream the bucket would get zeros or partial
+    sums.  World-size-1 RCCL group, two steps: the gradients DDP leaves behind (bucket views, all-reduced) are torch.equal
+    to the un-wrapped model's, and every block ran in line."""
+    import torch.distributed as dist
+    from picklebot_amd import kernels as K
+    ref = _large3d_train_grads(steps=2, region=False, set_to_none=True)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method=f"file://{tmp_path}/pg", rank=0, world_size=1,
+                            device_id=torch.device("cuda", torch.cuda.current_device()))
+    try:
+        K.branch_counts.update(side=0, inline=0)
+        ddp = lambda m: torch.nn.parallel.DistributedDataParallel(m, device_ids=[torch.cuda.current_device()])   # noqa: E731
+        got = _large3d_train_grads(steps=2, region=False, set_to_none=True, wrap=ddp)
+        assert K.branch_counts["side"] == 0 and K.branch_counts["inline"] >= 30, K.branch_counts
+        bad = [k for k in ref if not torch.equal(ref[k], got[k])]
+        assert not bad, bad[:5]
+    finally:
+        dist.destroy_process_group()
+
+
+def test_accumulate_grad_node_hook_sees_the_final_gradient():
+    """A hook on a parameter's AccumulateGrad NODE (what DDP registers from C++) is invisible on the parameter
+    (`_backward_hooks`, `_post_accumulate_grad_hooks` stay empty) and fires during backward, right after `.grad` is set:
+    what it reads on the calling stream must be the finished gradient."""
+    seen, nodes = {}, []
+
+    def node_hook(model):
+        for name, p in model.named_parameters():
+            if name.endswith(("pointwise_conv1.weight", "depthwise_conv.weight", "pointwise_conv2.weight", "se.1.weight")):
+                node = p.view_as(p).grad_fn.next_functions[0][0]
+                nodes.append(node)           # (the node must stay alive: parameters hold it weakly)
+                node.register_hook(lambda gi, go, name=name, p=p: seen.__setitem__(name, p.grad.clone()))
+
+    got = _large3d_train_grads(region=False, node_hook=node_hook)
+    assert len(seen) >= 45
+    bad = [k for k in seen if not torch.equal(seen[k], got[k])]
+    assert not bad, bad[:5]
+    assert all(float(seen[k].abs().sum()) > 0 for k in seen)
+
+
+def test_parameter_with_two_weight_gradient_nodes_in_one_pass():
+    """a module called twice (or tied weights) gets two gradients for one parameter in the same pass; autograd's
+    input buffer adds them on the calling stream when the second arrives.  With the side stream opted in the second block
+    must join the branch that still writes the first and run in line: same bits as the in-line schedule."""
+    from picklebot_amd import kernels as K
+
+    def run(region):
+        torch.manual_seed(11)
+        blk = picklebot_amd.Bottleneck3D(16, 16, 48, stride=1, use_se=True, kernel_size=3).to(DEV).train()
+        x = torch.randn(2, 16, 4, 12, 12, device=DEV).to(memory_format=torch.channels_last_3d).requires_grad_()
+        with (K.weight_grad_overlap() if region else contextlib.nullcontext()):
+            blk(blk(x)).square().mean().backward()
+        torch.cuda.synchronize()
+        return {k: p.grad.clone() for k, p in blk.named_parameters()}, x.grad.clone()
+
+    ref, dx_ref = run(False)
+    K.branch_counts.update(side=0, inline=0)
+    got, dx = run(True)
+    assert K.branch_counts == {"side": 1, "inline": 1}, K.branch_counts
+    assert not K._lag and not K._seen
+    assert torch.equal(dx_ref, dx) and all(torch.equal(ref[k], got[k]) for k in ref)
