@@ -61,6 +61,11 @@ def cpu_baseline(seconds_budget=20.0):
                       f"torch {torch.__version__} CPU, os.cpu_count()={os.cpu_count()}"}
 
 
+def log(*a):
+    if os.environ.get("PB_BENCH_VERBOSE"):
+        print("[bench %s]" % os.environ.get("RANK", "-"), *a, file=sys.stderr, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -231,6 +236,7 @@ def main():
 
         step()                                            # creates the RCCL communicator outside any capture
         sync()
+        log("first eager data-parallel step done")
         captured = False
         if flat_opt and not os.environ.get("PB_BENCH_NO_OVERLAP_GRAPH"):
             ok, graph = True, None
@@ -274,9 +280,11 @@ def main():
                 reducer.attach_grads()
                 reducer.zero_grad()
                 step = eager_step
+    log("launch mode:", launch_mode)
     for _ in range(args.warmup):
         step()
     sync()
+    log("warm-up done")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -352,6 +360,7 @@ def main():
                     "measured_over": f"{args.steps} steps re-run in line (weight-gradient side stream off) with HIP events around every launch"}
     if dp_path:
         dist.barrier()
+    log("profiling pass done")
 
     if rank == 0:
         out = {
@@ -376,8 +385,15 @@ def main():
         line = json.dumps(out)
     else:
         line = None
+    log("result ready")
+    if line is not None:
+        sys.stdout.flush()
+        print(line, flush=True)           # the ONE JSON line - BEFORE the process group is torn down (a teardown that
+        line = None                       # misbehaves must not cost the measurement)
     if dp_path:
+        os.dup2(2, 1)                     # whatever RCCL prints while it shuts down goes to stderr: the JSON line stays last on stdout
         dist.destroy_process_group()
+    log("process group destroyed")
     if line is not None:
         sys.stdout.flush()
         print(line, flush=True)           # the ONE JSON line, after anything RCCL may have written

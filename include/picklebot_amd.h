@@ -34,7 +34,7 @@ typedef enum {
   PB_ACT_HSIGMOID = 4, PB_ACT_SILU = 5
 } pb_act;
 
-#define PB_ABI_VERSION 15
+#define PB_ABI_VERSION 16
 
 /* Determinism.  Nothing in this library accumulates with floating-point atomics: two runs of the same binary on the
  * same inputs give bit-identical outputs and gradients.  Every reduction that spans workgroups stores one partial
@@ -204,28 +204,6 @@ int64_t pb_dwconv3d_bwd_weight_ws_bytes(const pb_dwconv_shape* s, pb_dtype dtype
 int pb_dwconv3d_bwd_weight(const void* dy, const void* x, float* dw, const pb_dwconv_shape* s, pb_dtype dtype,
                            const float* g_scale, const float* g_shift, void* ws, int64_t ws_bytes,
                            pb_reduce_job* deferred, int device, void* stream);
-
-/* ---------------------------------------------------------------- fused expansion conv -> depthwise conv
- * Bottleneck3D.forward runs pointwise_conv1 and depthwise_conv back to back with nothing in between (mobilenet.py:84-87;
- * also the Bottleneck3D blocks of mobilevit.py:168-185).  These entry points compute d = dw(pw1(x)) and the depthwise
- * weight gradient WITHOUT the expanded tensor e = pw1(x) in HBM: e tiles (bf16, rounded as pb_pwconv_fwd_bf16w stores them)
- * live in LDS only.  bf16 activations, kernel (1,k,k) with k in {3,5}, stride s in {1,2} on T, H and W, padding k/2,
- * Cin % 8 == 0, Cin <= 160, C (= expanded channels) % 8 == 0.  `s` describes the depthwise conv (s->C = E expanded
- * channels, input dims = x's).  w1_bf16: bf16 copy [E][Cin] of pointwise_conv1.weight (pb_pw_weight_prep[_batch]).
- * pb_xdw_supported: 1 when the shape is taken (else use pb_pwconv_fwd_bf16w + pb_dwconv3d_*).
- * pool_part: as pb_dwconv3d_fwd, with pb_xdw_pool_slots(s, Cin) slots.
- * Backward weight: dwdw[E][k*k] += sum g * pw1(x) with g = dy * g_scale[n,c] + g_shift[n,c]; e is recomputed from x. */
-int pb_xdw_supported(const pb_dwconv_shape* s, int Cin);
-int pb_xdw_pool_slots(const pb_dwconv_shape* s, int Cin);
-/* diagnostics: the tile plan {tile rows, tile cols, channels per chunk, chunks per workgroup, workgroups along E, LDS bytes,
- * grid x, segments, bands, rows per band, halo pixels, k-steps}; returns 0 when the shape is not taken */
-int pb_xdw_plan(const pb_dwconv_shape* s, int Cin, int wgrad, int* out12);
-int pb_xdw_fwd(const void* x, const void* w1_bf16, const float* wdw, void* d, const pb_dwconv_shape* s, int Cin,
-               float* pool_part, int pool_slots, int device, void* stream);
-int64_t pb_xdw_bwd_weight_ws_bytes(const pb_dwconv_shape* s, int Cin);
-int pb_xdw_bwd_weight(const void* x, const void* w1_bf16, const void* dy, float* dwdw, const pb_dwconv_shape* s, int Cin,
-                      const float* g_scale, const float* g_shift, void* ws, int64_t ws_bytes, pb_reduce_job* deferred,
-                      int device, void* stream);
 
 /* ---------------------------------------------------------------- frame gather / scatter (temporally strided bottlenecks)
  * Bottleneck3D's depthwise conv has a (1,k,k) kernel and strides T as well (mobilenet.py:67-75): with stride 2 only every

@@ -148,34 +148,6 @@ def dw_fwd_hist(x, hist, w, kernel, stride, pad_front, pad_back=None):
                   pad_front if pad_back is None else pad_back)
 
 
-# ---- fused expansion conv -> depthwise conv (kernels.xdw_*): the composition of the two mirrors, with the expanded tensor
-# rounded to the activation dtype in between (what the LDS tile holds).  FORCE_XDW (test-only) makes the CPU dataflow tests
-# take the fused branch of functional._Bottleneck.
-FORCE_XDW = False
-
-
-def xdw_enabled():
-    return bool(FORCE_XDW)
-
-
-def xdw_supported(x, E, kernel, stride, pad):
-    return bool(FORCE_XDW) and kernel[0] == 1 and kernel[1] == kernel[2] and kernel[1] in (3, 5)
-
-
-def xdw_fwd(x, w1, wdw, kernel, stride, pad, pool=False):
-    N, T, H, W, Cin = x.shape
-    e5 = pw_fwd(x.reshape(-1, Cin), w1).view(N, T, H, W, w1.shape[0])
-    if pool:
-        return dw_fwd_pool(e5, wdw, kernel, stride, pad)
-    return dw_fwd(e5, wdw, kernel, stride, pad), None
-
-
-def xdw_bwd_weight(dy, x, w1, dwdw, kernel, stride, pad, g_scale=None, g_shift=None):
-    N, T, H, W, Cin = x.shape
-    e5 = pw_fwd(x.reshape(-1, Cin), w1).view(N, T, H, W, w1.shape[0])
-    return dw_bwd_weight(dy, e5, dwdw, kernel, stride, pad, g_scale, g_shift)
-
-
 def act_row(shift, act, slope, dtype):
     return affine_act_fwd(shift.view(1, -1), act=act, slope=slope).to(dtype).view(-1)
 

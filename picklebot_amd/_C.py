@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libpicklebot_amd.so")
 
 PB_F32, PB_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY_RELU, ACT_HSWISH, ACT_HSIGMOID, ACT_SILU = range(6)
-ABI_VERSION = 15
+ABI_VERSION = 16
 STAT_SLOTS = 512
 
 
@@ -48,8 +48,6 @@ SIGNATURES = {
     "pb_dwconv3d_bwd_data": [P, P, P, POINTER(DwShape), I, P, P, I, P],
     "pb_dwconv3d_fwd_hist": [P, P, I, P, P, POINTER(DwShape), I, I, P],
     "pb_dwconv3d_bwd_weight": [P, P, P, POINTER(DwShape), I, P, P, P, L, POINTER(ReduceJob), I, P],
-    "pb_xdw_fwd": [P, P, P, P, POINTER(DwShape), I, P, I, I, P],
-    "pb_xdw_bwd_weight": [P, P, P, P, POINTER(DwShape), I, P, P, P, L, POINTER(ReduceJob), I, P],
     "pb_frames_gather": [P, P, I, I, I, L, I, I, I, P, I, I, P],
     "pb_stem_conv3d_fwd": [P, I, F, P, P, P, POINTER(StemShape), I, P, I, I, P],
     "pb_stem_conv3d_bwd_weight": [P, P, I, F, P, P, POINTER(StemShape), I, P, L, I, P],
@@ -101,16 +99,12 @@ SIZE_SIGNATURES = {
     "pb_dwconv3d_bwd_weight_ws_bytes": [POINTER(DwShape), I],
     "pb_stem_conv3d_bwd_weight_ws_bytes": [POINTER(StemShape), I, F, I],
     "pb_rowgroup_reduce_ws_bytes": [L, L, I, I],
-    "pb_xdw_bwd_weight_ws_bytes": [POINTER(DwShape), I],
 }
 
 # entry points returning a plain int count
 COUNT_SIGNATURES = {
     "pb_dwconv3d_pool_slots": [POINTER(DwShape), I],
     "pb_rowgroup_slots": [L, L, I, I],
-    "pb_xdw_supported": [POINTER(DwShape), I],
-    "pb_xdw_pool_slots": [POINTER(DwShape), I],
-    "pb_xdw_plan": [POINTER(DwShape), I, I, POINTER(c_int)],
     "pb_pwconv_fwd_bf16w_path": [L, I, I, I, L, I],
 }
 

@@ -204,8 +204,7 @@ class _Bottleneck(torch.autograd.Function):
         To = Tu = None
         compact = None                                # (t0, tstep, Tu, lead): input frames t0 + j * tstep <-> output frame lead + j
         xs5, dkernel, dstride, dpad = x5, kernel, stride, pad
-        fused = bool(getattr(K, "xdw_supported", None) and K.xdw_enabled() and K.xdw_supported(x5, E, kernel, stride, pad))
-        if kernel[0] == 1 and not fused and hasattr(K, "frames_gather"):
+        if kernel[0] == 1 and hasattr(K, "frames_gather"):
             To_full = (T + 2 * pad[0] - 1) // stride[0] + 1
             used = [to for to in range(To_full) if 0 <= to * stride[0] - pad[0] < T]
             if used and (len(used) < To_full or stride[0] > 1):
@@ -218,19 +217,14 @@ class _Bottleneck(torch.autograd.Function):
                 dpad = (0,) + tuple(pad[1:])
         Ts = xs5.shape[1]
         x2 = xs5.view(-1, Cin)
-        # expansion conv -> depthwise conv in ONE kernel (opt-in, bf16, (1,k,k)): the expanded tensor e never reaches HBM
-        e5 = None
-        if fused:
-            d5, pool_part = K.xdw_fwd(x5, w1.view(E, Cin), wdw.view(E, -1), kernel, stride, pad, pool=has_se)
+        e2 = K.pw_fwd(x2, w1.view(E, Cin))
+        e5 = e2.view(N, Ts, H, W, E)
+        if has_se:
+            # squeeze partial sums ride on the depthwise kernel; ONE launch turns them into pool / hidden / scale and the
+            # per-clip scaled bf16 projection weights (the squeeze-excite scale is folded into the GEMM's weights)
+            d5, pool_part = K.dw_fwd_pool(e5, wdw.view(E, -1), dkernel, dstride, dpad)
         else:
-            e2 = K.pw_fwd(x2, w1.view(E, Cin))
-            e5 = e2.view(N, Ts, H, W, E)
-            if has_se:
-                # squeeze partial sums ride on the depthwise kernel; ONE launch turns them into pool / hidden / scale and the
-                # per-clip scaled bf16 projection weights (the squeeze-excite scale is folded into the GEMM's weights)
-                d5, pool_part = K.dw_fwd_pool(e5, wdw.view(E, -1), dkernel, dstride, dpad)
-            else:
-                d5 = K.dw_fwd(e5, wdw.view(E, -1), dkernel, dstride, dpad)
+            d5 = K.dw_fwd(e5, wdw.view(E, -1), dkernel, dstride, dpad)
         Td, Ho, Wo = d5.shape[1:4]                    # Td = frames of d (compact: the data frames only)
         if To is None:
             To = Td
@@ -276,7 +270,7 @@ class _Bottleneck(torch.autograd.Function):
                               mean=bnc.mean if bnc is not None else None, **fmkw)
         if need_grad:
             ctx.cfg, ctx.bnc, ctx.dims = cfg, bnc, (N, T, H, W, Cin, E, Cout, To, Ho, Wo)
-            ctx.fused, ctx.compact, ctx.dconv, ctx.fmap = fused, compact, (dkernel, dstride, dpad), fmap
+            ctx.compact, ctx.dconv, ctx.fmap = compact, (dkernel, dstride, dpad), fmap
             ctx.save_for_backward(xs5, e5, d5, z2, w1, wdw, w2, se_w1, se_w2, pool, se_scale, hidden, gamma, drop)
         return y2.view(N, To, Ho, Wo, Cout)
 
@@ -316,10 +310,7 @@ class _Bottleneck(torch.autograd.Function):
             dse_w1, dse_w2 = dse_w1.view_as(se_w1), dse_w2.view_as(se_w2)
         dS5 = dS2.view(N, Td, Ho, Wo, E)
         dkernel, dstride, dpad = ctx.dconv       # (x5 here = the gathered frames when the block skips input frames)
-        if ctx.fused:
-            wgrads.append(lambda: K.xdw_bwd_weight(dS5, x5, w1.view(E, Cin), dwdw, kernel, stride, pad, g_scale, g_shift))
-        else:
-            wgrads.append(lambda: K.dw_bwd_weight(dS5, e5, dwdw, dkernel, dstride, dpad, g_scale, g_shift))
+        wgrads.append(lambda: K.dw_bwd_weight(dS5, e5, dwdw, dkernel, dstride, dpad, g_scale, g_shift))
         dE5 = K.dw_bwd_data(dS5, wdw.view(E, -1), (Ts, H, W), dkernel, dstride, dpad, g_scale, g_shift)
         dE2 = dE5.view(-1, E)
         wgrads.append(lambda: K.pw_bwd_weight(dE2, x5.view(-1, Cin), dw1))

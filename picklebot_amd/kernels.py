@@ -779,84 +779,6 @@ def dw_bwd_weight(dy, x, dw, kernel, stride, pad_front, g_scale=None, g_shift=No
     return dw
 
 
-# ------------------------------------------------------------------------------ fused expansion conv -> depthwise conv
-# opt-in: measured on MI355X (profiles/r03_xdw_*.txt) the fused kernel moves 2.5x fewer bytes but is latency/issue-bound and
-# does not yet beat the unfused pair on any MobileNetLarge3D layer; PB_XDW=1 enables it (tests always exercise it)
-_XDW = os.environ.get("PB_XDW", "0") != "0"
-_xdw_memo = {}
-
-
-def _xdw_shape(x, E, kernel, stride, pad):
-    N, T, H, W, Cin = x.shape
-    out = dw_out_shape((T, H, W), kernel, stride, pad)
-    return _dw_shape(N, E, (T, H, W), out, kernel, stride, pad), out
-
-
-def xdw_enabled():
-    return _XDW
-
-
-def xdw_supported(x, E, kernel, stride, pad):
-    """Can the fused expand+depthwise kernel (csrc/xdw.hip) take this bottleneck?  x [N,T,H,W,Cin] bf16 on the GPU."""
-    if not (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 5 and x.is_contiguous()):
-        return False
-    key = (tuple(x.shape), int(E), tuple(kernel), tuple(stride), tuple(pad))
-    ok = _xdw_memo.get(key)
-    if ok is None:
-        if min(dw_out_shape(tuple(x.shape[1:4]), kernel, stride, pad)) <= 0:
-            ok = False
-        else:
-            s, _ = _xdw_shape(x, E, kernel, stride, pad)
-            ok = bool(_C.load().pb_xdw_supported(ctypes.byref(s), x.shape[4]))
-        _xdw_memo[key] = ok
-    return ok
-
-
-def xdw_fwd(x, w1, wdw, kernel, stride, pad, pool=False):
-    """d = depthwise(pointwise(x)) without the expanded tensor in HBM.  x bf16 [N,T,H,W,Cin]; w1 fp32 [E,Cin];
-    wdw fp32 [E, k*k] -> (d [N,To,Ho,Wo,E], pool_part fp32 [slots,N,E] or None)."""
-    _ndhwc(x, "x")
-    N, T, H, W, Cin = x.shape
-    E = w1.shape[0]
-    _f32(w1, (E, Cin), "w1"); _f32(wdw, (E, kernel[0] * kernel[1] * kernel[2]), "wdw")
-    if not xdw_supported(x, E, kernel, stride, pad):
-        raise ValueError(f"xdw_fwd: shape {tuple(x.shape)} E={E} k={kernel} s={stride} is not taken by the fused kernel")
-    s, out = _xdw_shape(x, E, kernel, stride, pad)
-    wb = _prepped_weight(w1, False)
-    d = torch.empty((N,) + out + (E,), dtype=x.dtype, device=x.device)
-    part, slots = None, 0
-    if pool:
-        slots = int(_C.load().pb_xdw_pool_slots(ctypes.byref(s), Cin))
-        part = torch.empty((slots, N, E), dtype=torch.float32, device=x.device)
-    dev, st = _dev_stream(x)
-    _launch("xdw_fwd_kernel", _nb(x, d, wdw) + E * Cin * 2, "pb_xdw_fwd", _p(x), _p(wb), _p(wdw), _p(d), ctypes.byref(s), Cin, _p(part), slots, dev, st,
-            detail=f"Cin{Cin} E{E} {T}x{H}x{W}->{out[0]}x{out[1]}x{out[2]} k{tuple(kernel)} s{tuple(stride)}")
-    return d, part
-
-
-def xdw_bwd_weight(dy, x, w1, dwdw, kernel, stride, pad, g_scale=None, g_shift=None):
-    """dwdw[E,k*k] += sum g * pointwise(x), g = dy*g_scale+g_shift: the depthwise weight gradient with the expanded tensor
-    recomputed from x tile by tile (never read from HBM)."""
-    _ndhwc(dy, "dy"); _ndhwc(x, "x")
-    N, To, Ho, Wo, E = dy.shape
-    Cin = x.shape[4]
-    _f32(w1, (E, Cin), "w1"); _f32(dwdw, (E, kernel[0] * kernel[1] * kernel[2]), "dwdw")
-    _f32(g_scale, (N, E), "g_scale"); _f32(g_shift, (N, E), "g_shift")
-    if dy.dtype != x.dtype or not xdw_supported(x, E, kernel, stride, pad):
-        raise ValueError("xdw_bwd_weight: shape not taken by the fused kernel")
-    s, out = _xdw_shape(x, E, kernel, stride, pad)
-    if out != (To, Ho, Wo):
-        raise ValueError(f"xdw_bwd_weight: dy {tuple(dy.shape)} does not match the conv output {out}")
-    wb = _prepped_weight(w1, False)
-    ws = _scratch(_C.load().pb_xdw_bwd_weight_ws_bytes(ctypes.byref(s), Cin), dy.device)
-    dev, st = _dev_stream(dy)
-    job, jref = _defer_job()
-    _launch("xdw_wgrad_kernel", _nb(dy, x, dwdw) + E * Cin * 2, "pb_xdw_bwd_weight", _p(x), _p(wb), _p(dy), _p(dwdw), ctypes.byref(s), Cin, _p(g_scale), _p(g_shift),
-            _p(ws), ws.numel() * 4, jref, dev, st, detail=f"Cin{Cin} E{E} {tuple(x.shape[1:4])}->{To}x{Ho}x{Wo} k{tuple(kernel)} s{tuple(stride)}")
-    _keep_job(job, ws, dwdw)
-    return dwdw
-
-
 # ------------------------------------------------------------------------------ frame gather / scatter
 def frames_gather(x, t0, tstep, count):
     """x [N,T,H,W,C] -> [N,count,H,W,C]: frames t0, t0+tstep, ... (contiguous copy)."""

@@ -215,7 +215,7 @@ def setup_distributed(backend=None):
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     # the process group's flight recorder (read when the group is created): collectives_retired() asks it whether RCCL's
     # watchdog thread still holds work objects
-    os.environ.setdefault("TORCH_NCCL_TRACE_BUFFER_SIZE", "4096")
+    os.environ.setdefault("TORCH_FR_BUFFER_SIZE", "4096")
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"     # "nccl" is RCCL on ROCm
     if backend == "nccl":
@@ -250,7 +250,7 @@ def collectives_retired(timeout_s=20.0, poll_s=0.02):
         from torch._C._distributed_c10d import _dump_nccl_trace
     except ImportError:
         return None
-    if int(__import__("os").environ.get("TORCH_NCCL_TRACE_BUFFER_SIZE", "0") or 0) <= 0:
+    if int(__import__("os").environ.get("TORCH_FR_BUFFER_SIZE", __import__("os").environ.get("TORCH_NCCL_TRACE_BUFFER_SIZE", "0")) or 0) <= 0:
         return None
     t_end = time.monotonic() + timeout_s
     while True:

@@ -85,14 +85,3 @@ def test_causal_stream_buffer_value_and_chunked_streaming(case, cpu_kernels):
                 y, state = ours.forward_stream(x[:, :, t0:t0 + chunk], state)
                 pieces.append(y)
             assert torch.allclose(torch.cat(pieces, 2), want, atol=1e-5, rtol=1e-5), chunk
-
-
-@pytest.mark.parametrize("case", [c for c in BLOCKS if c.startswith("bneck_")])
-def test_block_dataflow_fused_expand_depthwise(case, golden, cpu_kernels, monkeypatch):
-    """The fused expansion->depthwise branch of functional._Bottleneck (the expanded tensor is neither kept nor saved;
-    backward recomputes it inside the depthwise weight gradient) over the CPU mirrors == the reference."""
-    monkeypatch.setattr(kernel_ref, "FORCE_XDW", True)
-    with contextlib.redirect_stdout(io.StringIO()):
-        res = protocol.run_block_case(picklebot_amd, case)
-    bad, worst = compare_full(res, golden("blocks"), case + "/", 1e-5, 1e-5)
-    assert not bad, f"{bad[:5]} worst {worst}"

@@ -680,51 +680,6 @@ def test_partials_reduce_more_than_eight_jobs_with_empty_and_accumulate(K):
 
 
 # ---------------------------------------------------------------------------- fused expansion conv -> depthwise conv
-XDW_CASES = [  # N, Cin, E, (T,H,W), k, s   - every MobileNetLarge3D bottleneck shape class at reduced batch, plus ragged frames
-    (2, 16, 16, (3, 112, 112), 3, 1), (2, 16, 64, (4, 112, 112), 3, 2), (2, 24, 72, (3, 56, 56), 3, 1),
-    (2, 24, 72, (4, 56, 56), 5, 2), (2, 40, 120, (3, 28, 28), 5, 1), (2, 40, 240, (5, 28, 28), 3, 2),
-    (2, 80, 240, (3, 14, 14), 3, 1), (2, 80, 184, (3, 14, 14), 3, 1), (2, 80, 480, (3, 14, 14), 3, 1),
-    (2, 112, 672, (4, 14, 14), 3, 1), (2, 112, 672, (5, 14, 14), 5, 2), (2, 160, 960, (3, 7, 7), 5, 1),
-    (1, 8, 24, (2, 9, 13), 3, 1), (3, 16, 40, (3, 11, 9), 5, 2), (1, 24, 96, (2, 33, 19), 3, 2), (2, 32, 128, (1, 5, 6), 5, 1),
-    (1, 48, 192, (3, 16, 16), 3, 1), (1, 64, 256, (3, 8, 8), 3, 2), (1, 96, 384, (2, 7, 9), 3, 1),
-]
-
-
-@pytest.mark.parametrize("N,Cin,E,thw,k,s", XDW_CASES)
-def test_xdw_fused_expand_depthwise_forward_and_weight_gradient(K, N, Cin, E, thw, k, s):
-    """csrc/xdw.hip: d = dw(pw1(x)) and the depthwise weight gradient with the expanded tensor only in LDS, against the
-    composition of the two mirrors (expanded tensor rounded to bf16 in between, as the unfused kernels store it) - and
-    against the unfused HIP kernels themselves."""
-    kernel, stride, pad = (1, k, k), (s, s, s), (k // 2,) * 3
-    x = rnd((N,) + thw + (Cin,), torch.bfloat16, 41)
-    w1, wdw = rnd((E, Cin), seed=42, scale=Cin ** -0.5), rnd((E, k * k), seed=43, scale=1.0 / k)
-    xd = dev(x)
-    if not K.xdw_supported(xd, E, kernel, stride, pad):
-        pytest.skip("shape not taken by the fused kernel")
-    want, pool_want = R.xdw_fwd(x, w1, wdw, kernel, stride, pad, pool=True)
-    got, part = K.xdw_fwd(xd, dev(w1), dev(wdw), kernel, stride, pad, pool=True)
-    check("xdw_fwd", got, want, torch.bfloat16)
-    check("xdw_pool", part.sum(0), pool_want.sum(0), torch.bfloat16)
-    got2, none = K.xdw_fwd(xd, dev(w1), dev(wdw), kernel, stride, pad, pool=False)
-    assert none is None and torch.equal(got2, got)
-    # the unfused HIP path computes the same bf16 expanded tensor and the same fp32 stencil: equal to rounding of the sums
-    e5 = K.pw_fwd(xd.view(-1, Cin), dev(w1)).view((N,) + thw + (E,))
-    unf = K.dw_fwd(e5, dev(wdw), kernel, stride, pad)
-    check("xdw_vs_unfused", got, unf.cpu(), torch.bfloat16, tol_scale=0.5)
-    # zero frames of the temporal growth quirk are exact zeros
-    To = got.shape[1]
-    zero_frames = [t for t in range(To) if not (0 <= t * s - k // 2 < thw[0])]
-    assert zero_frames and all(float(got[:, t].abs().max()) == 0.0 for t in zero_frames)
-    # weight gradient, with and without the squeeze-excite prologue
-    dy = rnd(tuple(got.shape), torch.bfloat16, 44)
-    gs, gh = torch.rand(N, E) + 0.5, rnd((N, E), seed=45, scale=0.1)
-    for kw in (dict(), dict(g_scale=gs, g_shift=gh), dict(g_scale=gs)):
-        want_w = R.xdw_bwd_weight(dy, x, w1, torch.zeros(E, k * k), kernel, stride, pad, **kw)
-        got_w = K.xdw_bwd_weight(dev(dy), xd, dev(w1), torch.zeros(E, k * k, device=DEV), kernel, stride, pad,
-                                 **{a: dev(b) for a, b in kw.items()})
-        check("xdw_wgrad", got_w, want_w, torch.bfloat16)
-
-
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("N,T,frame,t0,step", [(2, 10, (5, 6, 8), 1, 2), (3, 8, (4, 4, 16), 0, 2), (1, 7, (3, 3, 24), 2, 3), (2, 5, (2, 2, 8), 4, 2)])
 def test_frames_gather_scatter(K, N, T, frame, t0, step, dtype):

@@ -191,21 +191,6 @@ def test_gradients_bf16_per_tensor(case, mode, golden):
     assert not capped, f"{len(capped)} keys beyond {BF16_GRAD_CAP}x, first {capped[:5]}, worst {worst}"
 
 
-def test_fused_expand_depthwise_path_on_a_whole_model(golden, monkeypatch):
-    """PB_XDW=1 (csrc/xdw.hip, opt-in): MobileNetLarge3D bf16-autocast forward quantities against the goldens and the
-    train-mode bf16 gradients within the same per-tensor bound, with the expanded tensors never materialised."""
-    from picklebot_amd import kernels as K
-    monkeypatch.setattr(K, "_XDW", True)
-    K.start_profile()
-    with contextlib.redirect_stdout(io.StringIO()):
-        res = protocol.run_grad_case(picklebot_amd, "large3d", "train", device=DEV, autocast=True)
-    prof = K.stop_profile()
-    assert prof.get("xdw_fwd_kernel", {}).get("launches", 0) >= 11 and prof.get("xdw_wgrad_kernel", {}).get("launches", 0) >= 11
-    res = {k: v for k, v in res.items() if not k.startswith("gsamp/")}
-    bad, worst = check_model_result(res, golden_mode(golden("grad_large3d"), "train"), 1e-2, 1e-2, dev="refbf16_mean", factor=BF16_GRAD_FACTOR)
-    assert not bad, f"{len(bad)} keys off, first {bad[:5]}, worst {worst}"
-
-
 def _large(n, dtype=torch.bfloat16):
     torch.manual_seed(1234)
     m = protocol.build_model(picklebot_amd, "large3d", DEV)
