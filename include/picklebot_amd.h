@@ -34,7 +34,7 @@ typedef enum {
   PB_ACT_HSIGMOID = 4, PB_ACT_SILU = 5
 } pb_act;
 
-#define PB_ABI_VERSION 16
+#define PB_ABI_VERSION 17
 
 /* Determinism.  Nothing in this library accumulates with floating-point atomics: two runs of the same binary on the
  * same inputs give bit-identical outputs and gradients.  Every reduction that spans workgroups stores one partial
@@ -359,6 +359,15 @@ int pb_layernorm(const void* x, const void* dy, void* out, float* stat, int64_t 
                  pb_dtype dtype, int device, void* stream);
 int pb_copy_cols(const void* src, int64_t src_ld, int src_off, void* dst, int64_t dst_ld, int dst_off, int64_t M, int C,
                  int accumulate, pb_dtype dtype, int device, void* stream);
+/* The WIDE token stream (round 4): Transformer.forward's running sum `x = attn(x) + x; x = ff(x) + x`
+ * (mobilevit.py:100-104) kept in fp32 between blocks while every GEMM operand stays bf16.
+ * pb_layernorm_wide  forward : out_bf16 = bf16(LayerNorm(x fp32)), stat [rows][2] = mean, rstd
+ *                    backward: out32 = res32 + dLayerNorm(x, dy_bf16, stat); out_bf16 (optional) = bf16(out32)
+ * pb_stream_add      out32 (optional) = a + b, out_bf16 (optional) = bf16(a + b); a fp32 or bf16, b bf16; n % 8 == 0 */
+int pb_layernorm_wide(const float* x, const void* dy_bf16, const float* res32, void* out_bf16, float* out32, float* stat,
+                      int64_t rows, int D, float eps, int backward, int device, void* stream);
+int pb_stream_add(const void* a, pb_dtype a_dtype, const void* b_bf16, float* out32, void* out_bf16, int64_t n, int device,
+                  void* stream);
 
 /* ---------------------------------------------------------------- MobileViT patch attention
  * Replaces F.scaled_dot_product_attention(q,k,v) on (b, p, h=8, n, d=16) + the rearranges around it

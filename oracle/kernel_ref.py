@@ -469,6 +469,24 @@ def layernorm_bwd(x, dy, stat, eps):
     return dx.to(x.dtype)
 
 
+def layernorm_wide_fwd(x32, eps):
+    mean = x32.mean(1, keepdim=True)
+    rstd = torch.rsqrt(x32.var(1, unbiased=False, keepdim=True) + eps)
+    return ((x32 - mean) * rstd).to(torch.bfloat16), torch.cat([mean, rstd], 1)
+
+
+def layernorm_wide_bwd(x32, dxn, stat, eps, res32, want_bf16=True):
+    g = dxn.float()
+    xh = (x32 - stat[:, :1]) * stat[:, 1:]
+    g32 = res32 + stat[:, 1:] * (g - g.mean(1, keepdim=True) - xh * (g * xh).mean(1, keepdim=True))
+    return g32, (g32.to(torch.bfloat16) if want_bf16 else None)
+
+
+def stream_add(a, b, want32=True, want_bf16=True):
+    o = a.float() + b.float()
+    return (o if want32 else None), (o.to(torch.bfloat16) if want_bf16 else None)
+
+
 def copy_cols(src, src_off, dst, dst_off, C, accumulate=False):
     if accumulate:
         dst[:, dst_off:dst_off + C] += src[:, src_off:src_off + C]

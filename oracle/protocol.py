@@ -44,6 +44,16 @@ GRAD_CASES = {   # name -> (N, T, H, W, input salt)
     "mobilevit_xxs": (8, 8, 64, 64, 18),
 }
 
+# Larger train-mode clips, NOT screened: realistic spatial sizes for the compact-frame / frame-map paths (the
+# screened clips above leave the last MobileNet stages with 2x2 maps).  An unscreened clip has activation inputs within
+# rounding distance of a derivative jump, so any fp32 implementation - the reference's own included - lands on one side
+# or the other by luck: these cases are bounded by the reference's OWN fp32 spread over its arithmetic variants
+# (`ref32_spread`, stored per key), not by the flat 1e-3.
+GRAD_CASES_LARGE = {   # name -> (N, T, H, W, input salt)
+    "large3d": (4, 8, 112, 112, 7),
+    "small3d": (8, 8, 112, 112, 7),
+}
+
 N_SAMPLE = 8
 
 

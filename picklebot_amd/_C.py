@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libpicklebot_amd.so")
 
 PB_F32, PB_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY_RELU, ACT_HSWISH, ACT_HSIGMOID, ACT_SILU = range(6)
-ABI_VERSION = 16
+ABI_VERSION = 17
 STAT_SLOTS = 512
 
 
@@ -71,6 +71,8 @@ SIGNATURES = {
     "pb_unfold_fold": [P, P, I, I, I, I, I, I, I, I, I, I, I, P],
     "pb_layernorm": [P, P, P, P, L, I, F, I, I, I, P],
     "pb_copy_cols": [P, L, I, P, L, I, L, I, I, I, I, P],
+    "pb_layernorm_wide": [P, P, P, P, P, P, L, I, F, I, I, P],
+    "pb_stream_add": [P, I, P, P, P, L, I, P],
     "pb_attention_fwd": [P, P, P, L, I, F, I, I, P],
     "pb_attention_fwd_fp8": [P, P, P, L, I, F, I, P],
     "pb_attention_bwd": [P, P, P, P, P, P, L, I, F, I, I, P],

@@ -127,6 +127,110 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T_* x, const T_* d
   }
 }
 
+// ---- the WIDE token stream (round 4) ------------------------------------------------------------
+// Transformer.forward's `x = attn(x) + x; x = ff(x) + x` (mobilevit.py:100-104) with the running sum x kept in fp32
+// while every GEMM operand stays bf16: LayerNorm reads the fp32 stream and writes the bf16 GEMM input; the residual
+// add reads the fp32 stream and the bf16 block output and writes the fp32 stream (and, when the next consumer is a GEMM,
+// its bf16 rounding) in ONE pass.  Backward runs the same two kernels on the gradient stream.
+//   forward : xn = bf16((x - mean) * rstd), saves mean/rstd
+//   backward: out32 = res32 + rstd * (dy - mean(dy) - xhat * mean(dy * xhat));  out_bf16 = bf16(out32) (optional)
+template <bool BWD>
+__global__ __launch_bounds__(256) void layernorm_wide_kernel(const float* x, const bf16_t* dy, const float* res, bf16_t* out_bf,
+                                                             float* out32, float* stat, int64_t rows, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int c = lane * 4;
+  const bool ok = c < D;                 // D % 4 == 0
+  float v[4] = {0.f, 0.f, 0.f, 0.f}, g[4] = {0.f, 0.f, 0.f, 0.f}, r[4] = {0.f, 0.f, 0.f, 0.f};
+  if (ok) {
+    const float4 xv = *(const float4*)(x + row * D + c);
+    v[0] = xv.x; v[1] = xv.y; v[2] = xv.z; v[3] = xv.w;
+    if constexpr (BWD) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) g[i] = to_f32(dy[row * D + c + i]);
+      const float4 rv = *(const float4*)(res + row * D + c);
+      r[0] = rv.x; r[1] = rv.y; r[2] = rv.z; r[3] = rv.w;
+    }
+  }
+  float mean, rstd;
+  if constexpr (!BWD) {
+    const float s = wave_sum(v[0] + v[1] + v[2] + v[3]);
+    mean = s / D;
+    float q = 0.f;
+    if (ok) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) q += (v[i] - mean) * (v[i] - mean);
+    }
+    q = wave_sum(q);
+    rstd = rsqrtf(q / D + eps);
+    if (lane == 0) {
+      stat[row * 2] = mean;
+      stat[row * 2 + 1] = rstd;
+    }
+    if (ok) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) out_bf[row * D + c + i] = from_f32<bf16_t>((v[i] - mean) * rstd);
+    }
+  } else {
+    mean = stat[row * 2];
+    rstd = stat[row * 2 + 1];
+    float sg = 0.f, sgx = 0.f;
+    if (ok) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float xh = (v[i] - mean) * rstd;
+        sg += g[i];
+        sgx += g[i] * xh;
+      }
+    }
+    sg = wave_sum(sg) / D;
+    sgx = wave_sum(sgx) / D;
+    if (ok) {
+      float o[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float xh = (v[i] - mean) * rstd;
+        o[i] = r[i] + rstd * (g[i] - sg - xh * sgx);
+      }
+      *(float4*)(out32 + row * D + c) = make_float4(o[0], o[1], o[2], o[3]);
+      if (out_bf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) out_bf[row * D + c + i] = from_f32<bf16_t>(o[i]);
+      }
+    }
+  }
+}
+
+// out32 = a + b (a fp32 or bf16, b bf16), out_bf16 = bf16(out32); either output may be absent.  8 elements per thread.
+template <typename TA>
+__global__ __launch_bounds__(256) void stream_add_kernel(const TA* a, const bf16_t* b, float* out32, bf16_t* out_bf, int64_t n8) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+    float v[8];
+    if constexpr (sizeof(TA) == 4) {
+      const float4 a0 = *(const float4*)(a + i * 8), a1 = *(const float4*)(a + i * 8 + 4);
+      v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
+    } else {
+      const Vec16<bf16_t> av = vec_load<bf16_t>((const bf16_t*)a + i * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = av.get(e);
+    }
+    const Vec16<bf16_t> bv = vec_load<bf16_t>(b + i * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += bv.get(e);
+    if (out32) {
+      *(float4*)(out32 + i * 8) = make_float4(v[0], v[1], v[2], v[3]);
+      *(float4*)(out32 + i * 8 + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+    if (out_bf) {
+      Vec16<bf16_t> o = vec_zero<bf16_t>();
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o.set(e, v[e]);
+      vec_store<bf16_t>(out_bf + i * 8, o);
+    }
+  }
+}
+
 // ---- strided column copy: dst[m*ldd + doff + c] = src[m*lds + soff + c], c < C ------------------
 template <typename T_>
 __global__ __launch_bounds__(256) void copy_cols_kernel(const T_* src, int64_t lds_, int soff, T_* dst, int64_t ldd, int doff,
@@ -207,6 +311,37 @@ extern "C" int pb_copy_cols(const void* src, int64_t src_ld, int src_off, void* 
   hipStream_t st = (hipStream_t)stream;
   if (dtype == PB_BF16) hipLaunchKernelGGL(copy_cols_kernel<bf16_t>, dim3((unsigned)gx), dim3(256), 0, st, (const bf16_t*)src, src_ld, src_off, (bf16_t*)dst, dst_ld, dst_off, M, C, accumulate);
   else hipLaunchKernelGGL(copy_cols_kernel<float>, dim3((unsigned)gx), dim3(256), 0, st, (const float*)src, src_ld, src_off, (float*)dst, dst_ld, dst_off, M, C, accumulate);
+  PB_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pb_layernorm_wide(const float* x, const void* dy_bf16, const float* res32, void* out_bf16, float* out32,
+                                 float* stat, int64_t rows, int D, float eps, int backward, int device, void* stream) {
+  PB_CHECK_ARG(x && stat, "pb_layernorm_wide: null pointer");
+  PB_CHECK_ARG(backward ? (dy_bf16 && res32 && out32) : (out_bf16 != nullptr), "pb_layernorm_wide: missing operand");
+  PB_CHECK_ARG(rows >= 0 && D > 0 && D <= 256 && D % 4 == 0, "pb_layernorm_wide: D=%d must be a multiple of 4, <= 256", D);
+  if (rows == 0) return 0;
+  PB_ENTER(device);
+  dim3 grid((unsigned)pb_cdiv(rows, 4));
+  hipStream_t st = (hipStream_t)stream;
+  if (backward) hipLaunchKernelGGL(layernorm_wide_kernel<true>, grid, dim3(256), 0, st, x, (const bf16_t*)dy_bf16, res32, (bf16_t*)out_bf16, out32, stat, rows, D, eps);
+  else hipLaunchKernelGGL(layernorm_wide_kernel<false>, grid, dim3(256), 0, st, x, (const bf16_t*)dy_bf16, res32, (bf16_t*)out_bf16, out32, stat, rows, D, eps);
+  PB_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pb_stream_add(const void* a, pb_dtype a_dtype, const void* b_bf16, float* out32, void* out_bf16, int64_t n,
+                             int device, void* stream) {
+  PB_CHECK_ARG(a && b_bf16 && (out32 || out_bf16), "pb_stream_add: null pointer");
+  PB_CHECK_ARG(a_dtype == PB_F32 || a_dtype == PB_BF16, "pb_stream_add: bad dtype");
+  PB_CHECK_ARG(n >= 0 && n % 8 == 0, "pb_stream_add: n must be a multiple of 8");
+  if (n == 0) return 0;
+  PB_ENTER(device);
+  int64_t gx = pb_cdiv(n / 8, 256);
+  if (gx > 8192) gx = 8192;
+  hipStream_t st = (hipStream_t)stream;
+  if (a_dtype == PB_F32) hipLaunchKernelGGL(stream_add_kernel<float>, dim3((unsigned)gx), dim3(256), 0, st, (const float*)a, (const bf16_t*)b_bf16, out32, (bf16_t*)out_bf16, n / 8);
+  else hipLaunchKernelGGL(stream_add_kernel<bf16_t>, dim3((unsigned)gx), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b_bf16, out32, (bf16_t*)out_bf16, n / 8);
   PB_LAUNCH_CHECK();
   return 0;
 }

@@ -15,6 +15,8 @@ swap it for the CPU mirror to check this file's dataflow without a GPU; the prod
 """
 import functools
 
+import os
+
 import torch
 
 from . import kernels as K
@@ -774,6 +776,94 @@ class _FFBlock(torch.autograd.Function):
         K.weight_grad_branch(dy, (w1, w2), [lambda: K.pw_bwd_weight(dy, h, dw2), lambda: K.pw_bwd_weight(dhpre, x, dw1)],
                              (dy, h, dhpre, x, dw1, dw2), "ff")
         return dx, dw1.view_as(w1), dw2.view_as(w2), None                                          # (fresh views, see _ConvBnAct)
+
+
+class _TransformerWide(torch.autograd.Function):
+    """Transformer.forward (mobilevit.py:89-104: `x = attn(x) + x; x = ff(x) + x`, depth times) on bf16 token rows [G*n, D]
+    with the RUNNING SUM kept in fp32 (round 4).  Every GEMM / attention operand is bf16 exactly as under the reference's
+    autocast; what is wider than the reference is the residual stream between the blocks (autocast's `bf16 + bf16` add
+    rounds it to bf16 after every block - measured on CUDA autocast, profiles/r04_autocast_dtypes.txt) and, in backward,
+    the gradient stream.  The rounding of that stream was the systematic part of this path's bf16 gradient deviation
+    towards the input.  One autograd node for the whole stack: the fp32 stream and its bf16 rounding
+    travel together between the blocks, LayerNorm reads the fp32 stream directly and the residual add emits the next
+    GEMM's bf16 input in the same pass (K.stream_add / K.layernorm_wide_*)."""
+
+    @staticmethod
+    def forward(ctx, x, G, n, scale, eps, *weights):
+        L = len(weights) // 4
+        s32, saved = None, []
+        out = None
+        for l in range(L):
+            w_qkv, w_out, w1, w2 = weights[4 * l:4 * l + 4]
+            s_in = s32
+            if s32 is None:
+                xn, stat = K.layernorm_fwd(x, eps)                    # the stack's input is the bf16 output of conv2
+            else:
+                xn, stat = K.layernorm_wide_fwd(s32, eps)
+            qkv = K.pw_fwd(xn, w_qkv)
+            o, lse = K.attention_fwd(qkv, G, n, scale)
+            y = K.pw_fwd(o, w_out)
+            s32, xb = K.stream_add(x if s32 is None else s32, y)      # attn(x) + x: fp32 stream + the feed-forward's bf16 input
+            hpre = K.pw_fwd(xb, w1)
+            h = K.affine_act_fwd(hpre, act="silu")
+            y2 = K.pw_fwd(h, w2)
+            last = l == L - 1
+            s32, out = K.stream_add(s32, y2, want32=not last, want_bf16=last)   # ff(x) + x
+            saved += [s_in, stat, xn, qkv, o, lse, xb, hpre, h]
+        ctx.meta = (G, n, scale, eps, L)
+        ctx.save_for_backward(x, *weights, *saved)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        G, n, scale, eps, L = ctx.meta
+        x = ctx.saved_tensors[0]
+        weights = ctx.saved_tensors[1:1 + 4 * L]
+        saved = ctx.saved_tensors[1 + 4 * L:]
+        gb = dy if dy.is_contiguous() else dy.contiguous()            # bf16 rounding of the gradient stream
+        g32 = None                                                    # the fp32 gradient stream (None: it IS gb)
+        grads = [None] * (4 * L)
+        dx = None
+        for l in reversed(range(L)):
+            w_qkv, w_out, w1, w2 = weights[4 * l:4 * l + 4]
+            s_in, stat, xn, qkv, o, lse, xb, hpre, h = saved[9 * l:9 * l + 9]
+            dw_qkv, dw_out, dw1, dw2 = _zeros_many(x, tuple(w_qkv.shape), tuple(w_out.shape), tuple(w1.shape), tuple(w2.shape))
+            # feed-forward block
+            dh = K.pw_fwd(gb, w2, w_transposed=True)
+            dhpre = K.act_bwd_reduce(dh, hpre, act="silu")
+            dxf = K.pw_fwd(dhpre, w1, w_transposed=True)
+            K.weight_grad_branch(gb, (w1, w2), [lambda gb=gb, h=h, dw2=dw2: K.pw_bwd_weight(gb, h, dw2),
+                                                lambda dhpre=dhpre, xb=xb, dw1=dw1: K.pw_bwd_weight(dhpre, xb, dw1)],
+                                 (gb, h, dhpre, xb, dw1, dw2), "ff")
+            g32, gb = K.stream_add(gb if g32 is None else g32, dxf)
+            # attention block
+            do = K.pw_fwd(gb, w_out, w_transposed=True)
+            dqkv = K.attention_bwd(qkv, o, do, lse, G, n, scale)
+            dxn = K.pw_fwd(dqkv, w_qkv, w_transposed=True)
+            K.weight_grad_branch(gb, (w_qkv, w_out), [lambda gb=gb, o=o, dw_out=dw_out: K.pw_bwd_weight(gb, o, dw_out),
+                                                      lambda dqkv=dqkv, xn=xn, dw_qkv=dw_qkv: K.pw_bwd_weight(dqkv, xn, dw_qkv)],
+                                 (gb, o, dqkv, xn, dw_out, dw_qkv), "attn")
+            if s_in is not None:
+                g32, gb = K.layernorm_wide_bwd(s_in, dxn, stat, eps, g32)
+            else:
+                dxl = K.layernorm_bwd(x, dxn, stat, eps)
+                _, dx = K.stream_add(g32, dxl, want32=False, want_bf16=True)
+            grads[4 * l:4 * l + 4] = [dw_qkv.view_as(w_qkv), dw_out.view_as(w_out), dw1.view_as(w1), dw2.view_as(w2)]   # fresh views
+        return (dx, None, None, None, None) + tuple(grads)
+
+
+_VIT_WIDE = os.environ.get("PB_VIT_WIDE", "1") != "0"
+
+
+def transformer_wide_ok(rows):
+    """bf16 token rows (autocast) take the wide-stream stack; fp32 rows are wide anyway; fp8 inference keeps its own path."""
+    return _VIT_WIDE and rows.dtype == torch.bfloat16 and rows.numel() % 8 == 0 and not (_fp8_attention and not torch.is_grad_enabled())
+
+
+def transformer_wide(rows, layer_weights, G, n, scale, eps):
+    """layer_weights: [(w_qkv, w_out, w_ff1, w_ff2), ...] -> bf16 rows after all layers."""
+    flat = [w for lw in layer_weights for w in lw]
+    return _TransformerWide.apply(rows if rows.is_contiguous() else rows.contiguous(), G, n, scale, eps, *flat)
 
 
 _fp8_attention = False

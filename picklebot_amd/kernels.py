@@ -1259,6 +1259,47 @@ def layernorm_bwd(x, dy, stat, eps):
     return dx
 
 
+def layernorm_wide_fwd(x32, eps):
+    """bf16 LayerNorm(x) of the fp32 token stream -> (xn bf16 [M,D], stat fp32 [M,2])."""
+    _rows(x32, "x"); _f32(x32, None, "x")
+    M, D = x32.shape
+    xn = torch.empty((M, D), dtype=torch.bfloat16, device=x32.device)
+    stat = torch.empty((M, 2), dtype=torch.float32, device=x32.device)
+    dev, st = _dev_stream(x32)
+    _launch("layernorm_fwd", _nb(x32, xn), "pb_layernorm_wide", _p(x32), None, None, _p(xn), None, _p(stat), M, D, float(eps), 0, dev, st)
+    return xn, stat
+
+
+def layernorm_wide_bwd(x32, dxn, stat, eps, res32, want_bf16=True):
+    """-> (g32 = res32 + dLayerNorm(x32; dxn bf16), bf16(g32) or None): LayerNorm backward + the residual branch of the
+    gradient stream in one pass."""
+    _rows(x32, "x"); _f32(x32, None, "x"); _rows(dxn, "dxn"); _f32(res32, tuple(x32.shape), "res")
+    M, D = x32.shape
+    _f32(stat, (M, 2), "stat")
+    if dxn.shape != x32.shape or dxn.dtype != torch.bfloat16:
+        raise ValueError("layernorm_wide_bwd: dxn must be bf16 of x's shape")
+    g32 = torch.empty_like(x32)
+    gbf = torch.empty((M, D), dtype=torch.bfloat16, device=x32.device) if want_bf16 else None
+    dev, st = _dev_stream(x32)
+    _launch("layernorm_bwd", _nb(x32, dxn, res32, g32, gbf), "pb_layernorm_wide", _p(x32), _p(dxn), _p(res32), _p(gbf), _p(g32), _p(stat),
+            M, D, float(eps), 1, dev, st)
+    return g32, gbf
+
+
+def stream_add(a, b, want32=True, want_bf16=True):
+    """(a + b in fp32, its bf16 rounding): a fp32 or bf16, b bf16, same shape - the residual add of the wide token stream."""
+    _rows(a, "a"); _rows(b, "b")
+    if a.shape != b.shape or b.dtype != torch.bfloat16 or a.dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError("stream_add: a (fp32 / bf16) and b (bf16) must have the same shape")
+    if a.numel() % 8:
+        raise ValueError("stream_add: element count must be a multiple of 8")
+    o32 = torch.empty(a.shape, dtype=torch.float32, device=a.device) if want32 else None
+    obf = torch.empty(a.shape, dtype=torch.bfloat16, device=a.device) if want_bf16 else None
+    dev, st = _dev_stream(a)
+    _launch("stream_add", _nb(a, b, o32, obf), "pb_stream_add", _p(a), _dt(a), _p(b), _p(o32), _p(obf), a.numel(), dev, st)
+    return o32, obf
+
+
 def copy_cols(src, src_off, dst, dst_off, C, accumulate=False):
     """dst[:, dst_off:dst_off+C] (+)= src[:, src_off:src_off+C] for contiguous 2-D src/dst with equal row counts."""
     _rows(src, "src"); _rows(dst, "dst")

@@ -104,6 +104,14 @@ class Transformer(nn.Module):
         rows = x.reshape(-1, d)
         if rows.dtype != compute_dtype(x):
             rows = rows.to(compute_dtype(x))
+        if PF.transformer_wide_ok(rows) and all(a.heads == 8 and a.inner_dim == 128 for a, _ in self.layers):
+            # bf16 activations (autocast): one fused stack with the residual stream in fp32 between the blocks
+            for attn, ff in self.layers:
+                _no_dropout(attn.dropout_p if self.training else 0, "Attention")
+                _no_dropout(ff.net[2].p if self.training else 0, "FeedForward")
+            a0 = self.layers[0][0]
+            ws = [(a.to_qkv.weight, a.to_out[0].weight, f.net[0].weight, f.net[3].weight) for a, f in self.layers]
+            return PF.transformer_wide(rows, ws, b * p, n, a0.scale, a0.norm.eps).view(b, p, n, d)
         for attn, ff in self.layers:
             rows = attn.rows(rows, b * p, n)       # attn(x) + x
             rows = ff.rows(rows)                   # ff(x) + x

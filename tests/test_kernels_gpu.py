@@ -470,6 +470,32 @@ def test_unfold_fold_layernorm_copy(K, B, D, thw, dtype):
     check("copy_cols", dst, dst_ref, dtype)
 
 
+@pytest.mark.parametrize("M,D", [(37, 64), (1031, 144), (515, 240), (8, 96), (3001, 192)])
+def test_wide_token_stream_kernels(K, M, D):
+    """pb_layernorm_wide / pb_stream_add (round 4: the Transformer's fp32 residual stream between bf16 blocks) vs mirrors:
+    the fp32 outputs to fp32 accuracy, the bf16 outputs bit for bit as roundings of the kernel's own fp32 result."""
+    x32 = rnd((M, D), torch.float32, 70, scale=2.0) + 0.3
+    b = rnd((M, D), torch.bfloat16, 71)
+    xn_ref, st_ref = R.layernorm_wide_fwd(x32, 1e-5)
+    xn, st = K.layernorm_wide_fwd(dev(x32), 1e-5)
+    assert xn.dtype == torch.bfloat16
+    check("ln_wide", xn, xn_ref, torch.bfloat16, 0.5); check("ln_wide_stat", st, st_ref, torch.float32)
+    res = rnd((M, D), torch.float32, 72)
+    g32_ref, _ = R.layernorm_wide_bwd(x32, b, st_ref, 1e-5, res)
+    g32, gbf = K.layernorm_wide_bwd(dev(x32), dev(b), dev(st_ref), 1e-5, dev(res))
+    check("ln_wide_bwd", g32, g32_ref, torch.float32)
+    assert torch.equal(gbf, g32.to(torch.bfloat16))
+    g32b, none = K.layernorm_wide_bwd(dev(x32), dev(b), dev(st_ref), 1e-5, dev(res), want_bf16=False)
+    assert none is None and torch.equal(g32b, g32)
+    for a in (x32, x32.to(torch.bfloat16)):
+        o_ref, ob_ref = R.stream_add(a, b)
+        o, ob = K.stream_add(dev(a), dev(b))
+        assert torch.equal(o.cpu(), o_ref) and torch.equal(ob.cpu(), ob_ref)          # one fp32 add: exact
+        o2, n2 = K.stream_add(dev(a), dev(b), want_bf16=False)
+        n3, ob3 = K.stream_add(dev(a), dev(b), want32=False)
+        assert n2 is None and n3 is None and torch.equal(o2, o) and torch.equal(ob3, ob)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("G,n", [(8, 6), (3, 32), (2, 147), (2, 128), (1, 784)])
 def test_attention(K, G, n, dtype):

@@ -128,6 +128,24 @@ def test_gradients_fp32_flat_1e3(case, mode, golden):
     assert not bad, f"{len(bad)} keys off, first {bad[:5]}, worst {worst}"
 
 
+@pytest.mark.parametrize("case", [c for c in protocol.GRAD_CASES_LARGE if c in MODELS])
+def test_train_gradients_fp32_at_112x112_within_the_references_own_spread(case, golden):
+    """the screened train clips are 64x64 (the last MobileNet stages run 5x5 kernels on 2x2 maps), so this adds one
+    train-mode case per MobileNet at 8x112x112 - realistic frame sizes for the compact-frame / frame-map / frames_scatter
+    paths.  The clip is NOT screened: it has activation inputs within rounding distance of a derivative jump (16 / 2 within
+    1e-5, stored in train/meta), so every fp32 implementation lands on one side or the other by luck - the reference's own
+    four arithmetic variants are 1.2e-2 (median over the tensors) apart from fp64 on it.  Bound per key: 3 x the reference's
+    own fp32 spread (`ref32_spread` = its worst variant), floor 1e-3; forward quantities likewise."""
+    gold = golden_mode(golden("grad112_" + case), "train")
+    shape, salt = protocol.GRAD_CASES_LARGE[case][:4], protocol.GRAD_CASES_LARGE[case][4]
+    assert tuple(int(v) for v in gold["meta/clip"]) == tuple(shape) + (salt,)
+    with contextlib.redirect_stdout(io.StringIO()):
+        res = protocol.run_grad_case(picklebot_amd, case, "train", device=DEV, shape=shape, salt=salt)
+    bad, worst = check_model_result(res, gold, 1e-3, 1e-3, dev="ref32_spread", factor=3.0, samp_factor=4.0)
+    print(f"{case} 8x112x112 train fp32: worst {worst}")
+    assert not bad, f"{len(bad)} keys off, first {bad[:5]}, worst {worst}"
+
+
 @pytest.mark.parametrize("case", ["movinet_a2", "large3d"])
 def test_train_gradients_do_not_depend_on_the_summation_order(case, golden, monkeypatch):
     """with the squeeze-excite slot sums re-associated (PB_SE_ASSOC=1: tail into the last chain, chains added
@@ -145,8 +163,7 @@ def test_train_gradients_do_not_depend_on_the_summation_order(case, golden, monk
     assert moved, "the two associations gave identical bits: the knob is not reaching the kernels"
 
 
-BF16_GRAD_FACTOR = 3.0        # bar for (at least) nine tensors in ten
-BF16_GRAD_CAP = 6.0           # bar for every tensor
+BF16_GRAD_FACTOR = 3.0        # bar for EVERY tensor (round 4; rounds 2-3: 5x / "90 % within 3x, all within 6x")
 
 
 @pytest.mark.parametrize("mode", ["evalgrad", "train"])
@@ -154,41 +171,26 @@ BF16_GRAD_CAP = 6.0           # bar for every tensor
 def test_gradients_bf16_per_tensor(case, mode, golden):
     """bf16 autocast (train.py:264), PER TENSOR (norm and every full-tensor projection of every parameter gradient), against
     the reference's OWN bf16-autocast deviation from fp64 for that tensor (mean over four arithmetic variants of the real
-    reference, oracle/make_golden.py; floor = the north_star's 1e-2).
+    reference, oracle/make_golden.py; floor = the north_star's 1e-2): forward quantities, gradient norms and gradient
+    projections within 3x - ALL of them, all ten cases.
 
-    Forward quantities and gradient norms: within 3x, all of them.  Gradient projections: at least 90 % of the tensors
-    within 3x and none beyond 6x.  Where the numbers come from:
-      * 3 = 2.2 x 1.35.  The reference's deviation is its full-tensor error norm (exact); ours is measured through 8
-        random-sign projections, i.e. sqrt(chi2_8 / 8) x our true error - above 2.2 with probability 6e-6 per tensor at
-        EQUAL accuracy; 1.35 is this path's measured excess on single tensors (it keeps one more intermediate,
-        g = dy * act', in bf16).  Eight of the ten cases sit entirely inside 3x (tools/grad_err.py --bf16: ours /
-        reference = median 0.0-1.06, max 1.2-2.7).
-      * The tail.  The two MobileViT eval-mode cases do not: their input-side tensors (stem, conv1) are 2-2.4x the
-        reference's deviation as a STAGE MEAN and single tensors reach 3-4.5x.  Two things were measured about that
-        (profiles/r03_bf16_blame_*.txt, tools/probes/bf16_blame.py).  It is partly systematic: the reference's own
-        deviation shrinks towards the input (1.3e-2 in the stem against 2.5-4e-2 in the transformer stages - autocast
-        keeps LayerNorm, the residual adds and so the whole token stream in fp32), ours does not (this path rounds the
-        stream to bf16 at every block; keeping the token stream in fp32 brings MobileViT-S's stem from 2.4x to 1.5x).
-        And it is chaotic: five builds of the attention kernels that are equal or BETTER at kernel level (running
-        maximum exact / bounded / lazy, scores with an 8- or 16-bit multiplier; tools/probes/attn_accuracy.py) moved the
-        worst single tensor between 2.2x and 4.5x and the first conv between 0.7x and 2.4x - bf16-sized perturbations
-        flip hardswish / ReLU / SiLU derivative branches downstream, and everything upstream of a flip moves together.
-        The reference's four variants round identically in eval mode, so it offers one draw of that lottery, not a
-        distribution.  A single-tensor bar at 3x therefore tested the draw, not the path: hence the quantile form, with
-        the cap at 2.2 (sampling) x 2.4 (worst stage mean) ~ 6 (round 2's bar was 5x for every tensor).
-    Measured (gpurun_out/att, final build): tensors beyond 3x: MobileViT-S eval 5 of 86 (max 3.96), XXS eval 1 of 86
-    (3.04), every other case none."""
+    3 = 2.2 x 1.35: the reference's deviation is its full-tensor error norm (exact); ours is measured through 8 random-sign
+    projections, i.e. sqrt(chi2_8 / 8) x our true error - above 2.2 with probability 6e-6 per tensor at EQUAL accuracy;
+    1.35 is this path's measured excess on single tensors (it keeps one more intermediate, g = dy * act', in bf16).
+
+    Round 3 needed a quantile form (90 % within 3x, cap 6x) for the two MobileViT eval-mode cases, whose input-side tensors
+    sat at 2-2.4x as a stage mean (single tensors up to 3.96x).  The systematic part of that was the rounding of the
+    Transformer's residual stream to bf16 after every block in forward AND backward; the stream is fp32 now
+    (functional._TransformerWide - WIDER than the reference, whose autocast adds are bf16 + bf16 -> bf16,
+    profiles/r04_autocast_dtypes.txt).  Measured (profiles/r04_grad_err_bf16.txt), ours / reference over 86 tensors:
+    MobileViT-S eval median 0.77, max 2.29 (was 1.21 / 3.96); XXS eval 0.90 / 1.85 (was 1.34 / 3.04); train mode
+    0.82-0.86 / 1.34-1.76; the MobileNet / MoViNet cases are unchanged (max 1.2-2.7)."""
     with contextlib.redirect_stdout(io.StringIO()):
         res = protocol.run_grad_case(picklebot_amd, case, mode, device=DEV, autocast=True)
     res = {k: v for k, v in res.items() if not k.startswith("gsamp/")}
     gold = golden_mode(golden("grad_" + case), mode)
     bad, worst = check_model_result(res, gold, 1e-2, 1e-2, dev="refbf16_mean", factor=BF16_GRAD_FACTOR)
-    strict = [b for b in bad if not b[0].startswith("gproj/")]
-    assert not strict, f"forward / norm keys off: {strict[:5]}"
-    nproj = sum(1 for k in res if k.startswith("gproj/"))
-    assert len(bad) <= 0.10 * nproj, f"{len(bad)} of {nproj} tensors beyond {BF16_GRAD_FACTOR}x, first {bad[:5]}, worst {worst}"
-    capped, worst = check_model_result(res, gold, 1e-2, 1e-2, dev="refbf16_mean", factor=BF16_GRAD_CAP)
-    assert not capped, f"{len(capped)} keys beyond {BF16_GRAD_CAP}x, first {capped[:5]}, worst {worst}"
+    assert not bad, f"{len(bad)} keys beyond {BF16_GRAD_FACTOR}x, first {bad[:5]}, worst {worst}"
 
 
 def _large(n, dtype=torch.bfloat16):
