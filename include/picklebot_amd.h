@@ -34,7 +34,7 @@ typedef enum {
   PB_ACT_HSIGMOID = 4, PB_ACT_SILU = 5
 } pb_act;
 
-#define PB_ABI_VERSION 17
+#define PB_ABI_VERSION 18
 
 /* Determinism.  Nothing in this library accumulates with floating-point atomics: two runs of the same binary on the
  * same inputs give bit-identical outputs and gradients.  Every reduction that spans workgroups stores one partial
@@ -204,6 +204,13 @@ int64_t pb_dwconv3d_bwd_weight_ws_bytes(const pb_dwconv_shape* s, pb_dtype dtype
 int pb_dwconv3d_bwd_weight(const void* dy, const void* x, float* dw, const pb_dwconv_shape* s, pb_dtype dtype,
                            const float* g_scale, const float* g_shift, void* ws, int64_t ws_bytes,
                            pb_reduce_job* deferred, int device, void* stream);
+/* Both gradients of Bottleneck3D's depthwise conv (mobilenet.py:67-75) in ONE launch: dx as pb_dwconv3d_bwd_data, dw as
+ * pb_dwconv3d_bwd_weight; dy is read once.  bf16, (1,k,k) with k in {3,5}, stride 1, "same" spatial padding.
+ * pb_dwconv3d_bwd_fused_ws_bytes returns 0 when the shape / dtype is not taken (then call the two entry points above). */
+int64_t pb_dwconv3d_bwd_fused_ws_bytes(const pb_dwconv_shape* s, pb_dtype dtype);
+int pb_dwconv3d_bwd_fused(const void* dy, const void* x, const float* w, void* dx, float* dw, const pb_dwconv_shape* s,
+                          pb_dtype dtype, const float* g_scale, const float* g_shift, void* ws, int64_t ws_bytes,
+                          pb_reduce_job* deferred, int device, void* stream);
 
 /* ---------------------------------------------------------------- frame gather / scatter (temporally strided bottlenecks)
  * Bottleneck3D's depthwise conv has a (1,k,k) kernel and strides T as well (mobilenet.py:67-75): with stride 2 only every

@@ -25,7 +25,12 @@ class deferred_reductions:
         return False
 
 
-def weight_grad_branch(ref, params, thunks, keep, tag=""):
+class held_reductions(deferred_reductions):
+    """Mirror of kernels.held_reductions."""
+    jobs = ()
+
+
+def weight_grad_branch(ref, params, thunks, keep, tag="", held=()):
     """Mirror of kernels.weight_grad_branch (the product may run a block's weight-gradient launches on a side stream and
     join later; the mirror runs them in place)."""
     for t in thunks:
@@ -146,6 +151,21 @@ def dw_fwd_hist(x, hist, w, kernel, stride, pad_front, pad_back=None):
     nhist = hist.shape[1]
     return dw_fwd(torch.cat([hist, x], 1), w, kernel, stride, (pad_front[0] - nhist, pad_front[1], pad_front[2]),
                   pad_front if pad_back is None else pad_back)
+
+
+def dw_bwd_fused_ws_bytes(dy, in_thw, kernel, stride, pad_front):
+    """Mirror of kernels.dw_bwd_fused_ws_bytes: which shapes the one-launch depthwise backward takes (bf16, (1,k,k), stride 1,
+    "same" spatial padding, not the 7x7 frames)."""
+    ok = (dy.dtype == torch.bfloat16 and kernel[0] == 1 and kernel[1] == kernel[2] and kernel[1] in (3, 5) and tuple(stride) == (1, 1, 1)
+          and pad_front[1] == kernel[1] // 2 and pad_front[2] == kernel[2] // 2 and dy.shape[4] % 2 == 0 and dy.shape[4] >= 16
+          and tuple(dy.shape[2:4]) == tuple(in_thw[1:]) and dy.shape[1] == in_thw[0] + 2 * pad_front[0] and tuple(in_thw[1:]) != (7, 7))
+    return 4 if ok else 0
+
+
+def dw_bwd_fused(dy, x, w, dw, kernel, stride, pad_front, g_scale=None, g_shift=None):
+    dx = dw_bwd_data(dy, w, tuple(x.shape[1:4]), kernel, stride, pad_front, g_scale, g_shift)
+    dw_bwd_weight(dy, x, dw, kernel, stride, pad_front, g_scale, g_shift)
+    return dx
 
 
 def act_row(shift, act, slope, dtype):

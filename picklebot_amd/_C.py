@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libpicklebot_amd.so")
 
 PB_F32, PB_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY_RELU, ACT_HSWISH, ACT_HSIGMOID, ACT_SILU = range(6)
-ABI_VERSION = 17
+ABI_VERSION = 18
 STAT_SLOTS = 512
 
 
@@ -48,6 +48,7 @@ SIGNATURES = {
     "pb_dwconv3d_bwd_data": [P, P, P, POINTER(DwShape), I, P, P, I, P],
     "pb_dwconv3d_fwd_hist": [P, P, I, P, P, POINTER(DwShape), I, I, P],
     "pb_dwconv3d_bwd_weight": [P, P, P, POINTER(DwShape), I, P, P, P, L, POINTER(ReduceJob), I, P],
+    "pb_dwconv3d_bwd_fused": [P, P, P, P, P, POINTER(DwShape), I, P, P, P, L, POINTER(ReduceJob), I, P],
     "pb_frames_gather": [P, P, I, I, I, L, I, I, I, P, I, I, P],
     "pb_stem_conv3d_fwd": [P, I, F, P, P, P, POINTER(StemShape), I, P, I, I, P],
     "pb_stem_conv3d_bwd_weight": [P, P, I, F, P, P, POINTER(StemShape), I, P, L, I, P],
@@ -99,6 +100,7 @@ SIZE_SIGNATURES = {
     "pb_pwconv_bwd_weight_ws_bytes": [L, I, I, I, I, I, L, I],
     "pb_conv3d_bwd_weight_ws_bytes": [POINTER(ConvShape), I, I],
     "pb_dwconv3d_bwd_weight_ws_bytes": [POINTER(DwShape), I],
+    "pb_dwconv3d_bwd_fused_ws_bytes": [POINTER(DwShape), I],
     "pb_stem_conv3d_bwd_weight_ws_bytes": [POINTER(StemShape), I, F, I],
     "pb_rowgroup_reduce_ws_bytes": [L, L, I, I],
 }

@@ -55,12 +55,23 @@ PB_HIDDEN int pb_dw7_wgrad(const void* dy, const void* x, float* part, const pb_
 
 // rolling-window kernels with lanes along channel pairs (dw_rows.hip)
 PB_HIDDEN bool pb_dw_rows_eligible(const pb_dwconv_shape* s, bool wgrad);
-PB_HIDDEN int pb_dw_rows_pool_slots(const pb_dwconv_shape* s);
+PB_HIDDEN int pb_dw_rows_pool_slots(const pb_dwconv_shape* s, pb_dtype dtype);
 PB_HIDDEN int pb_dw_rows_fwd(const void* src, const float* w, void* dst, const pb_dwconv_shape* s, pb_dtype dtype, int flip,
                              const float* g_scale, const float* g_shift, float* pool, hipStream_t st);
 PB_HIDDEN int64_t pb_dw_rows_wgrad_slots(const pb_dwconv_shape* s, pb_dtype dtype);
 PB_HIDDEN int pb_dw_rows_wgrad(const void* dy, const void* x, float* part, const pb_dwconv_shape* s, pb_dtype dtype,
                                const float* g_scale, const float* g_shift, hipStream_t st, int64_t* slots);
+
+// backward-data + weight gradient in ONE walk over dy (bf16, (1,k,k), stride 1); ..._slots = 0: shape not taken
+PB_HIDDEN int64_t pb_dw_rows_bwd_fused_slots(const pb_dwconv_shape* s, pb_dtype dtype);
+PB_HIDDEN int pb_dw_rows_bwd_fused(const void* dy, const void* x, const float* w, void* dx, float* part, const pb_dwconv_shape* s,
+                                   pb_dtype dtype, const float* g_scale, const float* g_shift, hipStream_t st, int64_t* slots);
+
+// the same walk fed from a wave-private LDS ring filled by LDS-DMA, bf16 (dw_ring.hip); pb_dw_rows_fwd / _pool_slots try it first
+PB_HIDDEN bool pb_dw_ring_eligible(const pb_dwconv_shape* s, pb_dtype dtype);
+PB_HIDDEN int pb_dw_ring_pool_slots(const pb_dwconv_shape* s, pb_dtype dtype);
+PB_HIDDEN int pb_dw_ring_fwd(const void* src, const float* w, void* dst, const pb_dwconv_shape* s, pb_dtype dtype, int flip,
+                             const float* g_scale, const float* g_shift, float* pool, hipStream_t st);
 
 // (kt,3,3) kernels walking along time with a ring of kt output accumulators (dw3.hip)
 PB_HIDDEN bool pb_dw3_eligible(const pb_dwconv_shape* s);

@@ -326,6 +326,234 @@ __global__ __launch_bounds__(256) void dw_rows_wgrad_kernel(RowsWgArgs a) {
   }
 }
 
+// ---- backward-data AND weight gradient in ONE walk over the output gradient (round 4, bf16, stride 1) ---------------
+// A bottleneck's depthwise backward used to be two launches that both read dS = dy (backward-data: dy -> dx; weight gradient:
+// dy, x -> dw).  With the window held over dy, ONE product serves both:
+//     dx[ih][iw]  = sum_{a,b} g[ih-a+P][iw-b+P] * w[a][b]          g = dy * g_scale + g_shift (squeeze-excite prologue), 0 outside
+//     dw[a][b]    = sum_{ih,iw} x[ih][iw] * g[ih-a+P][iw-b+P]
+// i.e. the window element G = g[ih-a+P][iw-b+P] that is multiplied by w[a][b] into dx[ih][iw] is the one that is multiplied
+// by x[ih][iw] into dw[a][b].  A thread owns two channels of a WSEG-wide column segment (as above), walks a band of rows
+// with the k-row window over g, loads one row of x (the segment's own columns: every x element belongs to exactly one
+// segment, so nothing is counted twice) and issues two packed FMAs per (tap, column).  dy is read once instead of twice,
+// one launch and its ramp-up / drain disappears per block.  The weight-gradient epilogue (fixed-order partial slots) and
+// the persistent frame-group walk are dw_rows_wgrad_kernel's.
+struct RowsFusedArgs {
+  const void* x;       // [N, T, H, W, C]  forward input (read: weight gradient)
+  const void* dy;      // [N, To, H, W, C] output gradient, To = T + 2*pt
+  void* dx;            // [N, T, H, W, C]
+  const float* w;      // [C][K*K]
+  float* dw;           // partial gradients [slots][C][K*K]
+  const float* g_scale;
+  const float* g_shift;
+  int N, C, T, H, W, To, pt;
+  int nseg, nbands, band_rows, CP, FG;
+};
+
+template <int K, int WSEG, bool PRO>
+__global__ __launch_bounds__(256) void dw_rows_bwd_fused_kernel(RowsFusedArgs a) {
+  typedef unsigned raw_t;
+  constexpr int P = K / 2;
+  constexpr int IW = WSEG + K - 1;
+  constexpr int KK = K * K;
+  __shared__ float red[4][64 * 2 * KK];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t gu = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int per_frame = a.CP * a.nseg;
+  const int64_t units = (int64_t)a.FG * a.nbands * per_frame;
+  const bool active = gu < units;
+  const int64_t guc = active ? gu : 0;
+  const int fb = (int)(guc / per_frame);
+  const int u = (int)(guc - (int64_t)fb * per_frame);
+  const int sg = u / a.CP, cp = u - sg * a.CP;
+  const int c0 = cp * 2;
+  const int fg = fb / a.nbands, band = fb - fg * a.nbands;
+  const int h0 = band * a.band_rows;
+  const int nrows = min(a.H, h0 + a.band_rows) - h0;
+  const int w0 = sg * WSEG;
+  const int ps = a.C / 2;
+  unsigned cmask = 0;                                        // window columns inside the frame
+  int coloff[IW];
+#pragma unroll
+  for (int j = 0; j < IW; ++j) {
+    const int ws = w0 - P + j;
+    cmask |= (ws >= 0 && ws < a.W) ? (1u << j) : 0u;
+    coloff[j] = min(max(ws, 0), a.W - 1) * ps;
+  }
+  float wt[2 * KK];
+#pragma unroll
+  for (int i = 0; i < 2 * KK; ++i) wt[i] = active ? a.w[(int64_t)c0 * KK + i] : 0.f;
+  f32x2 acc[KK];
+#pragma unroll
+  for (int i = 0; i < KK; ++i) acc[i] = f32x2{0.f, 0.f};
+  const int hs_base = h0 - P;
+  const int nframes = a.N * a.T;
+  if (active && nrows > 0) {
+    for (int z = fg; z < nframes; z += a.FG) {
+      const int n = z / a.T, ts = z - n * a.T;
+      const int td = ts + a.pt;                              // (temporal stride 1: every input frame meets one output frame)
+      const raw_t* gy = (const raw_t*)a.dy + ((((int64_t)n * a.To + td) * a.H) * a.W * a.C + c0) / 2;
+      const raw_t* xs = (const raw_t*)a.x + (((int64_t)z * a.H + h0) * a.W * a.C + c0) / 2 + (int64_t)w0 * ps;
+      raw_t* dxp = (raw_t*)a.dx + (((int64_t)z * a.H + h0) * a.W * a.C + c0) / 2 + (int64_t)w0 * ps;
+      f32x2 gs = {1.f, 1.f}, gh = {0.f, 0.f};
+      if (PRO) {
+        if (a.g_scale) gs = *reinterpret_cast<const f32x2*>(a.g_scale + (int64_t)n * a.C + c0);
+        if (a.g_shift) gh = *reinterpret_cast<const f32x2*>(a.g_shift + (int64_t)n * a.C + c0);
+      }
+      f32x2 win[K][IW];
+      raw_t raw[IW], xraw[WSEG];
+      auto load_row = [&](int hs, raw_t (&r)[IW]) {
+        const raw_t* base = gy + (int64_t)min(max(hs, 0), a.H - 1) * a.W * ps;
+#pragma unroll
+        for (int j = 0; j < IW; ++j) r[j] = base[coloff[j]];
+      };
+      auto insert_row = [&](int hs, const raw_t (&r)[IW], f32x2 (&slot)[IW]) {
+        const bool rowok = hs >= 0 && hs < a.H;
+#pragma unroll
+        for (int j = 0; j < IW; ++j) {
+          const f32x2 v = PRO ? Pair<bf16_t>::up(r[j]) * gs + gh : Pair<bf16_t>::up(r[j]);
+          slot[j] = (rowok && ((cmask >> j) & 1u)) ? v : f32x2{0.f, 0.f};
+        }
+      };
+      auto load_x = [&](int t) {
+        const raw_t* base = xs + (int64_t)t * a.W * ps;
+#pragma unroll
+        for (int j = 0; j < WSEG; ++j) xraw[j] = base[(int64_t)min(j, a.W - 1 - w0) * ps];
+      };
+      {
+        raw_t r0[K][IW];
+#pragma unroll
+        for (int kh = 0; kh < K; ++kh) load_row(hs_base + kh, r0[kh]);
+        load_x(0);
+#pragma unroll
+        for (int kh = 0; kh < K; ++kh) insert_row(hs_base + kh, r0[kh], win[kh % K]);
+      }
+      if (nrows > 1) load_row(hs_base + K, raw);
+      for (int tk = 0; tk < nrows; tk += K) {
+#pragma unroll
+        for (int r = 0; r < K; ++r) {
+          const int t = tk + r;
+          if (t < nrows) {
+            f32x2 xv[WSEG];
+#pragma unroll
+            for (int j = 0; j < WSEG; ++j) xv[j] = (w0 + j < a.W) ? Pair<bf16_t>::up(xraw[j]) : f32x2{0.f, 0.f};
+            if (t > 0) insert_row(hs_base + t + K - 1, raw, win[(r + K - 1) % K]);
+            if (t + 1 < nrows) {
+              load_row(hs_base + t + K, raw);
+              load_x(t + 1);
+            }
+            f32x2 dxa[WSEG];
+#pragma unroll
+            for (int j = 0; j < WSEG; ++j) dxa[j] = f32x2{0.f, 0.f};
+#pragma unroll
+            for (int kh = 0; kh < K; ++kh)
+#pragma unroll
+              for (int kw = 0; kw < K; ++kw) {
+                const int tap = (K - 1 - kh) * K + (K - 1 - kw);          // w[a][b] with a = K-1-kh, b = K-1-kw
+                const f32x2 w2 = f32x2{wt[tap], wt[KK + tap]};
+#pragma unroll
+                for (int j = 0; j < WSEG; ++j) {
+                  const f32x2 G = win[(r + kh) % K][j + kw];
+                  pk_fma_keep(dxa[j], G, w2);
+                  acc[tap] += xv[j] * G;
+                }
+              }
+            raw_t* orow = dxp + (int64_t)t * a.W * ps;
+#pragma unroll
+            for (int j = 0; j < WSEG; ++j)
+              if (w0 + j < a.W) orow[(int64_t)j * ps] = Pair<bf16_t>::down(dxa[j]);
+          }
+        }
+      }
+    }
+  }
+  const int nall = 2 * a.CP * KK;
+  if (a.CP <= 256) {      // narrow layers: fixed-order reduction in LDS, one contiguous partial per workgroup (as dw_rows_wgrad_kernel)
+    float* ra = &red[0][0];
+    for (int i = threadIdx.x; i < nall; i += 256) ra[i] = 0.f;
+    __syncthreads();
+    const int rounds = (256 + a.CP - 1) / a.CP;
+    const int my_round = threadIdx.x / a.CP;
+    for (int r = 0; r < rounds; ++r) {
+      if (r == my_round && active && nrows > 0) {
+#pragma unroll
+        for (int i = 0; i < KK; ++i) {
+          ra[c0 * KK + i] += acc[i][0];
+          ra[(c0 + 1) * KK + i] += acc[i][1];
+        }
+      }
+      __syncthreads();
+    }
+    float* part = a.dw + (int64_t)blockIdx.x * 2 * a.CP * KK;
+    for (int i = threadIdx.x; i < nall; i += 256) part[i] = ra[i];
+    return;
+  }
+  float* rw = red[wave];
+#pragma unroll
+  for (int i = 0; i < KK; ++i) {
+    rw[lane * 2 * KK + i] = acc[i][0];
+    rw[lane * 2 * KK + KK + i] = acc[i][1];
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  const int64_t gu0 = gu - lane;
+#pragma unroll
+  for (int k = 0; k < 2 * KK; ++k) {
+    const int e = lane + 64 * k;
+    const int l2 = e / (2 * KK), off = e - l2 * (2 * KK);
+    const int64_t g2 = gu0 + l2;
+    if (g2 < units) {
+      const int fb2 = (int)(g2 / per_frame);
+      const int u2 = (int)(g2 - (int64_t)fb2 * per_frame);
+      const int sg2 = u2 / a.CP, cp2 = u2 - sg2 * a.CP;
+      const int ch2 = off >= KK;
+      a.dw[(((int64_t)fb2 * a.nseg + sg2) * 2 * a.CP + cp2 * 2 + ch2) * KK + (off - ch2 * KK)] = rw[e];
+    }
+  }
+}
+
+constexpr int fused_wseg(int K) { return K == 3 ? 7 : 2; }      // (k5 at 4 columns: 256 VGPRs + 48 AGPRs, one wave per SIMD)
+
+bool fused_ok(const pb_dwconv_shape* s, pb_dtype dtype) {
+  static const bool enabled = !(getenv("PB_DW_FUSED_BWD") && atoi(getenv("PB_DW_FUSED_BWD")) == 0);
+  return enabled && dtype == PB_BF16 && s->kt == 1 && s->kh == s->kw && (s->kh == 3 || s->kh == 5) && s->st == 1 && s->sh == 1 &&
+         s->sw == 1 && s->ph == s->kh / 2 && s->pw == s->kw / 2 && s->C % 2 == 0 && s->C >= 16 && s->Ho == s->Hi && s->Wo == s->Wi &&
+         s->To == s->Ti + 2 * s->pt && (int64_t)s->Wi * s->C < (1 << 24) && !(s->Hi == 7 && s->Wi == 7);
+}
+
+int64_t fused_geom(RowsFusedArgs& a, int K, int64_t* slots) {
+  const int WSEG = fused_wseg(K);
+  a.CP = a.C / 2;
+  a.nseg = (int)pb_cdiv(a.W, WSEG);
+  const int64_t per_frame = (int64_t)a.CP * a.nseg;
+  const int64_t frames = (int64_t)a.N * a.T;
+  static const int want = getenv("PB_DW_FUSED_THREADS") ? atoi(getenv("PB_DW_FUSED_THREADS")) : 128 * 1024;
+  int nbands = 1;
+  const int max_bands = (int)pb_cdiv(a.H, 2 * K);
+  int64_t fgroups = pb_cdiv(want, per_frame);
+  if (fgroups > frames) {
+    nbands = (int)pb_cdiv(fgroups, frames);
+    if (nbands > max_bands) nbands = max_bands;
+    fgroups = frames;
+  }
+  if (a.CP > 256) {                 // one partial gradient per (frame group, band, segment): at most 512 of them (12 MB at C = 672)
+    const int64_t writer_cap = pb_cdiv(512, (int64_t)a.nseg * nbands);
+    if (fgroups > writer_cap) fgroups = writer_cap;
+  }
+  if (fgroups < 1) fgroups = 1;
+  a.band_rows = (int)pb_cdiv(pb_cdiv(a.H, nbands), K) * K;
+  a.nbands = (int)pb_cdiv(a.H, a.band_rows);
+  a.FG = (int)fgroups;
+  const int64_t blocks = pb_cdiv(fgroups * a.nbands * per_frame, 256);
+  *slots = a.CP <= 256 ? blocks : fgroups * a.nbands * a.nseg;
+  return blocks;
+}
+
+RowsFusedArgs fused_args(const pb_dwconv_shape* s) {
+  RowsFusedArgs a = {};
+  a.N = s->N; a.C = s->C; a.T = s->Ti; a.H = s->Hi; a.W = s->Wi; a.To = s->To; a.pt = s->pt;
+  return a;
+}
+
 // (K, S) -> segment width: the fp32 window K x ((WSEG-1)*S + K) x 2 must stay near 100 registers
 constexpr int wseg_of(int K, int S) { return K == 3 ? (S == 1 ? 14 : 7) : (S == 1 ? 7 : 4); }
 // half-width segments: about half the window registers (twice the waves per SIMD) for 13-50 % more halo loads
@@ -499,7 +727,8 @@ int pb_dw_rows_wgrad(const void* dy, const void* x, float* part, const pb_dwconv
   return 0;
 }
 
-int pb_dw_rows_pool_slots(const pb_dwconv_shape* s) {
+int pb_dw_rows_pool_slots(const pb_dwconv_shape* s, pb_dtype dtype) {
+  if (const int n = pb_dw_ring_pool_slots(s, dtype)) return n;
   RowsArgs a = {};
   a.N = s->N; a.C = s->C; a.Tdst = s->To; a.Hd = s->Ho; a.Wd = s->Wo;
   const int K = s->kh, S = s->sh;
@@ -510,6 +739,10 @@ int pb_dw_rows_pool_slots(const pb_dwconv_shape* s) {
 int pb_dw_rows_fwd(const void* src, const float* w, void* dst, const pb_dwconv_shape* s, pb_dtype dtype, int flip,
                    const float* g_scale, const float* g_shift, float* pool, hipStream_t st) {
   if (!rows_ok(s)) return -1;
+  {
+    const int rc = pb_dw_ring_fwd(src, w, dst, s, dtype, flip, g_scale, g_shift, pool, st);      // bf16: the LDS-ring form
+    if (rc >= 0) return rc;
+  }
   PB_CHECK_ARG((int64_t)s->N * s->To * s->Ho * s->Wo * s->C < (1LL << 40), "dw_rows: tensor too large");
   RowsArgs a = {};
   a.src = src; a.dst = dst; a.w = w; a.g_scale = g_scale; a.g_shift = g_shift; a.pool = pool;
@@ -526,4 +759,32 @@ int pb_dw_rows_fwd(const void* src, const float* w, void* dst, const pb_dwconv_s
   if (dtype == PB_BF16) PB_ROWS(bf16_t);
   PB_ROWS(float);
 #undef PB_ROWS
+}
+
+// backward-data + weight gradient in one launch (bf16, (1,k,k), stride 1): 0 slots = shape not taken
+int64_t pb_dw_rows_bwd_fused_slots(const pb_dwconv_shape* s, pb_dtype dtype) {
+  if (!fused_ok(s, dtype)) return 0;
+  RowsFusedArgs a = fused_args(s);
+  int64_t slots = 0;
+  fused_geom(a, s->kh, &slots);
+  return slots;
+}
+
+int pb_dw_rows_bwd_fused(const void* dy, const void* x, const float* w, void* dx, float* part, const pb_dwconv_shape* s,
+                         pb_dtype dtype, const float* g_scale, const float* g_shift, hipStream_t st, int64_t* slots) {
+  if (!fused_ok(s, dtype)) return -1;
+  RowsFusedArgs a = fused_args(s);
+  a.x = x; a.dy = dy; a.dx = dx; a.w = w; a.dw = part; a.g_scale = g_scale; a.g_shift = g_shift;
+  const int64_t blocks = fused_geom(a, s->kh, slots);
+  const bool pro = g_scale || g_shift;
+  const dim3 grid((unsigned)blocks);
+  if (s->kh == 3) {
+    if (pro) hipLaunchKernelGGL((dw_rows_bwd_fused_kernel<3, fused_wseg(3), true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((dw_rows_bwd_fused_kernel<3, fused_wseg(3), false>), grid, dim3(256), 0, st, a);
+  } else {
+    if (pro) hipLaunchKernelGGL((dw_rows_bwd_fused_kernel<5, fused_wseg(5), true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((dw_rows_bwd_fused_kernel<5, fused_wseg(5), false>), grid, dim3(256), 0, st, a);
+  }
+  if (hipGetLastError() != hipSuccess) { pb_set_error("dw_rows fused backward launch failed"); return 1; }
+  return 0;
 }

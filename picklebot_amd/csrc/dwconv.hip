@@ -846,7 +846,7 @@ extern "C" const char* pb_dwconv3d_kernel_name(const pb_dwconv_shape* s, pb_dtyp
   if (which == 0) {
     if (pb_dw3_eligible(s)) return "dw3_fwd_kernel";
     if (pb_dw7_eligible(s)) return "dw7_fwd_kernel";
-    if (pb_dw_rows_eligible(s, false)) return "dw_rows_fwd_kernel";
+    if (pb_dw_rows_eligible(s, false)) return pb_dw_ring_eligible(s, dtype) ? "dw_ring_fwd_kernel" : "dw_rows_fwd_kernel";
     if (pb_dw_tile_eligible(s, dtype, false)) return "dw_tile_fwd_kernel";
     return strip_ok(*s) ? "dw_strip_fwd_kernel" : "dw_gen_fwd_kernel";
   }
@@ -855,7 +855,7 @@ extern "C" const char* pb_dwconv3d_kernel_name(const pb_dwconv_shape* s, pb_dtyp
     if (bwd_is_s1_corr(*s)) {
       const pb_dwconv_shape c = bwd_corr_shape(*s);
       if (pb_dw7_eligible(&c)) return "dw7_fwd_kernel";
-      if (pb_dw_rows_eligible(&c, false)) return "dw_rows_fwd_kernel";
+      if (pb_dw_rows_eligible(&c, false)) return pb_dw_ring_eligible(&c, dtype) ? "dw_ring_fwd_kernel" : "dw_rows_fwd_kernel";
       return pb_dw_tile_eligible(&c, dtype, false) ? "dw_tile_fwd_kernel" : "dw_strip_fwd_kernel";
     }
     if ((strip_ok(*s) && s->sh == 2 && s->ph == s->kh / 2) || bwd_is_kt_s2(*s)) return "dw_strip_bwd_s2_kernel";
@@ -897,7 +897,7 @@ extern "C" int pb_dwconv3d_pool_slots(const pb_dwconv_shape* s, pb_dtype dtype) 
   if (!s || s->N <= 0 || s->C <= 0) return 0;
   if (pb_dw3_eligible(s)) return pb_dw3_pool_slots(s);
   if (pb_dw7_eligible(s)) return s->To;
-  if (pb_dw_rows_eligible(s, false)) return pb_dw_rows_pool_slots(s);
+  if (pb_dw_rows_eligible(s, false)) return pb_dw_rows_pool_slots(s, dtype);
   if (strip_ok(*s)) {      // (the tile kernel has no fused pooling: pooled forwards skip it)
     StripArgs a = strip_fwd_args(nullptr, nullptr, nullptr, s, nullptr);
     return (int)(s->To * strip_fwd_geom(a, strip_ch(dtype == PB_BF16, s->kh, s->C)));
@@ -1159,5 +1159,33 @@ extern "C" int pb_dwconv3d_bwd_weight(const void* dy, const void* x, float* dw, 
   const pb_reduce_job job = {part, dw, n, n, (int)slots, 1};
   if (deferred) { *deferred = job; return 0; }
   if (pb_launch_partials_reduce(&job, 1, st)) { pb_set_error("pb_dwconv3d_bwd_weight: combine launch failed"); return 2; }
+  return 0;
+}
+
+// Backward-data AND weight gradient of a (1,k,k) stride-1 "same" depthwise conv in one launch (bf16): dy is read once.
+// pb_dwconv3d_bwd_fused_ws_bytes = 0: the shape is not taken - call pb_dwconv3d_bwd_data and pb_dwconv3d_bwd_weight.
+extern "C" int64_t pb_dwconv3d_bwd_fused_ws_bytes(const pb_dwconv_shape* s, pb_dtype dtype) {
+  if (!s || s->N <= 0 || s->C <= 0 || s->kt <= 0 || s->kh <= 0 || s->kw <= 0) return 0;
+  return pb_dw_rows_bwd_fused_slots(s, dtype) * s->C * s->kt * s->kh * s->kw * 4;
+}
+
+extern "C" int pb_dwconv3d_bwd_fused(const void* dy, const void* x, const float* w, void* dx, float* dw, const pb_dwconv_shape* s,
+                                     pb_dtype dtype, const float* g_scale, const float* g_shift, void* ws, int64_t ws_bytes,
+                                     pb_reduce_job* deferred, int device, void* stream) {
+  PB_CHECK_ARG(dy && x && w && dx && dw && ws, "pb_dwconv3d_bwd_fused: null pointer");
+  if (int rc = check_shape(s, "pb_dwconv3d_bwd_fused")) return rc;
+  const int64_t need = pb_dwconv3d_bwd_fused_ws_bytes(s, dtype);
+  PB_CHECK_ARG(need > 0, "pb_dwconv3d_bwd_fused: shape / dtype not taken by the fused kernel (ws_bytes query returns 0)");
+  PB_CHECK_ARG(((uintptr_t)ws % 16) == 0 && ws_bytes >= need, "pb_dwconv3d_bwd_fused: workspace too small or unaligned (%lld bytes needed)", (long long)need);
+  PB_ENTER(device);
+  hipStream_t st = (hipStream_t)stream;
+  int64_t slots = 0;
+  const int rc = pb_dw_rows_bwd_fused(dy, x, w, dx, (float*)ws, s, dtype, g_scale, g_shift, st, &slots);
+  if (rc) { if (rc < 0) pb_set_error("pb_dwconv3d_bwd_fused: shape not taken"); return rc < 0 ? 3 : rc; }
+  PB_LAUNCH_CHECK();
+  const int64_t n = (int64_t)s->C * s->kt * s->kh * s->kw;
+  const pb_reduce_job job = {(float*)ws, dw, n, n, (int)slots, 1};
+  if (deferred) { *deferred = job; return 0; }
+  if (pb_launch_partials_reduce(&job, 1, st)) { pb_set_error("pb_dwconv3d_bwd_fused: combine launch failed"); return 2; }
   return 0;
 }

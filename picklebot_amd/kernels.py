@@ -262,20 +262,21 @@ def _adopting(p, region):
 _WGRAD_TAGS = set(filter(None, os.environ.get("PB_WGRAD_TAGS", "").split(",")))     # debugging: only these block kinds defer
 
 
-def _run_inline(thunks):
+def _run_inline(thunks, held=()):
     branch_counts["inline"] += 1
-    with deferred_reductions():
+    with deferred_reductions(held):
         for t in thunks:
             t()
 
 
-def weight_grad_branch(ref, params, thunks, keep, tag=""):
+def weight_grad_branch(ref, params, thunks, keep, tag="", held=()):
     """Run `thunks` (the weight-gradient launches of one block; their partial-tile reductions are issued as one launch at
-    the end) - on the side stream without joining when that is safe (see above), in line otherwise."""
+    the end) - on the side stream without joining when that is safe (see above), in line otherwise.  held: reduction jobs
+    of kernels the CHAIN already launched (held_reductions) - they join the same single reduction launch."""
     region = weight_grad_overlap._depth > 0          # (process-wide: backward runs on autograd's device thread)
     defer = _WGRAD_OVERLAP and ref.is_cuda and all(_adopting(p, region) for p in params) and (not _WGRAD_TAGS or tag in _WGRAD_TAGS)
     if not defer:
-        return _run_inline(thunks)
+        return _run_inline(thunks, held)
     task = torch._C._current_graph_task_id()
     seen = _seen.setdefault(task, set())
     ids = [id(p) for p in params if p is not None]
@@ -283,7 +284,7 @@ def weight_grad_branch(ref, params, thunks, keep, tag=""):
         # second gradient for a parameter in this pass: autograd's input buffer is about to ADD it to the first one on the
         # calling stream - order that stream behind the branch that is still writing the first
         join_weight_grads()
-        return _run_inline(thunks)
+        return _run_inline(thunks, held)
     idx = ref.device.index if ref.device.index is not None else torch.cuda.current_device()
     main, side = torch.cuda.current_stream(idx), _side_stream(idx)
     try:
@@ -292,7 +293,7 @@ def weight_grad_branch(ref, params, thunks, keep, tag=""):
         # from it
         torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward)
     except RuntimeError:                  # not inside a backward pass of the engine: nobody would join
-        return _run_inline(thunks)
+        return _run_inline(thunks, held)
     seen.update(ids)
     prev = _lag.pop(idx, None)
     if prev is not None:
@@ -301,12 +302,12 @@ def weight_grad_branch(ref, params, thunks, keep, tag=""):
     ev.record(main)
     side.wait_event(ev)
     with torch.cuda.stream(side):
-        with deferred_reductions():
+        with deferred_reductions(held):
             for t in thunks:
                 t()
     done = torch.cuda.Event()
     done.record(side)
-    _lag[idx] = (done, keep)
+    _lag[idx] = (done, (keep, held))      # (held: the chain's workspaces the branch's reduction reads)
     branch_counts["side"] += 1
 
 
@@ -329,9 +330,12 @@ _deferred = threading.local()
 
 
 class deferred_reductions:
+    def __init__(self, held=()):
+        self.held = list(held)
+
     def __enter__(self):
         self.prev = getattr(_deferred, "jobs", None)
-        _deferred.jobs = []
+        _deferred.jobs = list(self.held)
         return self
 
     def __exit__(self, *exc):
@@ -343,6 +347,16 @@ class deferred_reductions:
             idx = dev.index if dev.index is not None else torch.cuda.current_device()
             st = ctypes.c_void_p(torch.cuda.current_stream(idx).cuda_stream)
             _launch("partials_reduce", sum(f[2] * 4 * (f[4] + 1) for f in flush), "pb_partials_reduce", arr, len(jobs), idx, st)
+        return False
+
+
+class held_reductions(deferred_reductions):
+    """Like deferred_reductions, but nothing is launched at exit: the collected jobs (`.jobs`, with the workspaces they
+    keep alive) are handed to a later weight_grad_branch(..., held=jobs), whose single reduction launch adds them up -
+    for a kernel of the data-gradient CHAIN that also leaves weight-gradient partials (dw_bwd_fused)."""
+
+    def __exit__(self, *exc):
+        self.jobs, _deferred.jobs = _deferred.jobs, self.prev
         return False
 
 
@@ -777,6 +791,39 @@ def dw_bwd_weight(dy, x, dw, kernel, stride, pad_front, g_scale=None, g_shift=No
             _p(ws), ws.numel() * 4, jref, dev, st, detail=f"C{C} {tuple(x.shape[1:4])}->{To}x{Ho}x{Wo} k{kernel} s{stride}")
     _keep_job(job, ws, dw)
     return dw
+
+
+def dw_bwd_fused_ws_bytes(dy, in_thw, kernel, stride, pad_front):
+    """Workspace of the one-launch depthwise backward for this shape; 0 = not taken (use dw_bwd_data + dw_bwd_weight)."""
+    if not dy.is_cuda or dy.dim() != 5:
+        return 0
+    N, To, Ho, Wo, C = dy.shape
+    s = _dw_shape(N, C, tuple(in_thw), (To, Ho, Wo), kernel, stride, pad_front)
+    return int(_C.load().pb_dwconv3d_bwd_fused_ws_bytes(ctypes.byref(s), _dt(dy)))
+
+
+def dw_bwd_fused(dy, x, w, dw, kernel, stride, pad_front, g_scale=None, g_shift=None):
+    """-> dx; dw[C, taps] += weight gradient.  Both gradients of a (1,k,k) stride-1 depthwise conv in ONE walk over dy
+    (g = dy * g_scale + g_shift read once): pb_dwconv3d_bwd_fused.  Check dw_bwd_fused_ws_bytes(...) > 0 first."""
+    _ndhwc(dy, "dy"); _ndhwc(x, "x")
+    N, To, Ho, Wo, C = dy.shape
+    if x.shape[0] != N or x.shape[4] != C or x.dtype != dy.dtype:
+        raise ValueError("dw_bwd_fused: dy/x mismatch")
+    taps = kernel[0] * kernel[1] * kernel[2]
+    _f32(w, (C, taps), "w"); _f32(dw, (C, taps), "dw")
+    _f32(g_scale, (N, C), "g_scale"); _f32(g_shift, (N, C), "g_shift")
+    s = _dw_shape(N, C, tuple(x.shape[1:4]), (To, Ho, Wo), kernel, stride, pad_front)
+    nws = int(_C.load().pb_dwconv3d_bwd_fused_ws_bytes(ctypes.byref(s), _dt(dy)))
+    if nws <= 0:
+        raise ValueError(f"dw_bwd_fused: shape {tuple(dy.shape)} k{kernel} s{stride} {dy.dtype} is not taken by the fused kernel")
+    dx = torch.empty_like(x)
+    ws = _scratch(nws, dy.device)
+    dev, st = _dev_stream(dy)
+    job, jref = _defer_job()
+    _launch("dw_rows_bwd_fused_kernel", _nb(dy, x, dx, dw), "pb_dwconv3d_bwd_fused", _p(dy), _p(x), _p(w), _p(dx), _p(dw), ctypes.byref(s), _dt(dy),
+            _p(g_scale), _p(g_shift), _p(ws), ws.numel() * 4, jref, dev, st, detail=f"C{C} {tuple(x.shape[1:4])}<->{To}x{Ho}x{Wo} k{kernel} s{stride}")
+    _keep_job(job, ws, dw)
+    return dx
 
 
 # ------------------------------------------------------------------------------ frame gather / scatter

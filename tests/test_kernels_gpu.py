@@ -3,6 +3,8 @@ same seeded inputs.  Tolerances: fp32 1e-4 relative per tensor (accumulation ord
 bf16 1e-2 (outputs rounded to bf16).  Edge cases: ragged M, channel counts that are
 not multiples of the vector/MFMA tile, N=13 class heads, zero frames of the temporal growth quirk,
 stride 2, k=5, prologue/epilogue combinations, broadcast gradients."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -227,6 +229,85 @@ def test_dwconv_fwd_bwd(K, N, C, thw, kernel, stride, pad, dtype):
         dw_ref = R.dw_bwd_weight(dy, x, torch.zeros(C, taps), kernel, stride, pad, a, b)
         dw = K.dw_bwd_weight(dev(dy), dev(x), torch.zeros(C, taps, device=DEV), kernel, stride, pad, dev(a), dev(b))
         check("dw_bwd_weight", dw, dw_ref, dtype)
+
+
+RING_CASES = [  # N, C, (T,H,W), k, s : bf16 shapes the LDS-ring depthwise kernel (csrc/dw_ring.hip) takes by default
+    (2, 16, (2, 30, 45), 3, 1),      # 8 segments per wave (2 chunks), ragged last segment (right-aligned), narrow segments
+    (1, 72, (3, 33, 29), 3, 2),      # 9 chunks: uneven channel slices, stride 2
+    (2, 64, (2, 41, 57), 3, 2),      # 29 output columns
+    (1, 120, (2, 30, 30), 5, 2),     # k5: 15 chunks, ring depth >= K
+    (1, 72, (2, 37, 37), 5, 2),      # 19 output columns: 5 segments of 4
+    (1, 184, (3, 29, 29), 3, 2),     # 23 chunks: three slices
+    (1, 672, (2, 14, 14), 5, 2),     # MobileNetLarge3D's 14 -> 7 layer: 84 chunks
+    (3, 24, (1, 100, 19), 3, 1),     # long frames: many row steps (prologue, steady state, tail), row bands
+    (1, 240, (2, 28, 28), 3, 2),
+    (2, 32, (2, 9, 16), 5, 1),       # fewer window rows than the steady state needs (tail from the start); k5 backward-data
+    (2, 24, (2, 20, 33), 5, 1),
+]
+
+
+@pytest.mark.parametrize("N,C,thw,k,s", RING_CASES)
+def test_dwconv_lds_ring_forward_and_backward_data(K, N, C, thw, k, s):
+    """csrc/dw_ring.hip (bf16): forward with the squeeze-excite pool sums, and backward-data (flipped taps, with and without
+    the (g_scale, g_shift) prologue) for stride 1, against the CPU mirror, on shapes that exercise several segments per wave,
+    right-aligned ragged segments, uneven channel slices, row bands, and rings longer / shorter than the band."""
+    from picklebot_amd import _C
+    import ctypes
+    dtype = torch.bfloat16
+    kernel, stride, pad = (1, k, k), (1, s, s), (0, k // 2, k // 2)
+    x = rnd((N, *thw, C), dtype, 21)
+    w = rnd((C, k * k), seed=22, scale=1.0 / k)
+    pool_ref = torch.zeros(N, C)
+    y_ref = R.dw_fwd(x, w, kernel, stride, pad, pool=pool_ref)
+    sh = K._dw_shape(N, C, thw, tuple(y_ref.shape[1:4]), kernel, stride, pad)
+    assert _C.load().pb_dwconv3d_kernel_name(ctypes.byref(sh), _C.PB_BF16, 0) == b"dw_ring_fwd_kernel"
+    pool = torch.zeros(N, C, device=DEV)
+    y = K.dw_fwd(dev(x), dev(w), kernel, stride, pad, pool=pool)
+    check("ring_fwd", y, y_ref, dtype)
+    check("ring_pool", pool, pool_ref, dtype)
+    if s == 1:
+        dy = rnd(tuple(y_ref.shape), dtype, 23)
+        gs, gh = torch.rand(N, C) + 0.5, rnd((N, C), seed=24) * 0.1
+        for a, b in ((None, None), (gs, gh)):
+            dx_ref = R.dw_bwd_data(dy, w, thw, kernel, stride, pad, a, b)
+            dx = K.dw_bwd_data(dev(dy), dev(w), thw, kernel, stride, pad, dev(a), dev(b))
+            check("ring_bwd_data", dx, dx_ref, dtype)
+
+
+FUSED_CASES = [  # N, C, (T,H,W), k, pt
+    (2, 16, (2, 30, 45), 3, 0), (1, 72, (3, 33, 29), 3, 0), (2, 120, (2, 28, 28), 5, 0), (1, 184, (3, 14, 14), 3, 0),
+    (1, 672, (2, 14, 14), 3, 0), (3, 24, (1, 100, 19), 3, 0), (2, 40, (2, 9, 16), 5, 2), (1, 600, (3, 10, 11), 5, 0),
+    (2, 64, (3, 17, 17), 3, 1),
+]
+
+
+@pytest.mark.parametrize("N,C,thw,k,pt", FUSED_CASES)
+def test_dwconv_fused_backward(K, N, C, thw, k, pt):
+    """pb_dwconv3d_bwd_fused (bf16, stride 1): data gradient and weight gradient from ONE walk over dy, with and without the
+    squeeze-excite prologue g = dy * g_scale + g_shift, against the two mirrors - and against the two separate HIP
+    kernels it replaces (the data gradient bit for bit: same taps in the same order)."""
+    dtype = torch.bfloat16
+    kernel, stride, pad = (1, k, k), (1, 1, 1), (pt, k // 2, k // 2)
+    x = rnd((N, *thw, C), dtype, 31)
+    w = rnd((C, k * k), seed=32, scale=1.0 / k)
+    dy = rnd((N, thw[0] + 2 * pt, thw[1], thw[2], C), dtype, 33)
+    assert K.dw_bwd_fused_ws_bytes(dev(dy), thw, kernel, stride, pad) > 0
+    assert R.dw_bwd_fused_ws_bytes(dy, thw, kernel, stride, pad) > 0
+    gs, gh = torch.rand(N, C) + 0.5, rnd((N, C), seed=34) * 0.1
+    for a, b in ((None, None), (gs, gh)):
+        dx_ref = R.dw_bwd_data(dy, w, thw, kernel, stride, pad, a, b)
+        dw_ref = R.dw_bwd_weight(dy, x, torch.zeros(C, k * k), kernel, stride, pad, a, b)
+        dw = torch.zeros(C, k * k, device=DEV)
+        dx = K.dw_bwd_fused(dev(dy), dev(x), dev(w), dw, kernel, stride, pad, dev(a), dev(b))
+        check("fused_dx", dx, dx_ref, dtype)
+        check("fused_dw", dw, dw_ref, dtype)
+        dx2 = K.dw_bwd_data(dev(dy), dev(w), thw, kernel, stride, pad, dev(a), dev(b))
+        assert torch.equal(dx, dx2)
+        dw2 = K.dw_bwd_weight(dev(dy), dev(x), torch.zeros(C, k * k, device=DEV), kernel, stride, pad, dev(a), dev(b))
+        check("fused_dw_vs_separate", dw, dw2.cpu(), torch.float32, 5.0)
+    # shapes the fused kernel leaves to the two-kernel path
+    assert K.dw_bwd_fused_ws_bytes(dev(dy).float(), thw, kernel, stride, pad) == 0
+    assert K.dw_bwd_fused_ws_bytes(dev(dy), thw, kernel, (1, 2, 2), pad) == 0
 
 
 def test_dwconv_temporal_growth_zero_frames(K):
