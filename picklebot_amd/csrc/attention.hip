@@ -231,6 +231,21 @@ __device__ __forceinline__ bf16x8 load_scaled_hilo(const bf16_t* row, int g, flo
   return v;
 }
 
+// 16 bytes global -> LDS without registers (lane i lands at lds_dst + 16 i); ordered by the issuing wave's vmcnt
+__device__ __forceinline__ void attn_glds16(const void* gsrc, unsigned char* lds_dst) {
+  typedef __attribute__((address_space(3))) unsigned char* lds_b;
+  const unsigned dst = (unsigned)(uintptr_t)(lds_b)lds_dst;
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
+
+// Round 4: K AND V are staged ROW-MAJOR ([npad][16], the layout they have in memory) by LDS-DMA - no registers, no
+// transposing 2-byte LDS writes, every chunk of the slice in flight at once (staging was a third of the kernel:
+// profiles/r04_attention_ablation.txt).  The V^T operand of O^T += V^T P^T comes from the hardware transposing read:
+// within a 16-lane group, lane 4q+p supplies the address of row q (key 4g+q of the tile), columns 4p..4p+3, and lane i
+// receives column i = V[4g..4g+3][d = i] - exactly the four k-slots (g, 0..3) the lane needs.  Rows >= n repeat row n-1
+// (their scores carry -1e30: p = 0 against finite values).
 __global__ __launch_bounds__(1024) void attn_fwd_onepass_bf16_kernel(AttnArgs a) {
   typedef bf16_t T;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -240,16 +255,45 @@ __global__ __launch_bounds__(1024) void attn_fwd_onepass_bf16_kernel(AttnArgs a)
   const T* base = (const T*)a.qkv + (int64_t)grp * n * QKV_LD + h * HD;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, g = lane >> 4;
-  // LDS: K [npad][16] | V^T [16][npad + 8]
-  const int ldt = npad + 8;
+  // LDS: K [npad][16] | V [npad][16]
   T* Ks = (T*)smem;
   T* Vs = Ks + npad * HD;
-  stage_head<T>(base + NH * HD, QKV_LD, n, npad, Ks, nullptr, 0);
-  stage_head<T>(base + 2 * NH * HD, QKV_LD, n, npad, nullptr, Vs, ldt);
+  {
+    const int nchunks = 2 * npad;                               // 16-byte chunks of one slice
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    for (int c0 = wave_u * 64; c0 < 2 * nchunks; c0 += nwv * 64) {    // K chunks, then V chunks (nchunks is a multiple of 64)
+      const bool isv = c0 >= nchunks;
+      const int i = c0 - (isv ? nchunks : 0) + lane;
+      const int r = min(i >> 1, n - 1), c = i & 1;
+      attn_glds16(base + (isv ? 2 : 1) * NH * HD + (int64_t)r * QKV_LD + c * 8, smem + (size_t)c0 * 16);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
   __syncthreads();
   const int npairs = npad >> 5;
   const float sl0 = a.scale * 1.44269504088896340736f;
+  // max_k |k|^2 of the head (one row per thread, wave maximum, then the waves' maxima through LDS): with |q| it bounds
+  // every score of a query tile (Cauchy-Schwarz) - used ONLY to decide whether the running maximum has to be tracked
+  float* kn = (float*)(smem + (size_t)2 * npad * HD * sizeof(T));
+  {
+    float k2 = 0.f;
+    for (int r = threadIdx.x; r < n; r += blockDim.x) {
+      const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(Ks + r * HD), k1 = *reinterpret_cast<const bf16x8*>(Ks + r * HD + 8);
+      float t = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) t += (float)k0[e] * (float)k0[e] + (float)k1[e] * (float)k1[e];
+      k2 = fmaxf(k2, t);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) k2 = fmaxf(k2, __shfl_xor(k2, o, 64));
+    if (lane == 0) kn[wave] = k2;
+  }
+  __syncthreads();
+  float k2max = 0.f;
+  for (int w = 0; w < nwv; ++w) k2max = fmaxf(k2max, kn[w]);
   const T* krow = Ks + li * HD + 8 * (g & 1);                  // this lane's chunk of key row li of a tile
+  typedef __attribute__((address_space(3))) bf16x4* lds_v4;
+  const T* vtr = Vs + (4 * g + (li >> 2)) * HD + 4 * (li & 3);   // transposing read: row 4g + q, columns 4p.. of a tile
   // query tile t belongs to workgroup t % split, and within it to wave (t / split) % waves: every workgroup gets the same
   // number of tiles (+-1), and the waves with one tile more are spread evenly over the four SIMDs
   for (int qt = sp + a.split * wave; qt * 16 < n; qt += nwv * a.split) {
@@ -259,9 +303,11 @@ __global__ __launch_bounds__(1024) void attn_fwd_onepass_bf16_kernel(AttnArgs a)
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
     f32x4 cm = {0.f, 0.f, 0.f, 0.f};                           // -m, the C operand of the score products
     float m = 0.f, l = 0.f;                                    // l: this lane's share (its 8 keys per pair) of the row sum
-    auto step = [&](int kp, auto first, auto last) {
+    auto step = [&](int kp, auto first, auto last, auto track) {
       const bf16x8 ka = *reinterpret_cast<const bf16x8*>(krow + kp * 32 * HD);
       const bf16x8 kb = *reinterpret_cast<const bf16x8*>(krow + kp * 32 * HD + 16 * HD);
+      const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(vtr + kp * 32 * HD));
+      const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(vtr + kp * 32 * HD + 16 * HD));
       f32x4 ca = cm, cb = cm;
       if constexpr (decltype(last)::value) {                   // the pair that can hold keys >= n
 #pragma unroll
@@ -272,6 +318,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_onepass_bf16_kernel(AttnArgs a)
       }
       f32x4 sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qv, ca, 0, 0, 0);             // x - m  (S^T[key][q])
       f32x4 sb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kb, qv, cb, 0, 0, 0);
+      if constexpr (decltype(first)::value || decltype(track)::value) {
       float mx = fmaxf(fmaxf(sa[0], sa[1]), sa[2]);
       mx = fmaxf(fmaxf(mx, sa[3]), sb[0]);
       mx = fmaxf(fmaxf(mx, sb[1]), sb[2]);
@@ -290,6 +337,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_onepass_bf16_kernel(AttnArgs a)
         m += delta;
         cm[0] = cm[1] = cm[2] = cm[3] = -m;
       }
+      }
       float p[8];
       bf16x8 pb;
 #pragma unroll
@@ -300,17 +348,36 @@ __global__ __launch_bounds__(1024) void attn_fwd_onepass_bf16_kernel(AttnArgs a)
 #pragma unroll
       for (int r = 0; r < 8; ++r) pb[r] = (bf16_t)p[r];
       l += ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
-      const bf16x4 v0 = *reinterpret_cast<const bf16x4*>(Vs + li * ldt + kp * 32 + 4 * g);
-      const bf16x4 v1 = *reinterpret_cast<const bf16x4*>(Vs + li * ldt + kp * 32 + 16 + 4 * g);
       const bf16x8 va = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
       o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, pb, o, 0, 0, 0);
     };
+    // |q'|^2 of this lane's query (q' = q * scale * log2 e as fed to the MFMA: the hi halves, the lo halves add < 2^-8 of it)
+    float q2 = 0.f;
+    if (g < 2) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) q2 += (float)qv[e] * (float)qv[e];
+    }
+    q2 += __shfl_xor(q2, 16, 64);
+    q2 += __shfl_xor(q2, 32, 64);
+    const float bound = 1.01f * __builtin_sqrtf(q2 * k2max) + 1.f;       // every |score| of this query (log2 domain) stays below it
+    const std::true_type T_true_{};
+    const std::false_type T_false_{};
     if (npairs == 1) {
-      step(0, std::true_type{}, std::true_type{});
+      step(0, T_true_, T_true_, T_true_);
     } else {
-      step(0, std::true_type{}, std::false_type{});
-      for (int kp = 1; kp < npairs - 1; ++kp) step(kp, std::false_type{}, std::false_type{});
-      step(npairs - 1, std::false_type{}, std::true_type{});
+      step(0, T_true_, T_false_, T_true_);
+      // After the first pair m is the maximum over its 32 keys.  If no later score of any query of the tile can exceed that
+      // reference by more than 2^100 (bound - m <= 100: the row sum of n terms stays finite in fp32, the probabilities
+      // are plain floats - bf16 keeps its 8 significant bits at any magnitude) the running maximum is NOT tracked for the
+      // rest of the tile: 6 dependent max operations, a compare and a branch per 32 keys were a quarter of the kernel
+      // (profiles/r04_attention_ablation.txt).  Otherwise (huge logits) the tracking loop runs as before.
+      if (__all(bound - m <= 100.f)) {
+        for (int kp = 1; kp < npairs - 1; ++kp) step(kp, T_false_, T_false_, T_false_);
+        step(npairs - 1, T_false_, T_true_, T_false_);
+      } else {
+        for (int kp = 1; kp < npairs - 1; ++kp) step(kp, T_false_, T_false_, T_true_);
+        step(npairs - 1, T_false_, T_true_, T_true_);
+      }
     }
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
@@ -748,13 +815,21 @@ __global__ __launch_bounds__(1024) void attn_bwd_dkv_bf16_kernel(AttnArgs a) {
   }
 }
 
+// hipFuncSetAttribute costs tens of microseconds of HOST time: once per kernel and size, not per launch (an eager loop of
+// attention launches was host-bound at ~90 us per launch, whatever the kernel did - tools/attn_bench.py, round 4)
 template <typename KernelT>
 int set_lds(KernelT k, size_t bytes) {
   if (bytes > 160 * 1024) {
     pb_set_error("attention: %zu bytes of LDS needed (n too large)", bytes);
     return 1;
   }
-  if (bytes > 48 * 1024) PB_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  static size_t have[8] = {0, 0, 0, 0, 0, 0, 0, 0};        // per device: the limit this kernel already has
+  int dev = 0;
+  PB_HIP(hipGetDevice(&dev));
+  if (bytes > 48 * 1024 && (dev < 0 || dev >= 8 || have[dev] < bytes)) {
+    PB_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    if (dev >= 0 && dev < 8) have[dev] = bytes;
+  }
   return 0;
 }
 
@@ -762,8 +837,11 @@ int set_lds(KernelT k, size_t bytes) {
 // enough workgroups per (group, head) to put ~1024 on the chip
 constexpr int ATT_THREADS = 512, ATT_THREADS_DKV = 1024;
 int attn_split(int64_t G, int n, int threads = ATT_THREADS) {
+  static const int forced = getenv("PB_ATTN_SPLIT") ? atoi(getenv("PB_ATTN_SPLIT")) : 0;
+  if (forced > 0) return forced;
   const int64_t tiles = pb_cdiv(n, 16), rounds = pb_cdiv(tiles, threads / 64);
   int64_t sp = pb_cdiv(1024, G * NH);
+  if (G * NH >= 512) sp = 1;        // (every workgroup stages its head's K and V: once, when 512 heads already give 2 workgroups per CU)
   if (sp > rounds) sp = rounds;
   return sp < 1 ? 1 : (int)sp;
 }
@@ -792,6 +870,7 @@ extern "C" int pb_attention_fwd(const void* qkv, void* out, float* lse, int64_t 
   a.split = attn_split(G, n);
   const size_t es = dtype == PB_BF16 ? 2 : 4;
   const size_t lds = (size_t)a.npad * HD * es + (dtype == PB_BF16 ? (size_t)HD * (a.npad + 8) * es : (size_t)a.npad * HD * es);
+  const size_t lds_onepass = (size_t)2 * a.npad * HD * 2 + 64;   // K and V row-major (+ the waves' |k|^2 maxima)
   dim3 grid((unsigned)(G * NH * a.split));
   static const bool onepass = !(getenv("PB_ATTN_ONEPASS") && atoi(getenv("PB_ATTN_ONEPASS")) == 0);
   if (dtype == PB_BF16 && onepass) {
@@ -799,8 +878,8 @@ extern "C" int pb_attention_fwd(const void* qkv, void* out, float* lse, int64_t 
     // round of workgroups fills the chip (512-thread workgroups at 3 per CU left a third of the second round empty)
     const int threads = onepass_threads(n);
     a.split = attn_split(G, n, threads);
-    if (int rc = set_lds(attn_fwd_onepass_bf16_kernel, lds)) return rc;
-    hipLaunchKernelGGL(attn_fwd_onepass_bf16_kernel, dim3((unsigned)(G * NH * a.split)), dim3(threads), lds, (hipStream_t)stream, a);
+    if (int rc = set_lds(attn_fwd_onepass_bf16_kernel, lds_onepass)) return rc;
+    hipLaunchKernelGGL(attn_fwd_onepass_bf16_kernel, dim3((unsigned)(G * NH * a.split)), dim3(threads), lds_onepass, (hipStream_t)stream, a);
   } else if (dtype == PB_BF16) {
     if (int rc = set_lds(attn_fwd_kernel<bf16_t>, lds)) return rc;
     hipLaunchKernelGGL(attn_fwd_kernel<bf16_t>, grid, dim3(ATT_THREADS), lds, (hipStream_t)stream, a);

@@ -10,7 +10,7 @@
 
 namespace {
 
-constexpr int MAX_JOBS = 8;
+constexpr int MAX_JOBS = 32;     // (1.4 KB of kernel arguments; a backward pass batches the jobs of several blocks into one launch)
 
 struct ReduceJobs {
   const float* part[MAX_JOBS];
@@ -29,9 +29,8 @@ struct ReduceJobs {
 __global__ __launch_bounds__(256) void partials_reduce_kernel(ReduceJobs J) {
   __shared__ f32x4 red[8][32];
   int j = 0;
-#pragma unroll
-  for (int i = 1; i < MAX_JOBS; ++i)
-    if (i < J.count && (int)blockIdx.x >= J.blk0[i]) j = i;
+  for (int i = 1; i < J.count; ++i)
+    if ((int)blockIdx.x >= J.blk0[i]) j = i;
   const float* P = J.part[j];
   float* out = J.out[j];
   const int64_t n = J.n[j], stride = J.stride[j];

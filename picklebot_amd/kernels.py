@@ -220,6 +220,9 @@ def partials_reduce(jobs, device):
 _WGRAD_OVERLAP = os.environ.get("PB_WGRAD_OVERLAP", "1") != "0"
 _side = {}
 _lag = {}        # device index -> (done event, tensors kept alive) of the branch not yet joined
+_pending = {}    # device index -> reduction jobs (with the tensors they keep alive) the deferred branches have not launched yet
+_flushed = []    # job lists already launched on the side stream: their workspaces live until the next join
+_REDUCE_BATCH = int(os.environ.get("PB_REDUCE_BATCH", "24"))     # jobs per reduction launch of the deferred branches (<= 32)
 _seen = {}       # graph-task id -> ids of the parameters whose gradient a branch of this pass has deferred
 branch_counts = {"side": 0, "inline": 0}      # how the blocks' weight gradients were issued (tests read this)
 
@@ -301,21 +304,48 @@ def weight_grad_branch(ref, params, thunks, keep, tag="", held=()):
     ev = torch.cuda.Event()
     ev.record(main)
     side.wait_event(ev)
+    pend = _pending.setdefault(idx, [])
     with torch.cuda.stream(side):
-        with deferred_reductions(held):
+        # the partial-tile reductions of SEVERAL blocks go out as one launch (whoever reads a gradient joins first, and the
+        # join flushes what is left): 23 -> 6 reduction launches per MobileNetLarge3D step
+        with deferred_reductions(held, pending=pend):
             for t in thunks:
                 t()
+        if len(pend) >= _REDUCE_BATCH:
+            _flush_pending(idx)
     done = torch.cuda.Event()
     done.record(side)
     _lag[idx] = (done, (keep, held))      # (held: the chain's workspaces the branch's reduction reads)
     branch_counts["side"] += 1
 
 
+def _flush_pending(idx):
+    """One pb_partials_reduce launch (on the current = side stream) for every reduction job the branches of device idx left."""
+    jobs = _pending.get(idx)
+    if not jobs:
+        return
+    _pending[idx] = []
+    arr = (_C.ReduceJob * len(jobs))(*[j for j, _ in jobs])
+    st = ctypes.c_void_p(torch.cuda.current_stream(idx).cuda_stream)
+    _launch("partials_reduce", sum(j.n * 4 * (j.split + 1) for j, _ in jobs), "pb_partials_reduce", arr, len(jobs), idx, st)
+    _flushed.append(jobs)      # the workspaces stay alive until the calling stream has joined (join_weight_grads)
+
+
 def join_weight_grads():
-    """Order the current stream(s) behind every weight-gradient branch still in flight (cheap when there is none)."""
+    """Order the current stream(s) behind every weight-gradient branch still in flight (cheap when there is none); reduction
+    jobs the branches left pending are launched first (behind the last branch, on the side stream)."""
+    for idx in [i for i, jobs in _pending.items() if jobs]:
+        side = _side_stream(idx)
+        with torch.cuda.stream(side):
+            _flush_pending(idx)
+        done = torch.cuda.Event()
+        done.record(side)
+        prev = _lag.pop(idx, None)
+        _lag[idx] = (done, prev[1] if prev else None)
     for idx in list(_lag):
         done, _ = _lag.pop(idx)
         torch.cuda.current_stream(idx).wait_event(done)
+    del _flushed[:]
 
 
 def _end_of_backward():
@@ -330,8 +360,9 @@ _deferred = threading.local()
 
 
 class deferred_reductions:
-    def __init__(self, held=()):
+    def __init__(self, held=(), pending=None):
         self.held = list(held)
+        self.pending = pending          # a list: the jobs are appended to it instead of being launched at exit
 
     def __enter__(self):
         self.prev = getattr(_deferred, "jobs", None)
@@ -340,6 +371,9 @@ class deferred_reductions:
 
     def __exit__(self, *exc):
         jobs, _deferred.jobs = _deferred.jobs, self.prev
+        if exc[0] is None and jobs and self.pending is not None:
+            self.pending.extend(jobs)
+            return False
         if exc[0] is None and jobs:
             flush = [(j.part, j.out, j.n, j.stride, j.split, j.accumulate) for j, _ in jobs]
             arr = (_C.ReduceJob * len(jobs))(*[j for j, _ in jobs])

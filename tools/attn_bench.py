@@ -18,14 +18,24 @@ dev = torch.device("cuda:0")
 
 
 def timed(fn):
+    """us per launch with `iters` launches replayed from ONE HIP graph: an eager loop of these launches is host-bound (output
+    allocation + ctypes + the launch itself ~ 90 us per iteration in round 3's numbers, whatever the kernel did)."""
     fn()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
         fn()
-    e1.record()
-    torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            for _ in range(iters):
+                fn()
+        g.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g.replay()
+        e1.record()
+        torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e3
 
 
