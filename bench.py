@@ -336,8 +336,15 @@ def main():
             families[name] = {"launches_per_step": d["launches"] // args.steps, "ms_per_step": round(d["ms"] / args.steps, 4),
                               "GBps": round(gbs, 1), "frac_hbm": round(gbs / HBM_PEAK_GBS, 4),
                               "share_of_kernel_time": round(d["ms"] / tot_ms, 4)}
-        dom = next(iter(families))
-        d = prof[dom]
+        # The dominant KERNEL, by name (the per-mode split of `ew_kernel` hid that the BatchNorm / activation passes
+        # are the largest consumer): families that are template modes of one kernel (`ew_kernel<...>`) are added up.
+        by_name = {}
+        for name, d in prof.items():
+            b = by_name.setdefault(name.split("<")[0], dict(launches=0, ms=0.0, bytes=0))
+            for k in ("launches", "ms", "bytes"):
+                b[k] += d[k]
+        dom = max(by_name, key=lambda k: by_name[k]["ms"])
+        d = by_name[dom]
         ach = d["bytes"] / 1e9 / (d["ms"] / 1e3)
         # HBM bytes per launch of the dominant kernel from the PMC summary (rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this
         # same command, corrected as MI355X_MICROARCH.md prescribes; tools/profile_round.sh + tools/pmc_summary.py).  Only a
@@ -346,18 +353,25 @@ def main():
         try:
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             from pmc_summary import csrc_digest
-            pmc = json.load(open(os.environ.get("PB_PMC_TRAFFIC", os.path.join(ROOT, "profiles", "r03_pmc_traffic.json"))))
+            pmc = json.load(open(os.environ.get("PB_PMC_TRAFFIC", os.path.join(ROOT, "profiles", "r04_pmc_traffic.json"))))
             if pmc.get("meta", {}).get("csrc_digest") == csrc_digest():
-                key = dom.split("<")[0]
-                if key in pmc["kernels"]:
-                    traffic = pmc["kernels"][key]["hbm_bytes_per_launch"]
+                if dom in pmc["kernels"]:
+                    traffic = pmc["kernels"][dom]["hbm_bytes_per_launch"]
         except Exception:
             traffic = None
         roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "bytes_per_launch": int(d["bytes"] / d["launches"]), "avg_launch_us": round(d["ms"] / d["launches"] * 1e3, 2),
                     "launches": d["launches"],
-                    "measured_over": f"{args.steps} steps re-run in line (weight-gradient side stream off) with HIP events around every launch"}
+                    "share_of_kernel_time": round(d["ms"] / tot_ms, 4),
+                    "measured_over": f"{args.steps} steps re-run in line (weight-gradient side stream off) with HIP events around every launch; "
+                                     "the kernel with the largest total time BY NAME (template modes added up)"}
+        # the depthwise-3D path as a whole (north_star target: >= 0.50 of the HBM roofline)
+        dw = [v for k, v in prof.items() if k.startswith("dw")]
+        if dw:
+            dwb, dwms = sum(v["bytes"] for v in dw), sum(v["ms"] for v in dw)
+            roofline["depthwise_path"] = {"GBps": round(dwb / 1e9 / (dwms / 1e3), 1), "frac": round(dwb / 1e9 / (dwms / 1e3) / HBM_PEAK_GBS, 4),
+                                          "ms_per_step": round(dwms / args.steps, 4), "launches_per_step": sum(v["launches"] for v in dw) // args.steps}
     if dp_path:
         dist.barrier()
     log("profiling pass done")

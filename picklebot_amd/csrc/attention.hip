@@ -240,6 +240,18 @@ __device__ __forceinline__ void attn_glds16(const void* gsrc, unsigned char* lds
                : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
 }
 
+// one [n][16] bf16 head slice (rows `ld` elements apart) -> LDS row-major [npad][16] at `dst`, by LDS-DMA; rows >= n repeat
+// row n-1 (callers that need zeros there overwrite them after the wait).  All waves take part; the caller waits
+// (s_waitcnt vmcnt(0)) and synchronises.
+__device__ __forceinline__ void stage_slice_dma(const bf16_t* src, int64_t ld, int n, int npad, unsigned char* dst, int wave_u, int nwv, int lane) {
+  const int nchunks = 2 * npad;                                 // 16-byte chunks (a multiple of 64)
+  for (int c0 = wave_u * 64; c0 < nchunks; c0 += nwv * 64) {
+    const int i = c0 + lane;
+    const int r = min(i >> 1, n - 1), c = i & 1;
+    attn_glds16(src + (int64_t)r * ld + c * 8, dst + (size_t)c0 * 16);
+  }
+}
+
 // Round 4: K AND V are staged ROW-MAJOR ([npad][16], the layout they have in memory) by LDS-DMA - no registers, no
 // transposing 2-byte LDS writes, every chunk of the slice in flight at once (staging was a third of the kernel:
 // profiles/r04_attention_ablation.txt).  The V^T operand of O^T += V^T P^T comes from the hardware transposing read:
@@ -675,18 +687,23 @@ __global__ __launch_bounds__(1024) void attn_bwd_dkv_kernel(AttnArgs a) {
 __global__ __launch_bounds__(512) void attn_bwd_dq_bf16_kernel(AttnArgs a) {
   typedef bf16_t T;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int n = a.n, npad = a.npad, ldt = npad + 8;
+  const int n = a.n, npad = a.npad;
   T* Ks = (T*)smem;                 // [npad][16]
-  T* Vs = Ks + npad * HD;           // [npad][16]
-  T* Kt = Vs + npad * HD;           // K^T [16][ldt]
+  T* Vs = Ks + npad * HD;           // [npad][16]   (round 4: no K^T copy - the transposing LDS read delivers it)
   const int gh = blockIdx.x / a.split, sp = blockIdx.x - gh * a.split, nwv = blockDim.x >> 6;
   const int grp = gh / NH, h = gh - grp * NH;
   const T* base = (const T*)a.qkv + (int64_t)grp * n * QKV_LD + h * HD;
-  stage_head<T>(base + NH * HD, QKV_LD, n, npad, Ks, Kt, ldt);
-  stage_head<T>(base + 2 * NH * HD, QKV_LD, n, npad, Vs, nullptr, 0);
-  __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  {
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    stage_slice_dma(base + NH * HD, QKV_LD, n, npad, (unsigned char*)Ks, wave_u, nwv, lane);
+    stage_slice_dma(base + 2 * NH * HD, QKV_LD, n, npad, (unsigned char*)Vs, wave_u, nwv, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
   const int li = lane & 15, g = lane >> 4;
+  typedef __attribute__((address_space(3))) bf16x4* lds_v4;
+  const T* ktr = Ks + (4 * g + (li >> 2)) * HD + 4 * (li & 3);   // transposing read: K^T[d = lane][keys 4g .. 4g+3] of a tile
   const T* krow = Ks + li * HD + 8 * (g & 1);
   const T* vrow = Vs + li * HD + 8 * (g & 1);
   const int npairs = npad >> 5, pfull = n >> 5;
@@ -723,8 +740,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_bf16_kernel(AttnArgs a) {
         dsb[r] = (bf16_t)xa;
         dsb[4 + r] = (bf16_t)xb;
       }
-      const bf16x4 k0 = *reinterpret_cast<const bf16x4*>(Kt + li * ldt + kp * 32 + 4 * g);
-      const bf16x4 k1 = *reinterpret_cast<const bf16x4*>(Kt + li * ldt + kp * 32 + 16 + 4 * g);
+      const bf16x4 k0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(ktr + kp * 32 * HD));
+      const bf16x4 k1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(ktr + kp * 32 * HD + 16 * HD));
       const bf16x8 kt8 = {k0[0], k0[1], k0[2], k0[3], k1[0], k1[1], k1[2], k1[3]};
       dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt8, dsb, dq, 0, 0, 0);
     };
@@ -743,26 +760,39 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_bf16_kernel(AttnArgs a) {
 __global__ __launch_bounds__(1024) void attn_bwd_dkv_bf16_kernel(AttnArgs a) {
   typedef bf16_t T;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int n = a.n, npad = a.npad, ldt = npad + 8;
+  const int n = a.n, npad = a.npad;
   T* Qs = (T*)smem;                      // [npad][16]
-  T* Os = Qs + npad * HD;                // dO [npad][16]
-  T* Qt = Os + npad * HD;                // Q^T, dO^T [16][ldt]
-  T* Ot = Qt + HD * ldt;
-  float* Ls = (float*)(Ot + HD * ldt);   // -lse * log2 e [npad], -delta [npad]
+  T* Os = Qs + npad * HD;                // dO [npad][16]   (round 4: no Q^T / dO^T copies - transposing LDS reads; 105 -> 55 KB
+  float* Ls = (float*)(Os + npad * HD);  //  at n = 768: two workgroups per CU instead of one)    -lse * log2 e [npad], -delta [npad]
   float* Ds = Ls + npad;
   const int gh = blockIdx.x / a.split, sp = blockIdx.x - gh * a.split, nwv = blockDim.x >> 6;
   const int grp = gh / NH, h = gh - grp * NH;
   const T* base = (const T*)a.qkv + (int64_t)grp * n * QKV_LD + h * HD;
   const T* dob = (const T*)a.dout + (int64_t)grp * n * OUT_LD + h * HD;
-  stage_head<T>(base, QKV_LD, n, npad, Qs, Qt, ldt);
-  stage_head<T>(dob, OUT_LD, n, npad, Os, Ot, ldt);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  {
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    stage_slice_dma(base, QKV_LD, n, npad, (unsigned char*)Qs, wave_u, nwv, lane);
+    stage_slice_dma(dob, OUT_LD, n, npad, (unsigned char*)Os, wave_u, nwv, lane);
+  }
   for (int i = threadIdx.x; i < npad; i += blockDim.x) {
     Ls[i] = i < n ? -a.lse[((int64_t)grp * n + i) * NH + h] * 1.44269504088896340736f : 0.f;
     Ds[i] = i < n ? -a.delta[((int64_t)grp * n + i) * NH + h] : 0.f;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // the padding queries must be ZERO rows (Q = dO = 0 with L2 = delta = 0: P = 1, dS = 0 against zero dO^T / Q^T columns);
+  // the DMA repeated row n-1 there
+  for (int i = threadIdx.x; i < (npad - n) * 4; i += blockDim.x) {
+    const int r = n + (i >> 2), c = i & 3;
+    bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    *reinterpret_cast<bf16x8*>((c < 2 ? Qs : Os) + r * HD + (c & 1) * 8) = z;
+  }
+  __syncthreads();
   const int li = lane & 15, g = lane >> 4;
+  typedef __attribute__((address_space(3))) bf16x4* lds_v4;
+  const T* qtr = Qs + (4 * g + (li >> 2)) * HD + 4 * (li & 3);   // transposing reads: Q^T / dO^T[d = lane][queries 4g .. 4g+3]
+  const T* otr = Os + (4 * g + (li >> 2)) * HD + 4 * (li & 3);
   const T* qrow = Qs + li * HD + 8 * (g & 1);
   const T* orow = Os + li * HD + 8 * (g & 1);
   const int npairs = npad >> 5;
@@ -796,12 +826,12 @@ __global__ __launch_bounds__(1024) void attn_bwd_dkv_bf16_kernel(AttnArgs a) {
         dsb[r] = (bf16_t)(p0 * da[r]);
         dsb[4 + r] = (bf16_t)(p1 * db[r]);
       }
-      const bf16x4 o0 = *reinterpret_cast<const bf16x4*>(Ot + li * ldt + qp * 32 + 4 * g);
-      const bf16x4 o1 = *reinterpret_cast<const bf16x4*>(Ot + li * ldt + qp * 32 + 16 + 4 * g);
+      const bf16x4 o0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(otr + qp * 32 * HD));
+      const bf16x4 o1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(otr + qp * 32 * HD + 16 * HD));
       const bf16x8 ot8 = {o0[0], o0[1], o0[2], o0[3], o1[0], o1[1], o1[2], o1[3]};
       dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ot8, pb, dv, 0, 0, 0);
-      const bf16x4 q0 = *reinterpret_cast<const bf16x4*>(Qt + li * ldt + qp * 32 + 4 * g);
-      const bf16x4 q1 = *reinterpret_cast<const bf16x4*>(Qt + li * ldt + qp * 32 + 16 + 4 * g);
+      const bf16x4 q0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(qtr + qp * 32 * HD));
+      const bf16x4 q1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(qtr + qp * 32 * HD + 16 * HD));
       const bf16x8 qt8 = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
       dk = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt8, dsb, dk, 0, 0, 0);
     }
@@ -930,7 +960,7 @@ extern "C" int pb_attention_bwd(const void* qkv, const void* out, const void* do
   if (bf) {
     hipLaunchKernelGGL(attn_delta_kernel<bf16_t>, dim3((unsigned)pb_cdiv(R * NH, 256)), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)out, delta, R);
     const size_t tr = (size_t)HD * (a.npad + 8) * es;                                      // one transposed slice
-    const size_t lds_dkv = 2 * rm + 2 * tr + 2 * (size_t)a.npad * 4, lds_dq = 2 * rm + tr;
+    const size_t lds_dkv = 2 * rm + 2 * (size_t)a.npad * 4, lds_dq = 2 * rm;     // (row-major slices only: transposing reads)
     if (int rc = set_lds(attn_bwd_dkv_bf16_kernel, lds_dkv)) return rc;
     hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel, grid_kv, dim3(ATT_THREADS_DKV), lds_dkv, st, akv);
     if (int rc = set_lds(attn_bwd_dq_bf16_kernel, lds_dq)) return rc;
