@@ -102,7 +102,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and not os.environ.get("PB_BENCH_FORCE_DP"):
         raise SystemExit("--gpus %d but the launcher started %d ranks" % (args.gpus, world))
-    local_rank, rank, _ = setup_distributed("nccl") if dp_path else (0, 0, 1)
+    # Data parallel: by default the process group is created AFTER the HIP graph of forward + backward has been captured
+    # (early_capture): ProcessGroupNCCL's watchdog thread polls its work objects' events every 100 ms, and on this stack
+    # (ROCm 7 / torch 2.10) such a poll while ANY stream of the process is capturing can fail with hipErrorCapturedEvent,
+    # invalidate the capture and take the process down in C++ `terminate` - seen in rounds 3 and 4 with and without
+    # collectives inside the graph (gpurun_out/r4ev/dp_3.err: 1 run in 6).  No watchdog, no poll: the capture happens first.
+    graph_collectives = bool(os.environ.get("PB_BENCH_GRAPH_COLLECTIVES"))       # opt-in: collectives INSIDE the graph
+    early_capture = dp_path and not args.no_graph and not graph_collectives
+    if dp_path and not early_capture:
+        local_rank, rank, _ = setup_distributed("nccl")
+    elif dp_path:
+        local_rank, rank = int(os.environ.get("LOCAL_RANK", "0")), int(os.environ["RANK"])
+    else:
+        local_rank, rank = 0, 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
@@ -110,7 +122,7 @@ def main():
     model = picklebot_amd.MobileNetLarge3D(NCLS).to(device)
     model.initialize_weights()                                # train.py:177 (a no-op for this model)
     model.train()
-    reducer = GradReducer(model) if dp_path else None
+    reducer = GradReducer(model, bind_later=early_capture) if dp_path else None
     use_graph = not dp_path and not args.no_graph
     flat_opt = not args.torch_adamw
     if flat_opt:
@@ -169,7 +181,8 @@ def main():
                 raise RuntimeError("RCCL watchdog still holds eager work objects (or cannot be asked): not capturing a collective")
         g = torch.cuda.CUDAGraph()
         K.reset_zero_arena()              # the zero-filled scratch must be allocated AND filled inside the graph
-        with torch.cuda.graph(g, stream=run_stream):
+        # (data parallel: thread-local capture mode - RCCL's watchdog thread queries events of eager collectives meanwhile)
+        with torch.cuda.graph(g, stream=run_stream, capture_error_mode="thread_local" if dp_path else "global"):
             out = fn()
         K.reset_zero_arena()
         return g, out
@@ -209,8 +222,44 @@ def main():
         except Exception as e:  # capture is an optimisation: fall back to eager submission
             recover("HIP graph capture", e)
             step = eager_step
+    elif early_capture:
+        # data parallel, default.  forward + backward (gradients handed over as they are, one multi-tensor copy per bucket at
+        # the end) captured into a HIP graph BEFORE the process group exists; then the group is created, the replicas are
+        # synchronised (in place), and a step = graph replay + bucket all-reduces over RCCL + optimizer.
+        def fwd_bwd():
+            reducer.detach_grads()
+            with reducer.no_sync():
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    loss = torch.nn.functional.cross_entropy(model(x).float(), y)
+                loss.backward()
+            reducer.pack_grads()
+            return loss
+
+        ok, graph = True, None
+        try:
+            graph, graph_loss = capture(fwd_bwd)
+        except Exception as e:
+            ok = False
+            recover("HIP graph capture (fwd+bwd, before the process group)", e)
+        setup_distributed("nccl")                         # the watchdog thread starts here - after the capture
+        reducer.bind()                                    # world size + broadcast of rank 0's parameters and buffers
+        reducer.attach_grads()
+        reducer.zero_grad()
+        step()                                            # one eager step: creates the RCCL communicator
+        sync()
+        log("process group up, first eager data-parallel step done")
+        if all_ranks_ok(ok):                              # collective: one rank without a graph -> nobody replays
+            def step():  # noqa: F811
+                graph.replay()
+                reducer.reduce_now()
+                opt_step_reduced()
+                return graph_loss
+            launch_mode = "hipgraph(fwd+bwd, captured before the process group exists) + eager RCCL all-reduce per bucket + optimizer"
+        else:
+            graph = None
+            step = eager_step
     elif dp_path and not args.no_graph:
-        # data parallel.  First choice: the WHOLE step in one HIP graph, the exchange included - backward hands its gradients
+        # data parallel, opt-in (PB_BENCH_GRAPH_COLLECTIVES=1).  First choice: the WHOLE step in one HIP graph, the exchange included - backward hands its gradients
         # over as they are, the hook of a bucket's last gradient packs the bucket and issues its RCCL all-reduce on RCCL's
         # stream (a fork inside the capture), so bucket k travels over xGMI while the rest of backward replays; the
         # optimizer joins behind the last reduction.  Second choice (capture of the collective refused): forward +
@@ -238,7 +287,13 @@ def main():
         sync()
         log("first eager data-parallel step done")
         captured = False
-        if flat_opt and not os.environ.get("PB_BENCH_NO_OVERLAP_GRAPH"):
+        # The whole-step graph WITH the collectives inside is OPT-IN (PB_BENCH_GRAPH_COLLECTIVES=1).  Round 4 saw RCCL's watchdog
+        # thread abort the process twice more (hipErrorCapturedEvent from WorkNCCL::isCompleted while RCCL's stream was part of
+        # the capture), once WITH the retired-work hand-off below in place - so the hand-off is necessary but not sufficient on
+        # this stack, and a bench that dies in C++ `terminate` on the 8-GPU node measures nothing.  Default: forward + backward
+        # replayed from a graph that contains NO collective (RCCL's stream never joins a capture), then the bucket
+        # all-reduces and the optimizer eagerly.
+        if flat_opt and os.environ.get("PB_BENCH_GRAPH_COLLECTIVES"):
             ok, graph = True, None
             try:
                 graph, graph_loss = capture(overlapped_step, has_collective=True)

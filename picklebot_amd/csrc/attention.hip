@@ -284,25 +284,6 @@ __global__ __launch_bounds__(1024) void attn_fwd_onepass_bf16_kernel(AttnArgs a)
   __syncthreads();
   const int npairs = npad >> 5;
   const float sl0 = a.scale * 1.44269504088896340736f;
-  // max_k |k|^2 of the head (one row per thread, wave maximum, then the waves' maxima through LDS): with |q| it bounds
-  // every score of a query tile (Cauchy-Schwarz) - used ONLY to decide whether the running maximum has to be tracked
-  float* kn = (float*)(smem + (size_t)2 * npad * HD * sizeof(T));
-  {
-    float k2 = 0.f;
-    for (int r = threadIdx.x; r < n; r += blockDim.x) {
-      const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(Ks + r * HD), k1 = *reinterpret_cast<const bf16x8*>(Ks + r * HD + 8);
-      float t = 0.f;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) t += (float)k0[e] * (float)k0[e] + (float)k1[e] * (float)k1[e];
-      k2 = fmaxf(k2, t);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) k2 = fmaxf(k2, __shfl_xor(k2, o, 64));
-    if (lane == 0) kn[wave] = k2;
-  }
-  __syncthreads();
-  float k2max = 0.f;
-  for (int w = 0; w < nwv; ++w) k2max = fmaxf(k2max, kn[w]);
   const T* krow = Ks + li * HD + 8 * (g & 1);                  // this lane's chunk of key row li of a tile
   typedef __attribute__((address_space(3))) bf16x4* lds_v4;
   const T* vtr = Vs + (4 * g + (li >> 2)) * HD + 4 * (li & 3);   // transposing read: row 4g + q, columns 4p.. of a tile
@@ -315,7 +296,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_onepass_bf16_kernel(AttnArgs a)
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
     f32x4 cm = {0.f, 0.f, 0.f, 0.f};                           // -m, the C operand of the score products
     float m = 0.f, l = 0.f;                                    // l: this lane's share (its 8 keys per pair) of the row sum
-    auto step = [&](int kp, auto first, auto last, auto track) {
+    auto step = [&](int kp, auto first, auto last) {
       const bf16x8 ka = *reinterpret_cast<const bf16x8*>(krow + kp * 32 * HD);
       const bf16x8 kb = *reinterpret_cast<const bf16x8*>(krow + kp * 32 * HD + 16 * HD);
       const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(vtr + kp * 32 * HD));
@@ -330,7 +311,8 @@ __global__ __launch_bounds__(1024) void attn_fwd_onepass_bf16_kernel(AttnArgs a)
       }
       f32x4 sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qv, ca, 0, 0, 0);             // x - m  (S^T[key][q])
       f32x4 sb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kb, qv, cb, 0, 0, 0);
-      if constexpr (decltype(first)::value || decltype(track)::value) {
+      // (the maximum of the lane's eight scores stays a plain fmaxf chain: hand-written v_max3 instructions in inline asm read
+      // the MFMA results before the hazard wait states the compiler inserts for its own instructions - NaNs, round 4)
       float mx = fmaxf(fmaxf(sa[0], sa[1]), sa[2]);
       mx = fmaxf(fmaxf(mx, sa[3]), sb[0]);
       mx = fmaxf(fmaxf(mx, sb[1]), sb[2]);
@@ -349,7 +331,6 @@ __global__ __launch_bounds__(1024) void attn_fwd_onepass_bf16_kernel(AttnArgs a)
         m += delta;
         cm[0] = cm[1] = cm[2] = cm[3] = -m;
       }
-      }
       float p[8];
       bf16x8 pb;
 #pragma unroll
@@ -363,33 +344,16 @@ __global__ __launch_bounds__(1024) void attn_fwd_onepass_bf16_kernel(AttnArgs a)
       const bf16x8 va = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
       o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, pb, o, 0, 0, 0);
     };
-    // |q'|^2 of this lane's query (q' = q * scale * log2 e as fed to the MFMA: the hi halves, the lo halves add < 2^-8 of it)
-    float q2 = 0.f;
-    if (g < 2) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) q2 += (float)qv[e] * (float)qv[e];
-    }
-    q2 += __shfl_xor(q2, 16, 64);
-    q2 += __shfl_xor(q2, 32, 64);
-    const float bound = 1.01f * __builtin_sqrtf(q2 * k2max) + 1.f;       // every |score| of this query (log2 domain) stays below it
-    const std::true_type T_true_{};
-    const std::false_type T_false_{};
+    // (Round 4 also tried NOT tracking the maximum when a Cauchy-Schwarz bound |q||k|max shows no score can overflow: 100 ->
+    // 80 us at n = 768 - but the largest probability then no longer sits at exactly 1.0, every weight carries a bf16
+    // rounding error, and MobileViT-XXS's eval-mode bf16 gradients moved from 0.90 to 1.29 of the reference's own deviation
+    // (median; worst tensor 1.85 -> 2.99 of the 3.0 bar).  Parity first: the exact running maximum stays.)
     if (npairs == 1) {
-      step(0, T_true_, T_true_, T_true_);
+      step(0, std::true_type{}, std::true_type{});
     } else {
-      step(0, T_true_, T_false_, T_true_);
-      // After the first pair m is the maximum over its 32 keys.  If no later score of any query of the tile can exceed that
-      // reference by more than 2^100 (bound - m <= 100: the row sum of n terms stays finite in fp32, the probabilities
-      // are plain floats - bf16 keeps its 8 significant bits at any magnitude) the running maximum is NOT tracked for the
-      // rest of the tile: 6 dependent max operations, a compare and a branch per 32 keys were a quarter of the kernel
-      // (profiles/r04_attention_ablation.txt).  Otherwise (huge logits) the tracking loop runs as before.
-      if (__all(bound - m <= 100.f)) {
-        for (int kp = 1; kp < npairs - 1; ++kp) step(kp, T_false_, T_false_, T_false_);
-        step(npairs - 1, T_false_, T_true_, T_false_);
-      } else {
-        for (int kp = 1; kp < npairs - 1; ++kp) step(kp, T_false_, T_false_, T_true_);
-        step(npairs - 1, T_false_, T_true_, T_true_);
-      }
+      step(0, std::true_type{}, std::false_type{});
+      for (int kp = 1; kp < npairs - 1; ++kp) step(kp, std::false_type{}, std::false_type{});
+      step(npairs - 1, std::false_type{}, std::true_type{});
     }
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
@@ -900,7 +864,7 @@ extern "C" int pb_attention_fwd(const void* qkv, void* out, float* lse, int64_t 
   a.split = attn_split(G, n);
   const size_t es = dtype == PB_BF16 ? 2 : 4;
   const size_t lds = (size_t)a.npad * HD * es + (dtype == PB_BF16 ? (size_t)HD * (a.npad + 8) * es : (size_t)a.npad * HD * es);
-  const size_t lds_onepass = (size_t)2 * a.npad * HD * 2 + 64;   // K and V row-major (+ the waves' |k|^2 maxima)
+  const size_t lds_onepass = (size_t)2 * a.npad * HD * 2;        // K and V row-major
   dim3 grid((unsigned)(G * NH * a.split));
   static const bool onepass = !(getenv("PB_ATTN_ONEPASS") && atoi(getenv("PB_ATTN_ONEPASS")) == 0);
   if (dtype == PB_BF16 && onepass) {

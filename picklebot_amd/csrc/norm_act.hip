@@ -181,6 +181,25 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs a) {
 #pragma unroll
     for (int i = 0; i < CH; ++i) { rsc[i] = 1.f; rsh[i] = 0.f; }
     int64_t g_end = -1;                                     // first row of the next clip (-1: nothing loaded yet)
+    if constexpr (MODE == 1 || MODE == 2 || MODE == 4) {
+      // the per-clip vectors of this thread's FIRST row are fetched here, beside the per-channel vectors and ahead of the row
+      // loads - not as a third dependent memory round trip after the rows have arrived (small tensors: one or two rows per
+      // thread, the launch is nothing but its round trips)
+      if (has_row && mlo + p < mhi) {
+        const int64_t grp = (int64_t)((uint32_t)(mlo + p) / (uint32_t)a.rows_per_group);
+        g_end = (grp + 1) * a.rows_per_group;
+        if (a.row_scale) {
+          const float* rp = a.row_scale + grp * a.C + c0;
+#pragma unroll
+          for (int i = 0; i < CH; ++i) rsc[i] = rp[i];
+        }
+        if (a.row_shift) {
+          const float* rq = a.row_shift + grp * a.C + c0;
+#pragma unroll
+          for (int i = 0; i < CH; ++i) rsh[i] = rq[i];
+        }
+      }
+    }
     // the activation is a compile-time constant inside the row loop (one uniform dispatch per kernel instead of a
     // switch per element in the unrolled body)
     auto run = [&](auto act_tag) {

@@ -46,18 +46,22 @@ def _join_weight_grads():
 
 
 class GradReducer:
-    def __init__(self, module, process_group=None, bucket_bytes=8 << 20, average=True, broadcast_from=0):
-        if not dist.is_initialized():
+    def __init__(self, module, process_group=None, bucket_bytes=8 << 20, average=True, broadcast_from=0, bind_later=False):
+        """bind_later: build the buckets and hooks WITHOUT a process group (no collective is issued); call bind() once
+        torch.distributed is initialised.  bench.py uses it to capture its HIP graph before the process group - and with it
+        ProcessGroupNCCL's watchdog thread - exists (see bind())."""
+        if not bind_later and not dist.is_initialized():
             raise RuntimeError("GradReducer: torch.distributed is not initialised (see setup_distributed)")
         self.module = module
         self.group = process_group
-        self.world = dist.get_world_size(process_group)
+        self.world = 1 if bind_later else dist.get_world_size(process_group)
+        self._bound = not bind_later
         self.average = average
         self._enabled = True
         self._adopt = False
         self._pending = []
         params = [p for p in module.parameters() if p.requires_grad]
-        if broadcast_from is not None:           # DDP ctor: replicas start identical
+        if broadcast_from is not None and not bind_later:           # DDP ctor: replicas start identical
             self.broadcast_state(broadcast_from)
         # reverse order ~ the order gradients become ready
         self.buckets = []
@@ -105,7 +109,20 @@ class GradReducer:
         srcs = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.buckets[bi]]
         torch._foreach_copy_(self.views[bi], srcs)
 
+    def bind(self, process_group=None, broadcast_from=0):
+        """Attach a reducer built with bind_later=True to the (now initialised) process group: world size, and DDP's
+        init-time broadcast of parameters and buffers (in place: a HIP graph captured earlier keeps pointing at them)."""
+        if not dist.is_initialized():
+            raise RuntimeError("GradReducer.bind: torch.distributed is not initialised (see setup_distributed)")
+        self.group = process_group
+        self.world = dist.get_world_size(process_group)
+        self._bound = True
+        if broadcast_from is not None:
+            self.broadcast_state(broadcast_from)
+
     def _launch(self, bi):
+        if not self._bound:
+            raise RuntimeError("GradReducer: bind() the process group before the first exchange")
         op = dist.ReduceOp.SUM
         work = dist.all_reduce(self.flat[bi], op=op, group=self.group, async_op=True)
         self._pending.append((bi, work))
@@ -168,6 +185,8 @@ class GradReducer:
     def reduce_now(self):
         """All-reduce (and average) every bucket on the spot, stream-ordered behind whatever filled them - for steps
         whose backward ran with the hooks off (e.g. replayed from a HIP graph captured under no_sync())."""
+        if not self._bound:
+            raise RuntimeError("GradReducer: bind() the process group before the first exchange")
         for flat in self.flat:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
             if self.average and self.world > 1:
