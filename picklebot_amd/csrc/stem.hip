@@ -703,6 +703,210 @@ __global__ __launch_bounds__(256) void stem3_fwd_kernel(StemArgs a) {
   }
 }
 
+// ---- the same forward with the window rows arriving by LDS-DMA (round 4) -----------------------------------------
+// stem3_fwd_kernel fetches an item's 9 window rows as 5 unaligned 12-byte loads per lane, waits for them, computes, stores -
+// one item at a time per wave, nothing in flight while it computes: 190 us for 257 MB (0.17 of the HBM peak, two rounds
+// overdue).  Here the RAW rows (the 416 bytes of 16-byte-aligned chunks that cover input pixels 2wo0-1 .. 2wo0+64) go HBM ->
+// LDS by `global_load_lds_dwordx4` into a ring of S3D_NRAW item buffers per wave, S3D_NRAW-1 items AHEAD of the one being
+// computed and without registers; the slot image (slot p = the 6 elements of pixels (2p-1, 2p) + [one, zero]) is then built
+// from LDS: 4 aligned ds_read_b32 + 3 v_alignbit per slot (the 12 bytes start 2 bytes into a dword).  MFMA part unchanged.
+// vmcnt: 4 DMAs and 1 store per item, counted exactly (switch over immediates).
+constexpr int S3D_NRAW = 3;
+constexpr int S3D_RAWCH = 26;                 // 16-byte chunks per raw row: bytes [12 wo0 - 16, 12 wo0 + 400)
+constexpr int S3D_RAWROW = S3D_RAWCH * 16;
+constexpr int S3D_RAWBUF = 4096;              // 9 rows x 416 B = 3744 B, rounded to the 4 DMA instructions' 4 KiB
+constexpr int S3D_LDS = 4 * S3D_NRAW * S3D_RAWBUF + 4 * S3_MAXROWS * S3_SP * 16 + 4 * SW_PIX * OCB * 2;
+
+__device__ __forceinline__ void s3d_glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+__global__ __launch_bounds__(256) void stem3_fwd_dma_kernel(StemArgs a) {
+  typedef bf16_t T;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char s3d_smem[];
+  __shared__ float red[4][2 * OCB];
+  const pb_stem_shape& s = a.s;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  unsigned char* raw_w = s3d_smem + wave * (S3D_NRAW * S3D_RAWBUF);
+  T* win = (T*)(s3d_smem + 4 * S3D_NRAW * S3D_RAWBUF) + wave * (S3_MAXROWS * S3_SP * 8);
+  T* outt = (T*)(s3d_smem + 4 * S3D_NRAW * S3D_RAWBUF + 4 * S3_MAXROWS * S3_SP * 16) + wave * (SW_PIX * OCB);
+  typedef __attribute__((address_space(3))) unsigned char* lds_b;
+  const unsigned raw_lds = (unsigned)(uintptr_t)(lds_b)raw_w;
+  const int nrows = s.kt * s.kh, taps = nrows * 3, CT = 3 * taps;
+  const int wblocks = (s.Wo + SW_PIX - 1) / SW_PIX;
+  const int64_t nitems = (int64_t)s.N * s.To * s.Ho * wblocks;
+  const T* x = (const T*)a.x;
+  T* y = (T*)a.y;
+  const int row = lane & 15, g = lane >> 4;
+  constexpr int NKS = 5;
+  bf16x8 wf[NKS], wl[NKS];
+  int aoff[NKS];
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    const int grp = 4 * ks + g, r = grp >> 1, shift = grp & 1;
+    const bool gv = r < nrows;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float v = 0.f;
+      if (gv) {
+        if (shift == 0 && j < 6) v = a.w[(int64_t)row * CT + (j % 3) * taps + r * 3 + j / 3];
+        else if (shift == 0 && j == 6 && r == 0 && a.bias) v = a.bias[row];
+        else if (shift == 1 && j < 3) v = a.w[(int64_t)row * CT + j * taps + r * 3 + 2];
+      }
+      wf[ks][j] = (bf16_t)v;
+      wl[ks][j] = (bf16_t)(v - (float)wf[ks][j]);
+    }
+    aoff[ks] = ((gv ? r : 0) * S3_SP + shift) * 8;
+  }
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) asm volatile("" : "+v"(wf[ks]), "+v"(wl[ks]));     // (loads consumed: vmcnt is counted by hand below)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  float ssum = 0.f, ssq = 0.f;
+
+  // (An XCD-aware item order - XCD x sweeping whole clips so that the halo rows / frames are L2 hits - measured SLOWER: 159 ->
+  // 174 us; the spread order stays.)
+  const int64_t step = (int64_t)gridDim.x * 4;
+  const int64_t it0 = (int64_t)blockIdx.x * 4 + wave;
+  const int nloc = it0 < nitems ? (int)((nitems - it0 + step - 1) / step) : 0;        // this wave's items
+  auto item_of = [&](int k) -> S3Item { return s3_item(s, it0 + (int64_t)k * step, wblocks); };
+  const int rowbytes = s.Wi * 6;
+  // DMA: instruction i moves raw chunks i*64 + lane (row = idx / 26, chunk = idx % 26; the 22 spare lanes repeat the last chunk)
+  int drow[4], dch[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = min(i * 64 + lane, nrows * S3D_RAWCH - 1);
+    drow[i] = idx / S3D_RAWCH;
+    dch[i] = idx - drow[i] * S3D_RAWCH;
+  }
+  auto issue = [&](int k) {
+    const S3Item q = item_of(k);
+    const unsigned dst = raw_lds + (unsigned)(k % S3D_NRAW) * S3D_RAWBUF;
+    const T* xn = x + (int64_t)q.n * s.xs_n;
+    const int ti0 = q.to * s.st - s.pt, hi0 = q.ho * s.sh - s.ph;
+    const int b0 = q.wo0 * 12 - 16;                                                  // raw byte 0 in row bytes
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int at = drow[i] / s.kh, ah = drow[i] - at * s.kh;
+      const int ti = min(max(ti0 + at, 0), s.Ti - 1), hi = min(max(hi0 + ah, 0), s.Hi - 1);   // rows / chunks outside: any valid
+      const int cb = min(max(b0 + 16 * dch[i], 0), rowbytes - 16);                                // address - masked when the slots are built
+      s3d_glds16((const unsigned char*)(xn + (int64_t)ti * s.xs_t + (int64_t)hi * s.xs_h) + cb, dst + i * 1024);
+    }
+  };
+  for (int k = 0; k < min(nloc, S3D_NRAW); ++k) issue(k);
+
+  for (int k = 0; k < nloc; ++k) {
+    const S3Item cur = item_of(k);
+    const int n = cur.n, to = cur.to, ho = cur.ho, wo0 = cur.wo0, npx = cur.npx;
+    // behind item k's DMAs: the DMAs of the items issued after it and one store per iteration since it was issued
+    {
+      const int behind = 4 * min(S3D_NRAW - 1, nloc - 1 - k) + min(k, S3D_NRAW);
+      switch (behind) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+      }
+    }
+    // ---- raw rows -> slot image
+    {
+      const unsigned char* raw = raw_w + (k % S3D_NRAW) * S3D_RAWBUF;
+      const int ti0 = to * s.st - s.pt, hi0 = ho * s.sh - s.ph, wi0 = wo0 * 2 - s.pw;
+#pragma unroll
+      for (int kk = 0; kk < S3_NT; ++kk) {
+        const int t = lane + 64 * kk;
+        const int r = t / S3_SP, sp = t - r * S3_SP;
+        if (r < nrows && sp < S3_SP - 1) {
+          const int at = r / s.kh, ah = r - at * s.kh;
+          const int ti = ti0 + at, hi = hi0 + ah;
+          const bool rowok = ti >= 0 && ti < s.Ti && hi >= 0 && hi < s.Hi;
+          const int wa = wi0 + 2 * sp, wb = wa + 1;
+          const bool oka = rowok && wa >= 0 && wa < s.Wi, okb = rowok && wb >= 0 && wb < s.Wi;
+          const unsigned* rp = reinterpret_cast<const unsigned*>(raw + r * S3D_RAWROW + 8 + 12 * sp);   // the slot's 12 bytes start at +2
+          const unsigned d0 = rp[0], d1 = rp[1], d2 = rp[2], d3 = rp[3];
+          unsigned o0 = __builtin_amdgcn_alignbit(d1, d0, 16), o1 = __builtin_amdgcn_alignbit(d2, d1, 16), o2 = __builtin_amdgcn_alignbit(d3, d2, 16);
+          // elements 0..2 = pixel wa, 3..5 = pixel wb
+          if (!oka) { o0 = 0u; o1 &= 0xffff0000u; }
+          if (!okb) { o1 &= 0x0000ffffu; o2 = 0u; }
+          *reinterpret_cast<u32x4*>(win + t * 8) = u32x4{o0, o1, o2, r == 0 ? 0x3f80u : 0u};
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    if (k + S3D_NRAW < nloc) issue(k + S3D_NRAW);                // this item's raw buffer is free again
+    f32x4 acc[2], accl[2];
+    acc[0] = acc[1] = accl[0] = accl[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const bf16x8 fa = *reinterpret_cast<const bf16x8*>(win + aoff[ks] + (mt * 16 + row) * 8);
+        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, wf[ks], acc[mt], 0, 0, 0);
+        accl[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, wl[ks], accl[mt], 0, 0, 0);
+      }
+    }
+    acc[0] += accl[0];
+    acc[1] += accl[1];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int p = mt * 16 + g * 4 + i;
+        const T tv = from_f32<T>(acc[mt][i]);
+        outt[p * OCB + row] = tv;
+        if (a.stats && p < npx) {
+          const float fv = to_f32(tv);
+          ssum += fv;
+          ssq += fv * fv;
+        }
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    {
+      // one 16-byte store per lane and item (SW_PIX * OCB / 8 = 64 chunks); lanes of a ragged block's missing pixels are off,
+      // lane 0 never is: exactly ONE store instruction per item in the vmcnt count
+      const int64_t pix0 = (((int64_t)n * s.To + to) * s.Ho + ho) * s.Wo + wo0;
+      const int p = lane * 8 / OCB;
+      if (p < npx) vec_store<T>(y + pix0 * OCB + (int64_t)lane * 8, vec_load<T>(outt + lane * 8));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (a.stats) {
+    ssum += __shfl_xor(ssum, 16, 64); ssum += __shfl_xor(ssum, 32, 64);
+    ssq += __shfl_xor(ssq, 16, 64); ssq += __shfl_xor(ssq, 32, 64);
+    if (lane < 16) {
+      red[wave][lane] = ssum;
+      red[wave][OCB + lane] = ssq;
+    }
+    __syncthreads();
+    if (tid < OCB) {
+      float* st = a.stats + (size_t)blockIdx.x * 2 * s.Cout;
+      st[tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+      st[s.Cout + tid] = (red[0][OCB + tid] + red[1][OCB + tid]) + (red[2][OCB + tid] + red[3][OCB + tid]);
+    }
+  }
+}
+
+// the DMA forward additionally needs 16-byte-aligned rows (pointer, strides) of whole chunks and the reference stem's 3x3 window rows
+bool stem3_dma_ok(const pb_stem_shape* s, const void* x) {
+  static const bool enabled = !(getenv("PB_STEM3_DMA") && atoi(getenv("PB_STEM3_DMA")) == 0);
+  return enabled && ((uintptr_t)x % 16) == 0 && s->xs_h % 8 == 0 && s->xs_t % 8 == 0 && s->xs_n % 8 == 0 && s->Wi % 8 == 0 &&
+         s->Wi >= 72 && s->kt * s->kh == S3_MAXROWS && s->Wo % 4 == 0 &&
+         (int64_t)s->xs_n * 2 < (1LL << 40);
+}
+
 bool stem3_ok(const pb_stem_shape* s, int x_dtype, pb_dtype dtype) {
   static const bool enabled = !(getenv("PB_STEM3") && atoi(getenv("PB_STEM3")) == 0);
   return enabled && x_dtype == 1 && dtype == PB_BF16 && s->Cin == 3 && s->kw == 3 && s->sw == 2 && s->pw == 1 &&
@@ -756,7 +960,14 @@ extern "C" int pb_stem_conv3d_fwd(const void* x, int x_dtype, float x_scale, con
     if (gx > 2048) gx = 2048;
     if (stats && gx > stat_slots) gx = stat_slots;             // one statistics slot per workgroup
     dim3 grid((unsigned)gx, (unsigned)pb_cdiv(s->Cout, OCB));
-    if (stem3_ok(s, x_dtype, dtype) && x_scale == 1.f) hipLaunchKernelGGL(stem3_fwd_kernel, grid, dim3(256), 0, st, a);
+    if (stem3_ok(s, x_dtype, dtype) && x_scale == 1.f && stem3_dma_ok(s, x)) {
+      static bool attr = false;
+      if (!attr) {
+        PB_HIP(hipFuncSetAttribute((const void*)stem3_fwd_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S3D_LDS));
+        attr = true;
+      }
+      hipLaunchKernelGGL(stem3_fwd_dma_kernel, grid, dim3(256), S3D_LDS, st, a);
+    } else if (stem3_ok(s, x_dtype, dtype) && x_scale == 1.f) hipLaunchKernelGGL(stem3_fwd_kernel, grid, dim3(256), 0, st, a);
     else PB_STEM_DISPATCH(stem_fwd_mfma_kernel, grid);
   } else {
     int64_t gx = pb_cdiv(a.npix, 256);
