@@ -170,6 +170,7 @@ def main():
         """Warm up, then capture fn() into a HIP graph on the same stream; returns (graph, fn's result)."""
         for _ in range(3):
             fn()
+        K.launch_count[0] = 0                 # counts the C-ABI calls of the captured step
         torch.cuda.synchronize()
         if dp_path and has_collective:
             # RCCL's watchdog thread polls the end events of the eager warm-up collectives; on ROCm that query fails with
@@ -210,10 +211,12 @@ def main():
     # captured once into a HIP graph and replayed; every replay does the full work on the same buffers.
     launch_mode = "eager"
     eager_step = step
+    abi_calls = None
     if use_graph:
         try:
             opt.zero_grad(set_to_none=True)
             graph, graph_loss = capture(step)
+            abi_calls = K.launch_count[0]                      # (capture() = 3 eager warm-up steps + the captured one: all equal)
 
             def step():  # noqa: F811
                 graph.replay()
@@ -441,6 +444,7 @@ def main():
                        "precision": "fp32 params, bf16 activations (autocast)", "parallelism": f"dp{world}",
                        "step": "fwd + CE loss + bwd + RCCL grad all-reduce (n>1) + fused AdamW (%s)" % ("picklebot_amd.FlatAdamW" if flat_opt else "torch fused"),
                        "launch": launch_mode,
+                       "c_abi_calls_per_step": abi_calls,      # entry points called per replayed step (a few launch 2-3 kernels; torch adds ~15 launches of its own)
                        "streams": ("each block's weight gradients on a second HIP stream beside the next block's data-gradient chain, "
                                    "joined when backward ends (kernels.weight_grad_branch; opted in by FlatAdamW / GradReducer)") if side_branches else "one",
 

@@ -34,7 +34,7 @@ typedef enum {
   PB_ACT_HSIGMOID = 4, PB_ACT_SILU = 5
 } pb_act;
 
-#define PB_ABI_VERSION 18
+#define PB_ABI_VERSION 19
 
 /* Determinism.  Nothing in this library accumulates with floating-point atomics: two runs of the same binary on the
  * same inputs give bit-identical outputs and gradients.  Every reduction that spans workgroups stores one partial
@@ -345,6 +345,10 @@ int pb_se_fused_fwd(const float* pool_part, int slots, float inv_count, const fl
 int pb_se_fused_bwd(const float* dscale_part, int slots, const float* pool, float inv_count, const float* scale,
                     const float* hidden, const float* w1, const float* w2, float* g_shift, float* dw1, float* db1,
                     float* dw2, float* db2, float* work, int G, int C, int Cm, int device, void* stream);
+/* dw1 == dw2 == NULL in pb_se_fused_bwd: only the per-clip vectors (g_shift, and `work` = dz2 | dh) are produced; the FC weight /
+ * bias gradients follow from `work` with pb_se_fc_bwd_w - later, or on another stream (nothing on the data-gradient chain reads them). */
+int pb_se_fc_bwd_w(const float* work, const float* pool, float inv_count, const float* hidden, float* dw1, float* db1, float* dw2,
+                   float* db2, int G, int C, int Cm, int device, void* stream);
 /* Row-group partial sums only (the first half of pb_rowgroup_reduce): part fp32 [slots][G][C] with
  * slots = pb_rowgroup_slots(...) for a consumer that adds the slots itself (pb_se_fused_bwd / pb_se_fused_fwd). */
 int pb_rowgroup_slots(int64_t G, int64_t rows_per_group, int C, pb_dtype dtype);

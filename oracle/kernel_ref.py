@@ -402,8 +402,14 @@ def rowgroup_partials(a, b, G):
     return rowgroup_reduce(a, b, G).unsqueeze(0)
 
 
-def se_fused_bwd(dscale_part, pool, inv_count, scale, hidden, w1, w2, want_bias=True):
-    return se_fc_bwd(dscale_part.sum(0), pool, inv_count, scale, hidden, w1, w2, want_bias)
+def se_fused_bwd(dscale_part, pool, inv_count, scale, hidden, w1, w2, want_bias=True, defer_weights=False):
+    out = se_fc_bwd(dscale_part.sum(0), pool, inv_count, scale, hidden, w1, w2, want_bias)
+    if defer_weights:          # (the product launches the FC weight gradients later, from the block's weight-gradient branch)
+        def weights():
+            pass
+        weights.keep = ()
+        return out + (weights,)
+    return out
 
 
 def se_fc_bwd(dscale, pool, inv_count, scale, hidden, w1, w2, want_bias=True):

@@ -582,7 +582,8 @@ void rows_fwd_geom(RowsArgs& a, int K, int WSEG) {
   const int64_t per_frame = (int64_t)a.CP * a.nseg;
   const int64_t frames = (int64_t)a.N * a.Tdst;
   // enough threads for ~8 waves per SIMD... bands of rows (multiples of K) when the frames alone are too few
-  int nbands = (int)pb_cdiv(160 * 1024, per_frame * frames);
+  static const int want = getenv("PB_DW_ROWS_THREADS") ? atoi(getenv("PB_DW_ROWS_THREADS")) : 160 * 1024;
+  int nbands = (int)pb_cdiv(want, per_frame * frames);
   const int max_bands = (int)pb_cdiv(a.Hd, 2 * K);
   if (nbands > max_bands) nbands = max_bands;
   if (nbands < 1) nbands = 1;

@@ -436,7 +436,7 @@ extern "C" int pb_se_fused_bwd(const float* dscale_part, int slots, const float*
                                const float* hidden, const float* w1, const float* w2, float* g_shift, float* dw1,
                                float* db1, float* dw2, float* db2, float* work, int G, int C, int Cm, int device,
                                void* stream) {
-  PB_CHECK_ARG(dscale_part && pool && scale && hidden && w1 && w2 && g_shift && dw1 && dw2 && work && slots >= 1,
+  PB_CHECK_ARG(dscale_part && pool && scale && hidden && w1 && w2 && g_shift && work && slots >= 1 && (!dw1 == !dw2),
                "pb_se_fused_bwd: null pointer / bad slots");
   PB_CHECK_ARG(G > 0 && G <= 65535 && C > 0 && Cm > 0 && C <= 8192 && Cm <= 8192, "pb_se_fused_bwd: bad sizes G=%d C=%d Cm=%d", G, C, Cm);
   PB_ENTER(device);
@@ -444,8 +444,24 @@ extern "C" int pb_se_fused_bwd(const float* dscale_part, int slots, const float*
   SeBwdArgs a = {dscale_part, slots, inv_count, scale, hidden, w1, w2, g_shift, work, G, C, Cm, se_assoc()};
   hipLaunchKernelGGL(se_bwd_dh_kernel, dim3((unsigned)pb_cdiv(Cm, 64), (unsigned)G), dim3(SEB_T), ((size_t)C + SEB_T) * 4, st, a);
   hipLaunchKernelGGL(se_bwd_gshift_kernel, dim3((unsigned)pb_cdiv(C, 64), (unsigned)G), dim3(SEB_T), ((size_t)Cm + SEB_T) * 4, st, a);
+  if (dw1) {      // (dw1 == dw2 == NULL: the weight gradients are left to pb_se_fc_bwd_w - off the data-gradient chain)
+    const int64_t total = 2LL * C * Cm + C + Cm;
+    hipLaunchKernelGGL(se_fc_bwd_w_kernel, dim3((unsigned)pb_cdiv(total, 256)), dim3(256), 0, st, (const float*)work, pool,
+                       inv_count, hidden, dw1, db1, dw2, db2, G, C, Cm);
+  }
+  PB_LAUNCH_CHECK();
+  return 0;
+}
+
+// The weight / bias gradients of the two squeeze-excite FCs from the `work` vectors pb_se_fused_bwd left ([G][C + Cm]: dz2, dh):
+// nothing on the data-gradient chain reads them, so a caller can launch this later / on another stream.
+extern "C" int pb_se_fc_bwd_w(const float* work, const float* pool, float inv_count, const float* hidden, float* dw1, float* db1,
+                              float* dw2, float* db2, int G, int C, int Cm, int device, void* stream) {
+  PB_CHECK_ARG(work && pool && hidden && dw1 && dw2, "pb_se_fc_bwd_w: null pointer");
+  PB_CHECK_ARG(G > 0 && G <= 65535 && C > 0 && Cm > 0 && C <= 8192 && Cm <= 8192, "pb_se_fc_bwd_w: bad sizes G=%d C=%d Cm=%d", G, C, Cm);
+  PB_ENTER(device);
   const int64_t total = 2LL * C * Cm + C + Cm;
-  hipLaunchKernelGGL(se_fc_bwd_w_kernel, dim3((unsigned)pb_cdiv(total, 256)), dim3(256), 0, st, (const float*)work, pool,
+  hipLaunchKernelGGL(se_fc_bwd_w_kernel, dim3((unsigned)pb_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, work, pool,
                      inv_count, hidden, dw1, db1, dw2, db2, G, C, Cm);
   PB_LAUNCH_CHECK();
   return 0;

@@ -273,12 +273,12 @@ class _Bottleneck(torch.autograd.Function):
         if need_grad:
             ctx.cfg, ctx.bnc, ctx.dims = cfg, bnc, (N, T, H, W, Cin, E, Cout, To, Ho, Wo)
             ctx.compact, ctx.dconv, ctx.fmap = compact, (dkernel, dstride, dpad), fmap
-            ctx.save_for_backward(xs5, e5, d5, z2, w1, wdw, w2, se_w1, se_w2, pool, se_scale, hidden, gamma, drop)
+            ctx.save_for_backward(xs5, e5, d5, z2, w1, wdw, w2, se_w1, se_w2, pool, se_scale, hidden, gamma, drop, se_b1, se_b2)
         return y2.view(N, To, Ho, Wo, Cout)
 
     @staticmethod
     def backward(ctx, dy5):
-        x5, e5, d5, z2, w1, wdw, w2, se_w1, se_w2, pool, se_scale, hidden, gamma, drop = ctx.saved_tensors
+        x5, e5, d5, z2, w1, wdw, w2, se_w1, se_w2, pool, se_scale, hidden, gamma, drop, se_b1, se_b2 = ctx.saved_tensors
         cfg, bnc = ctx.cfg, ctx.bnc
         N, T, H, W, Cin, E, Cout, To, Ho, Wo = ctx.dims
         kernel, stride, pad = cfg["kernel"], cfg["stride"], cfg["pad"]
@@ -297,6 +297,7 @@ class _Bottleneck(torch.autograd.Function):
         d2 = d5.view(-1, E)
         dw2, dwdw, dw1 = _zeros_many(x5, (Cout, E), (E, wdw[0].numel()), (E, Cin))
         g_scale = g_shift = dse_w1 = dse_b1 = dse_w2 = dse_b2 = None
+        se_keep = ()
         # The chain (data gradients) runs here; the three weight gradients are collected and issued as one branch at the
         # end (K.weight_grad_branch: their partial tiles are added up by ONE launch; on a side stream when that is safe).
         wgrads = []
@@ -306,10 +307,16 @@ class _Bottleneck(torch.autograd.Function):
         if has_se:
             Cm = se_w1.shape[0]
             dpart = K.rowgroup_partials(dS2, d2, N)
-            g_shift, dse_w1, dse_b1, dse_w2, dse_b2 = K.se_fused_bwd(dpart, pool, 1.0 / R2, se_scale, hidden,
-                                                                     se_w1.view(Cm, E), se_w2.view(E, Cm))
+            # (the FC weight / bias gradients are not on the chain: their launch joins the block's weight-gradient branch)
+            g_shift, dse_w1, dse_b1, dse_w2, dse_b2, se_wg = K.se_fused_bwd(dpart, pool, 1.0 / R2, se_scale, hidden,
+                                                                            se_w1.view(Cm, E), se_w2.view(E, Cm), defer_weights=True)
+            wgrads.append(se_wg)
+            se_keep = se_wg.keep
             g_scale = se_scale
             dse_w1, dse_w2 = dse_w1.view_as(se_w1), dse_w2.view_as(se_w2)
+            # (fresh views for the biases too: the deferred launch still holds the buffers, and a gradient object somebody else
+            # holds is CLONED by autograd - on the calling stream, at once)
+            dse_b1, dse_b2 = dse_b1.view_as(se_b1), dse_b2.view_as(se_b2)
         dS5 = dS2.view(N, Td, Ho, Wo, E)
         dkernel, dstride, dpad = ctx.dconv       # (x5 here = the gathered frames when the block skips input frames)
         held = ()
@@ -333,8 +340,9 @@ class _Bottleneck(torch.autograd.Function):
             dx5 = K.pw_fwd(dE2, w1.view(E, Cin), w_transposed=True).view(N, Ts, H, W, Cin)
             if compact is not None and Ts != T:       # exact zeros in the input frames the block never read
                 dx5 = K.frames_scatter(dx5, T, compact[0], compact[1])
-        K.weight_grad_branch(dE2, (w1, wdw, w2), wgrads,
-                             (dz, d2, dS2, e5, x5, dE2, w1, se_scale, g_scale, g_shift, dw2, dwdw, dw1), "bneck", held=held)
+        se_params = (se_w1, se_b1, se_w2, se_b2) if has_se else ()
+        K.weight_grad_branch(dE2, (w1, wdw, w2) + se_params, wgrads,
+                             (dz, d2, dS2, e5, x5, dE2, w1, se_scale, g_scale, g_shift, dw2, dwdw, dw1, se_keep), "bneck", held=held)
         return (dx5, dw1.view_as(w1), dwdw.view_as(wdw), dw2.view_as(w2), dse_w1, dse_b1, dse_w2, dse_b2, dgamma,
                 dbeta, None, None, None, None)
 

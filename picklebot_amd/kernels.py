@@ -103,8 +103,12 @@ def _nb(*ts):
 _SYNC_DEBUG = os.environ.get("PB_SYNC_DEBUG", "0") != "0"    # print every launch and synchronise after it (fault / hang hunting)
 
 
+launch_count = [0]          # C-ABI calls so far (bench.py reports how many one captured step makes)
+
+
 def _launch(family, nbytes, fn, *args, detail=""):
     """Algorithmic bytes = every external input/output tensor once at its stored dtype."""
+    launch_count[0] += 1
     if _SYNC_DEBUG:
         print(f"[pb] {fn} {family} {detail}", flush=True)
         _C.call(fn, *args)
@@ -1195,8 +1199,10 @@ def rowgroup_partials(a, b, G):
     return part
 
 
-def se_fused_bwd(dscale_part, pool, inv_count, scale, hidden, w1, w2, want_bias=True):
-    """dscale_part fp32 [slots,G,C] -> (g_shift [G,C], dw1, db1, dw2, db2): two launches (per-clip vectors; weight grads)."""
+def se_fused_bwd(dscale_part, pool, inv_count, scale, hidden, w1, w2, want_bias=True, defer_weights=False):
+    """dscale_part fp32 [slots,G,C] -> (g_shift [G,C], dw1, db1, dw2, db2): the per-clip vectors (two launches) and the FC weight
+    gradients (one).  defer_weights: the weight-gradient launch is NOT issued; a sixth return value is the thunk that issues it
+    (pb_se_fc_bwd_w) - for the block's weight-gradient branch: nothing on the data-gradient chain reads these gradients."""
     dscale_part = _few_slots(dscale_part)
     slots, G, C = dscale_part.shape
     Cm = w1.shape[0]
@@ -1211,6 +1217,16 @@ def se_fused_bwd(dscale_part, pool, inv_count, scale, hidden, w1, w2, want_bias=
     db1, db2 = flat[2 * C * Cm:2 * C * Cm + Cm], flat[2 * C * Cm + Cm:]
     work = torch.empty(G * (C + Cm), dtype=torch.float32, device=dev_t)
     dev, st = _dev_stream(pool)
+    if defer_weights:
+        _launch("se_fused_bwd", _nb(dscale_part, w1, w2), "pb_se_fused_bwd", _p(dscale_part), slots, _p(pool), float(inv_count),
+                _p(scale), _p(hidden), _p(w1), _p(w2), _p(g_shift), None, None, None, None, _p(work), G, C, Cm, dev, st)
+
+        def weights():
+            d2, s2 = _dev_stream(pool)
+            _launch("se_fc_bwd_w", _nb(dw1, dw2), "pb_se_fc_bwd_w", _p(work), _p(pool), float(inv_count), _p(hidden), _p(dw1),
+                    _p(db1) if want_bias else None, _p(dw2), _p(db2) if want_bias else None, G, C, Cm, d2, s2)
+        weights.keep = (work, pool, hidden, flat)
+        return g_shift, dw1, (db1 if want_bias else None), dw2, (db2 if want_bias else None), weights
     _launch("se_fused_bwd", _nb(dscale_part, w1, w2, dw1, dw2), "pb_se_fused_bwd", _p(dscale_part), slots, _p(pool), float(inv_count),
             _p(scale), _p(hidden), _p(w1), _p(w2), _p(g_shift), _p(dw1), _p(db1) if want_bias else None, _p(dw2),
             _p(db2) if want_bias else None, _p(work), G, C, Cm, dev, st)
