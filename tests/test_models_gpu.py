@@ -780,3 +780,25 @@ def test_parameter_with_two_weight_gradient_nodes_in_one_pass():
     assert K.branch_counts == {"side": 1, "inline": 1}, K.branch_counts
     assert not K._lag and not K._seen
     assert torch.equal(dx_ref, dx) and all(torch.equal(ref[k], got[k]) for k in ref)
+
+
+def test_bench_data_parallel_path_on_one_gpu(tmp_path):
+    """The path the 8-GPU run takes, at world size 1 over RCCL (PB_BENCH_FORCE_DP=1): bench.py builds the reducer, captures
+    forward + backward into a HIP graph BEFORE the process group exists (ProcessGroupNCCL's watchdog thread polling events
+    during a capture aborted the process 1 run in 6-10 on this stack), binds the group, replays + all-reduces + steps, and
+    prints ONE JSON line last on stdout."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, PB_BENCH_FORCE_DP="1", MASTER_PORT="29533")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--batch", "4", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    d = json.loads(lines[-1])                            # (RCCL prints a version banner first; the JSON line is the LAST line)
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["clips_per_gpu"] == 4
+    assert "captured before the process group exists" in d["config"]["launch"], d["config"]["launch"]
+    assert d["roofline"]["kernel"] and d["roofline"]["frac"] > 0

@@ -150,3 +150,61 @@ def test_grad_reducer_world2_gloo():
         p.join(120)
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     assert sorted(q.get(timeout=5)[0] for _ in range(2)) == [0, 1]
+
+
+def _worker_bind_later(rank, world, port, q):
+    """bench.py's data-parallel order (round 4): reducer and `recorded step` first, process group afterwards."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from picklebot_amd.parallel import GradReducer, setup_distributed
+    assert not dist.is_initialized()
+    model = _model(seed=200 + rank)                      # replicas start DIFFERENT
+    red = GradReducer(model, bucket_bytes=2048, bind_later=True)      # no process group yet: no collective may be issued
+    torch.manual_seed(9)
+    data, target = torch.randn(world, 6, 12), torch.randn(world, 6, 5)
+    # the "captured" part of a step works without a process group: backward with the hooks off + one copy per bucket
+    red.detach_grads()
+    with red.no_sync():
+        nn.functional.mse_loss(model(data[rank]), target[rank]).backward()
+    red.pack_grads()
+    try:
+        red.reduce_now()
+        raise AssertionError("reduce_now() before bind() must refuse")
+    except RuntimeError as e:
+        assert "bind()" in str(e)
+    setup_distributed("gloo")                            # the process group (and, with RCCL, its watchdog thread) starts HERE
+    red.bind()                                           # world size + broadcast of rank 0's parameters
+    ref = _model(seed=200)
+    assert red.world == world and all(torch.equal(a, b) for a, b in zip(model.parameters(), ref.parameters()))
+    # a full step in the replay form after binding
+    red.detach_grads()
+    with red.no_sync():
+        nn.functional.mse_loss(model(data[rank]), target[rank]).backward()
+    red.pack_grads()
+    red.reduce_now()
+    red.attach_grads()
+    mine = [p.grad.clone() for p in model.parameters()]
+    m = _model(seed=200)
+    nn.functional.mse_loss(m(data[rank]), target[rank]).backward()
+    want = [p.grad.clone() for p in m.parameters()]
+    gathered = [[torch.zeros_like(g) for _ in range(world)] for g in want]
+    for g, outs in zip(want, gathered):
+        dist.all_gather(outs, g)
+    for got, outs in zip(mine, gathered):
+        assert torch.allclose(got, sum(outs) / world, atol=1e-6), "bind_later: averaged gradient mismatch"
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, "ok"))
+
+
+def test_grad_reducer_bound_after_the_step_was_recorded_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_bind_later, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert sorted(q.get(timeout=5)[0] for _ in range(2)) == [0, 1]
