@@ -520,31 +520,77 @@ bool fused_ok(const pb_dwconv_shape* s, pb_dtype dtype) {
          s->To == s->Ti + 2 * s->pt && (int64_t)s->Wi * s->C < (1 << 24) && !(s->Hi == 7 && s->Wi == 7);
 }
 
-int64_t fused_geom(RowsFusedArgs& a, int K, int64_t* slots) {
+// Workgroups that are co-resident on the chip for this kernel (occupancy x CUs), cached per instantiation.
+template <typename KernelT>
+int fused_resident(KernelT k) {
+  static int cached = 0;
+  if (cached == 0) {
+    int per_cu = 0, cus = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, 256, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+    cached = per_cu * cus;
+  }
+  return cached;
+}
+
+// Geometry (frame groups FG x row bands) by ROUNDS, round 4: the launch time of these kernels is a staircase in
+// ceil(workgroups / resident workgroups) (profiles/r04_dw_staircase_*.txt: 768 workgroups on 512 slots cost two rounds), so
+// the split is chosen to minimise  rounds x frames per thread x (rows per band + halo)  - e.g. 195 frame groups = exactly
+// 512 workgroups with 3 frames per thread for the 14x14x672 layer instead of 256 groups = 672 workgroups = two rounds of 2.
+int64_t fused_geom(RowsFusedArgs& a, int K, int64_t* slots, int resident = 512) {
   const int WSEG = fused_wseg(K);
   a.CP = a.C / 2;
   a.nseg = (int)pb_cdiv(a.W, WSEG);
   const int64_t per_frame = (int64_t)a.CP * a.nseg;
   const int64_t frames = (int64_t)a.N * a.T;
+  static const bool by_rounds = !(getenv("PB_DW_FUSED_ROUNDS") && atoi(getenv("PB_DW_FUSED_ROUNDS")) == 0);
   static const int want = getenv("PB_DW_FUSED_THREADS") ? atoi(getenv("PB_DW_FUSED_THREADS")) : 128 * 1024;
-  int nbands = 1;
-  const int max_bands = (int)pb_cdiv(a.H, 2 * K);
-  int64_t fgroups = pb_cdiv(want, per_frame);
-  if (fgroups > frames) {
-    nbands = (int)pb_cdiv(fgroups, frames);
-    if (nbands > max_bands) nbands = max_bands;
-    fgroups = frames;
+  int best_fg = 1, best_nb = 1;
+  if (by_rounds) {
+    double best = 1e30;
+    const int max_bands = (int)pb_cdiv(a.H, 2 * K);
+    // time ~ rounds x (start-up + frames per thread x rows per band): for every (bands, rounds) the LARGEST number of frame
+    // groups whose workgroups still fit that many rounds; start-up of a workgroup (weights, first rows, ramp) ~ 8 row steps
+    constexpr double STARTUP = 8.0;
+    for (int nb = 1; nb <= max_bands && nb <= 4; ++nb) {
+      const int band_rows = (int)pb_cdiv(pb_cdiv(a.H, nb), K) * K;
+      const int nbe = (int)pb_cdiv(a.H, band_rows);
+      if (nb > 1 && nbe != nb) continue;
+      for (int r = 1; r <= 4; ++r) {
+        int64_t fg = ((int64_t)r * resident * 256) / (nbe * per_frame);        // blocks(fg) <= r * resident
+        if (fg > frames) fg = frames;
+        if (a.CP > 256 && fg * nbe * a.nseg > 512) fg = 512 / ((int64_t)nbe * a.nseg);      // partial-gradient slots (12 MB at C = 672)
+        if (fg < 1) continue;
+        const int64_t fpt = pb_cdiv(frames, fg);
+        const int64_t blocks = pb_cdiv(fg * nbe * per_frame, 256);
+        const int64_t rounds = pb_cdiv(blocks, resident);
+        const double cost = (double)rounds * (STARTUP + (double)fpt * (band_rows + K - 1));
+        if (cost < best - 1e-9) { best = cost; best_fg = (int)fg; best_nb = nbe; }
+        if (fg == frames) break;
+      }
+    }
+  } else {
+    int nbands = 1;
+    const int max_bands = (int)pb_cdiv(a.H, 2 * K);
+    int64_t fgroups = pb_cdiv(want, per_frame);
+    if (fgroups > frames) {
+      nbands = (int)pb_cdiv(fgroups, frames);
+      if (nbands > max_bands) nbands = max_bands;
+      fgroups = frames;
+    }
+    if (a.CP > 256) {
+      const int64_t writer_cap = pb_cdiv(512, (int64_t)a.nseg * nbands);
+      if (fgroups > writer_cap) fgroups = writer_cap;
+    }
+    best_fg = (int)(fgroups < 1 ? 1 : fgroups);
+    best_nb = nbands;
   }
-  if (a.CP > 256) {                 // one partial gradient per (frame group, band, segment): at most 512 of them (12 MB at C = 672)
-    const int64_t writer_cap = pb_cdiv(512, (int64_t)a.nseg * nbands);
-    if (fgroups > writer_cap) fgroups = writer_cap;
-  }
-  if (fgroups < 1) fgroups = 1;
-  a.band_rows = (int)pb_cdiv(pb_cdiv(a.H, nbands), K) * K;
+  a.band_rows = (int)pb_cdiv(pb_cdiv(a.H, best_nb), K) * K;
   a.nbands = (int)pb_cdiv(a.H, a.band_rows);
-  a.FG = (int)fgroups;
-  const int64_t blocks = pb_cdiv(fgroups * a.nbands * per_frame, 256);
-  *slots = a.CP <= 256 ? blocks : fgroups * a.nbands * a.nseg;
+  a.FG = best_fg;
+  const int64_t blocks = pb_cdiv((int64_t)a.FG * a.nbands * per_frame, 256);
+  *slots = a.CP <= 256 ? blocks : (int64_t)a.FG * a.nbands * a.nseg;
   return blocks;
 }
 
@@ -762,12 +808,17 @@ int pb_dw_rows_fwd(const void* src, const float* w, void* dst, const pb_dwconv_s
 #undef PB_ROWS
 }
 
+// (one resident count per kernel size - the PRO variants differ by a few registers, the geometry must not depend on them)
+static int fused_resident_of(int K) {
+  return K == 3 ? fused_resident(dw_rows_bwd_fused_kernel<3, fused_wseg(3), true>) : fused_resident(dw_rows_bwd_fused_kernel<5, fused_wseg(5), true>);
+}
+
 // backward-data + weight gradient in one launch (bf16, (1,k,k), stride 1): 0 slots = shape not taken
 int64_t pb_dw_rows_bwd_fused_slots(const pb_dwconv_shape* s, pb_dtype dtype) {
   if (!fused_ok(s, dtype)) return 0;
   RowsFusedArgs a = fused_args(s);
   int64_t slots = 0;
-  fused_geom(a, s->kh, &slots);
+  fused_geom(a, s->kh, &slots, fused_resident_of(s->kh));
   return slots;
 }
 
@@ -776,7 +827,7 @@ int pb_dw_rows_bwd_fused(const void* dy, const void* x, const float* w, void* dx
   if (!fused_ok(s, dtype)) return -1;
   RowsFusedArgs a = fused_args(s);
   a.x = x; a.dy = dy; a.dx = dx; a.w = w; a.dw = part; a.g_scale = g_scale; a.g_shift = g_shift;
-  const int64_t blocks = fused_geom(a, s->kh, slots);
+  const int64_t blocks = fused_geom(a, s->kh, slots, fused_resident_of(s->kh));
   const bool pro = g_scale || g_shift;
   const dim3 grid((unsigned)blocks);
   if (s->kh == 3) {
