@@ -34,7 +34,7 @@ typedef enum {
   PB_ACT_HSIGMOID = 4, PB_ACT_SILU = 5
 } pb_act;
 
-#define PB_ABI_VERSION 19
+#define PB_ABI_VERSION 20
 
 /* Determinism.  Nothing in this library accumulates with floating-point atomics: two runs of the same binary on the
  * same inputs give bit-identical outputs and gradients.  Every reduction that spans workgroups stores one partial
@@ -106,6 +106,13 @@ int pb_pw_weight_prep_batch(const int64_t* desc, int count, int device, void* st
 int pb_pwconv_fwd_bf16w(const void* x, const void* wb, void* y, int64_t M, int K, int N, int groups,
                         int64_t rows_per_group, const float* out_scale, const float* out_shift, pb_act out_act,
                         float out_slope, float* stats, const void* residual, int device, void* stream);
+/* K = 16 layers, four rows per 128-byte line: x [M][16] is the same memory as [M/4][64] and y [M][N] as [M/4][4N] =
+ * X' * blockdiag(B,B,B,B)^T - a full-width K = 64 product on a quarter of the rows (the kernel is HBM-bound; the MFMA work
+ * on the zero blocks is free).  wb4: the block-diagonal bf16 matrix [4N][64] (pb_pw_weight_prep_many mode 2 / 3).
+ * stats (may be NULL): [slots][2][N] as for pb_pwconv_fwd - the four column replicas of a channel are added up inside
+ * the workgroup before its slot is written.  M % 4 == 0, N % 8 == 0, N <= 24. */
+int pb_pwconv_fwd_fold4(const void* x, const void* wb4, void* y, int64_t M, int N, pb_act out_act, float out_slope,
+                        float* stats, int device, void* stream);
 /* Which kernel pb_pwconv_fwd_bf16w runs for a shape: 1 = the weight-stationary streaming kernel (pw_stream_kernel: one
  * weight matrix, K <= 160), 2 = its long-reduction form (pw_stream_wide_kernel: the output columns spread over the waves),
  * 0 = the LDS-DMA ring kernel (pw_gemm_dma_kernel).  For profilers' labels; no device work. */

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libpicklebot_amd.so")
 
 PB_F32, PB_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY_RELU, ACT_HSWISH, ACT_HSIGMOID, ACT_SILU = range(6)
-ABI_VERSION = 19
+ABI_VERSION = 20
 STAT_SLOTS = 512
 
 
@@ -70,6 +70,7 @@ SIGNATURES = {
     "pb_pw_weight_prep": [P, I, I, I, P, I, P, I, P],
     "pb_pw_weight_prep_batch": [P, I, I, P],
     "pb_pwconv_fwd_bf16w": [P, P, P, L, I, I, I, L, P, P, I, F, P, P, I, P],
+    "pb_pwconv_fwd_fold4": [P, P, P, L, I, I, F, P, I, P],
     "pb_unfold_fold": [P, P, I, I, I, I, I, I, I, I, I, I, I, P],
     "pb_layernorm": [P, P, P, P, L, I, F, I, I, I, P],
     "pb_copy_cols": [P, L, I, P, L, I, L, I, I, I, I, P],

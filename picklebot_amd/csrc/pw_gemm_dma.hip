@@ -543,7 +543,7 @@ extern "C" int pb_pw_weight_prep_batch(const int64_t* desc, int count, int devic
 __attribute__((visibility("hidden"))) int pb_pw_stream_fwd(const void* x, const void* wb, void* y, int64_t M, int K, int N,
                                                            const float* out_scale, const float* out_shift, pb_act out_act,
                                                            float out_slope, float* stats, const void* residual, int device,
-                                                           hipStream_t st);
+                                                           hipStream_t st, int stat_fold = 1);
 
 __attribute__((visibility("hidden"))) int pb_pw_stream_wide_fwd(const void* x, const void* wb, void* y, int64_t M, int K, int N,
                                                                 int groups, int64_t rows_per_group, const float* out_scale,
@@ -617,6 +617,24 @@ extern "C" int pb_pwconv_fwd_bf16w(const void* x, const void* wb, void* y, int64
 __attribute__((visibility("hidden"))) int pb_conv3d_halo_fwd(const void* x, const void* wb, void* y, const pb_conv_shape* s,
                                                              const void* zero16, const float* out_scale, const float* out_shift,
                                                              pb_act out_act, float out_slope, float* stats, int device, hipStream_t st);
+
+extern "C" int pb_pwconv_fwd_fold4(const void* x, const void* wb4, void* y, int64_t M, int N, pb_act out_act, float out_slope,
+                                   float* stats, int device, void* stream) {
+  PB_CHECK_ARG(x && wb4 && y, "pb_pwconv_fwd_fold4: null pointer");
+  PB_CHECK_ARG(M > 0 && M % 4 == 0 && N > 0 && N % 8 == 0 && 4 * N <= 96, "pb_pwconv_fwd_fold4: M %% 4 == 0, N %% 8 == 0, N <= 24 (M=%lld N=%d)",
+               (long long)M, N);
+  PB_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)wb4 % 16) == 0, "pb_pwconv_fwd_fold4: unaligned pointer");
+  PB_ENTER(device);
+  const int rc = pb_pw_stream_fwd(x, wb4, y, M / 4, 64, 4 * N, nullptr, nullptr, out_act, out_slope, stats, nullptr, device, (hipStream_t)stream,
+                                  stats ? 4 : 1);
+  if (rc > 0) return rc;
+  if (rc < 0) {
+    pb_set_error("pb_pwconv_fwd_fold4: shape not taken by the streaming kernel (M=%lld N=%d)", (long long)M, N);
+    return 1;
+  }
+  PB_LAUNCH_CHECK();
+  return 0;
+}
 
 // Dense Conv3d (groups = 1, stride 1) as implicit GEMM on the same kernel: M = output voxels, K = taps*Cin.
 extern "C" int pb_conv3d_fwd_bf16w(const void* x, const void* wb, void* y, const pb_conv_shape* s, const void* zero16,

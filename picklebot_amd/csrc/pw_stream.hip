@@ -7,7 +7,7 @@ __attribute__((visibility("hidden"))) int pb_pw_stream_stats_launch(const void* 
 namespace {
 
 // (column tile, column groups per workgroup) for a shape, or false when the streaming kernel does not take it
-bool stream_choice(int64_t M, int K, int N, bool stats, int* nt_out, int* cg_out) {
+bool stream_choice(int64_t M, int K, int N, bool stats, int* nt_out, int* cg_out, bool one_column = false) {
   static const int on = getenv("PB_GEMM_STREAM") ? atoi(getenv("PB_GEMM_STREAM")) : 1;
   static const int force_cg = getenv("PB_GEMM_STREAM_CG") ? atoi(getenv("PB_GEMM_STREAM_CG")) : 0;
   if (!on || K > 160 || K % 8 || N % 8 || M < 1024) return false;
@@ -22,7 +22,7 @@ bool stream_choice(int64_t M, int K, int N, bool stats, int* nt_out, int* cg_out
     for (int c = (cg == 1 ? 1 : 4); c <= kMaxNT[stats][ks]; ++c) {
       const int64_t tiles = pb_cdiv(N, c * 16);
       const int64_t wgc = pb_cdiv(tiles, cg);
-      if (8 * wgc > 256) continue;
+      if (8 * wgc > 256 || (one_column && (wgc != 1 || tiles > cg))) continue;
       int64_t q = 256 / (8 * wgc);
       if (q > groups) q = groups;
       const double occupancy = (double)(8 * wgc * q) / 256.0;
@@ -53,14 +53,15 @@ extern "C" int pb_pwconv_fwd_bf16w_path(int64_t M, int K, int N, int groups, int
 __attribute__((visibility("hidden"))) int pb_pw_stream_fwd(const void* x, const void* wb, void* y, int64_t M, int K, int N,
                                                            const float* out_scale, const float* out_shift, pb_act out_act,
                                                            float out_slope, float* stats, const void* residual, int device,
-                                                           hipStream_t st) {
+                                                           hipStream_t st, int stat_fold) {
   int best_nt, best_cg;
-  if (!stream_choice(M, K, N, stats != nullptr, &best_nt, &best_cg)) return -1;
+  if (!stream_choice(M, K, N, stats != nullptr, &best_nt, &best_cg, stat_fold > 1)) return -1;
   const int ks = (K + 31) / 32;
   StreamArgs a = {};
   a.X = (const bf16_t*)x; a.WB = (const bf16_t*)wb; a.Y = (bf16_t*)y; a.R = (const bf16_t*)residual;
   a.M = M; a.K = K; a.N = N;
   a.out_scale = out_scale; a.out_shift = out_shift; a.out_act = (int)out_act; a.out_slope = out_slope; a.stats = stats;
+  a.stat_fold = stat_fold;
   a.n_tiles = (int)pb_cdiv(N, best_nt * 16);
   return stats ? pb_pw_stream_stats_launch(&a, ks, best_nt, best_cg, device, st) : dispatch_ks<false>(a, ks, best_nt, best_cg, device, st);
 }

@@ -40,6 +40,8 @@ struct StreamArgs {
   int out_act;
   float out_slope;
   float* stats;
+  int stat_fold;             // > 1: columns n and n + N/stat_fold (+ ...) are replicas of ONE channel (the 4-rows-per-line form of
+                             // K = 16 layers): their sums fold into stats [slots][2][N/stat_fold]; all columns in one workgroup
   int n_tiles, m_tiles;      // column tiles of BN, row panels of SBM
   int wgc;                   // workgroup columns = ceil(n_tiles / CG)
   int q;                     // grid = 8 * wgc * q: a workgroup's row panels are (g0 + i*q)*8 + (blockIdx & 7)
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(STHREADS) void pw_stream_kernel(StreamArgs a) {
   for (int j = 0; j < (STATS ? NT : 1); ++j) csum[j] = csq[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // one 16-row block: multiply, convert, exchange, store
-  auto block = [&](auto plain_tag, const unsigned char* Ab, int64_t m, T* yrow, const T* rrow) {
+  auto block = [&](auto plain_tag, const unsigned char* Ab, int64_t m, bool full, T* yrow, const T* rrow) {
     constexpr bool PLAIN = decltype(plain_tag)::value;
     bf16x8 af[KS];
 #pragma unroll
@@ -226,15 +228,27 @@ __global__ __launch_bounds__(STHREADS) void pw_stream_kernel(StreamArgs a) {
       }
 #undef PB_ACT_CASE
     }
-    u32x2 pk[NT];
+    if constexpr (STATS) {
+      // (fp32 values, before the bf16 rounding of the store.)  Only the last block of the matrix can hold rows past M: the
+      // test for it is wave-uniform - per-lane selects of 8*NT sums were two thirds of this kernel's statistics cost
+      if (full) {
+        asm volatile("");                             // (keeps the branch: hipcc otherwise if-converts both arms back into selects)
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      if constexpr (STATS) {
-        if (m_ok) {                                   // (fp32 values, before the bf16 rounding of the store)
+        for (int j = 0; j < NT; ++j) {
+          csum[j] += acc[j];
+          csq[j] += acc[j] * acc[j];
+        }
+      } else if (m_ok) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
           csum[j] += acc[j];
           csq[j] += acc[j] * acc[j];
         }
       }
+    }
+    u32x2 pk[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
       const bf16x4 o = __builtin_convertvector(acc[j], bf16x4);
       pk[j] = __builtin_bit_cast(u32x2, o);
     }
@@ -308,21 +322,22 @@ __global__ __launch_bounds__(STHREADS) void pw_stream_kernel(StreamArgs a) {
     const unsigned char* As = smem + cbuf * stage_bytes;
     if (++cbuf == NS) cbuf = 0;
     if (active) {
-      const int64_t m = (int64_t)((g0 + ct * a.q) * 8 + r8) * SBM + rg * (16 * RB) + frow;
+      const int64_t mb = (int64_t)((g0 + ct * a.q) * 8 + r8) * SBM + rg * (16 * RB);      // (wave-uniform)
+      const int64_t m = mb + frow;
       T* yrow = a.Y + m * a.N + n0;
       const T* rrow = a.R ? a.R + m * a.N + n0 : nullptr;
       // (rolled: an unrolled loop hoists every block's fragment loads and spills the weight slice)
       if (plain) {
 #pragma unroll 1
         for (int rb = 0; rb < RB; ++rb) {
-          block(std::true_type{}, As + rb * 256 * CH, m + rb * 16, yrow, rrow);
+          block(std::true_type{}, As + rb * 256 * CH, m + rb * 16, mb + rb * 16 + 16 <= a.M, yrow, rrow);
           yrow += row_step;
           if (rrow) rrow += row_step;
         }
       } else {
 #pragma unroll 1
         for (int rb = 0; rb < RB; ++rb) {
-          block(std::false_type{}, As + rb * 256 * CH, m + rb * 16, yrow, rrow);
+          block(std::false_type{}, As + rb * 256 * CH, m + rb * 16, mb + rb * 16 + 16 <= a.M, yrow, rrow);
           yrow += row_step;
           if (rrow) rrow += row_step;
         }
@@ -353,6 +368,24 @@ __global__ __launch_bounds__(STHREADS) void pw_stream_kernel(StreamArgs a) {
       }
     }
     lds_barrier();
+    if (a.stat_fold > 1) {
+      const int Nr = a.N / a.stat_fold;
+      float* st = a.stats + (size_t)blockIdx.x * 2 * Nr;
+      for (int c = tid; c < Nr; c += STHREADS) {
+        float s = 0.f, qv = 0.f;
+        for (int f = 0; f < a.stat_fold; ++f) {
+          const int n = c + f * Nr, g = n / BN, cc = n - g * BN;            // (wgc == 1: column tile = column group)
+#pragma unroll
+          for (int w = 0; w < RG; ++w) {
+            s += sred[((g * RG + w) * BN + cc) * 2 + 0];
+            qv += sred[((g * RG + w) * BN + cc) * 2 + 1];
+          }
+        }
+        st[c] += s;
+        st[Nr + c] += qv;
+      }
+      return;
+    }
     float* st = a.stats + (size_t)blockIdx.x * 2 * a.N;      // this workgroup's own slot (grid <= PB_STAT_SLOTS)
     for (int c = tid; c < CG * BN; c += STHREADS) {
       const int g = c / BN, cc = c - g * BN;

@@ -610,15 +610,16 @@ def pw_fwd(x, w, *, w_transposed=False, in_scale=None, in_shift=None, in_act="no
     y = torch.empty((M, N), dtype=x.dtype, device=x.device)
     dev, st = _dev_stream(x)
     if (_GEMM_DMA and _K16_FOLD and x.dtype == torch.bfloat16 and K == 16 and N % 8 == 0 and 4 * N <= 96 and M % 4 == 0 and M >= 4096
-            and in_scale is None and in_shift is None and in_act == "none" and row_scale is None and stats is None
+            and in_scale is None and in_shift is None and in_act == "none" and row_scale is None
             and out_scale is None and out_shift is None and w.is_contiguous() and residual is None):
         # K = 16 (the first stage): a row is 32 bytes, a quarter of an LDS stage.  [M,16] is the same memory as
         # [M/4,64], and Y[M,N] the same as [M/4,4N] = X' * blockdiag(W,W,W,W)^T: a full-width K = 64 GEMM on a quarter
         # of the rows (4x the MFMA work, on zeros - the kernel is HBM-bound): 3.2 -> 4.6 TB/s on the 4M-row tensors when
-        # the folded output stays one column tile (N = 16); wider outputs (N = 64 -> 256 columns) measured slower
+        # the folded output stays one column tile (N = 16); wider outputs (N = 64 -> 256 columns) measured slower.
+        # BatchNorm statistics: the four replicas of a channel are folded inside the workgroup.
         wb4 = _prepped_weight(w, w_transposed, fold4=True)
-        _launch(_bf16w_family(M // 4, 64, 4 * N, 1, False), _nb(x, y) + 4 * N * 64 * 2, "pb_pwconv_fwd_bf16w", _p(x), _p(wb4), _p(y), M // 4, 64, 4 * N, 1,
-                0, None, None, ACT[out_act], float(out_slope), None, None, dev, st, detail=f"M{M} K{K} N{N} (4-row fold)")
+        _launch("pw_stream_kernel", _nb(x, y) + 4 * N * 64 * 2, "pb_pwconv_fwd_fold4", _p(x), _p(wb4), _p(y), M, N, ACT[out_act], float(out_slope),
+                _p(stats), dev, st, detail=f"M{M} K{K} N{N} (4-row fold{', stats' if stats is not None else ''})")
         return y
     if (_GEMM_DMA and x.dtype == torch.bfloat16 and _dma_gemm_pays(M, K, N) and K % 8 == 0 and N % 8 == 0
             and in_scale is None and in_shift is None and in_act == "none" and w.is_contiguous()
@@ -638,7 +639,8 @@ def pw_fwd(x, w, *, w_transposed=False, in_scale=None, in_shift=None, in_act="no
             wb = wbs
         _launch(_bf16w_family(M, K, N, groups, stats is not None), _nb(x, y) + N * K * 2, "pb_pwconv_fwd_bf16w", _p(x), _p(wb), _p(y), M, K, N, groups,
                 int(rows_per_group) if groups > 1 else 0, _p(out_scale), _p(out_shift), ACT[out_act], float(out_slope),
-                _p(stats), _p(residual), dev, st, detail=f"M{M} K{K} N{N}")
+                _p(stats), _p(residual), dev, st,
+                detail=f"M{M} K{K} N{N}" + (" stats" if stats is not None else "") + (" res" if residual is not None else "") + (" se" if groups > 1 else ""))
         return y
     skinny = (M <= 64 and in_scale is None and in_shift is None and in_act == "none" and row_scale is None
               and stats is None)

@@ -127,13 +127,15 @@ def test_pw_bwd_weight_training_paths(K, M, Kd, N, G, dtype):
     (5 * 1801, 80, 480, 5), (12000, 112, 672, 0), (6 * 2001, 672, 112, 6), (5000, 160, 960, 0), (4 * 1250, 960, 160, 4), (3000, 480, 112, 0),
     (130, 200, 80, 0), (40000, 64, 16, 0), (129, 24, 48, 0), (70000, 16, 112, 0), (3 * 3528, 672, 160, 3), (8 * 131, 120, 40, 8),
     (4100, 192, 112, 0), (2500, 768, 192, 0), (3001, 760, 128, 0), (2111, 184, 96, 0), (4000, 200, 80, 0), (2600, 480, 240, 0),
-    (32 * 343, 672, 112, 32), (5 * 777, 240, 112, 5), (2 * 1031, 392, 120, 2), (9000, 480, 520, 0), (2048, 1032, 16, 0)])
+    (32 * 343, 672, 112, 32), (5 * 777, 240, 112, 5), (2 * 1031, 392, 120, 2), (9000, 480, 520, 0), (2048, 1032, 16, 0),
+    (70000, 16, 16, 0), (40004, 16, 24, 0), (4100, 16, 8, 0)])
 def test_pw_fwd_dma_ring_gemm(K, M, Kd, N, G):
     """The three bf16 GEMM kernels behind pb_pwconv_fwd_bf16w on their own - the weight-stationary streaming kernel
     (K <= 160), its long-reduction form (columns over the waves, K <= 1024, also with per-clip weights) and the LDS-DMA ring
     kernel (everything else): every column-tile width, several column tiles / groups per row panel, persistent workgroups
     walking many panels, ragged last panels, clip-aligned panels with per-clip weights, statistics (one slot per
-    workgroup), affine + activation epilogue, residual.  Bit-identical reruns."""
+    workgroup), affine + activation epilogue, residual; K = 16 with N <= 24: four rows per line (pb_pwconv_fwd_fold4), the
+    statistics of the four column replicas folded in the workgroup.  Bit-identical reruns."""
     bf = torch.bfloat16
     x, w = rnd((M, Kd), bf, 41), rnd((N, Kd), seed=42, scale=Kd ** -0.5)
     kw = {}
