@@ -574,7 +574,9 @@ struct WgArgs {
 // 4-byte reads.  No workgroup barrier in the loop (waves are independent); the next block's global
 // loads are issued before the current block's MFMAs.  At the end the four waves' tiles are summed
 // in LDS (wave order) and stored as this row range's partial tile of the workspace a.P[range][N][K].
-template <typename T, int TNW, int TKW, bool CONV = false>
+// DIAG (K = N = 16, four rows per 128-byte line: dY and X are read as [M/4][64]): only the four diagonal 16 x 16 blocks of
+// the 64 x 64 product are computed; they are stored as four partial tiles [range][4][16][16] and the reduction adds them up.
+template <typename T, int TNW, int TKW, bool CONV = false, bool DIAG = false>
 __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgArgs a) {
   constexpr int VEC = ElemTraits<T>::VEC;
   constexpr int TN = TNW * 16, TK = TKW * 16;
@@ -693,7 +695,8 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgArgs a) {
 #pragma unroll
       for (int i = 0; i < TNW; ++i)
 #pragma unroll
-        for (int j = 0; j < TKW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TKW; ++j)
+          if (!DIAG || i == j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     } else {
       const int col = lane & 15, g = lane >> 4;
 #pragma unroll
@@ -721,15 +724,25 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgArgs a) {
 #pragma unroll
       for (int i = 0; i < TNW; ++i)
 #pragma unroll
-        for (int j = 0; j < TKW; ++j)
+        for (int j = 0; j < TKW; ++j) {
+          if (DIAG && i != j) continue;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int idx = (i * 16 + (lane >> 4) * 4 + r) * TK + j * 16 + (lane & 15);
             if (w == 0) R[idx] = acc[i][j][r];
             else R[idx] += acc[i][j][r];
           }
+        }
     }
     __syncthreads();
+  }
+  if constexpr (DIAG) {
+    static_assert(!DIAG || (TN == 64 && TK == 64), "diagonal form: one 64 x 64 tile");
+    for (int e = tid; e < 4 * 256; e += 256) {
+      const int b = e >> 8, nn = (e >> 4) & 15, kk = e & 15;
+      a.P[(int64_t)blockIdx.y * 1024 + e] = R[(b * 16 + nn) * TK + b * 16 + kk];
+    }
+    return;
   }
   const int64_t ldw = CONV ? (int64_t)a.ckt * a.ckh * a.ckw * a.K : a.K;
   const int64_t woff = CONV ? (int64_t)blockIdx.z * a.K : 0;
@@ -1406,6 +1419,12 @@ bool wgrad_is_big(int K, int N, pb_dtype dtype) {
   return dtype == PB_BF16 && (N > 64 || K > 64) && (N % 8) == 0 && (K % 8) == 0;
 }
 
+// K = N = 16 without a prologue: the four-rows-per-line form (pw_wgrad_kernel<DIAG>)
+bool wgrad_is_fold4(int64_t M, int K, int N, pb_dtype dtype, bool affine, bool row_scale) {
+  static const int on = getenv("PB_WGRAD_FOLD4") ? atoi(getenv("PB_WGRAD_FOLD4")) : 1;
+  return on && dtype == PB_BF16 && K == 16 && N == 16 && M % 4 == 0 && M >= 4096 && !affine && !row_scale;
+}
+
 }  // namespace
 
 namespace {
@@ -1440,6 +1459,7 @@ extern "C" int64_t pb_pwconv_bwd_weight_ws_bytes(int64_t M, int K, int N, pb_dty
     const WgPlan p = wgrad128_plan(M, K, N, has_row_scale != 0, has_affine != 0, rows_per_group > 0 ? rows_per_group : 1, true, device);
     return p.split * (int64_t)N * K * 4;
   }
+  if (wgrad_is_fold4(M, K, N, dtype, has_affine != 0, has_row_scale != 0)) return wgrad_small_plan(M / 4, 64, 64, dtype).msplit * (int64_t)4096;
   return wgrad_small_plan(M, K, N, dtype).msplit * (int64_t)N * K * 4;
 }
 
@@ -1465,7 +1485,14 @@ extern "C" int pb_pwconv_bwd_weight_ws(const void* dy, const void* x, float* dw,
   a.in_scale = in_scale; a.in_shift = in_shift; a.in_act = (int)in_act; a.in_slope = in_slope;
   a.row_scale = row_scale; a.rows_per_group = rows_per_group > 0 ? rows_per_group : 1;
   int64_t nsplit;
-  if (wgrad_is_big(K, N, dtype)) {
+  if (wgrad_is_fold4(M, K, N, dtype, affine, row_scale != nullptr)) {
+    a.M = M / 4; a.K = 64; a.N = 64;
+    const WgSmallPlan p = wgrad_small_plan(a.M, 64, 64, dtype);
+    a.n_tiles = 1; a.k_tiles = 1; a.rows_per_wg = p.rows_per_wg;
+    a.ranges_per_group = 0; a.split = (int)p.msplit;
+    nsplit = 4 * p.msplit;                                  // (four diagonal blocks per row range, each a partial [16][16])
+    hipLaunchKernelGGL((pw_wgrad_kernel<bf16_t, 4, 4, false, true>), dim3(1, (unsigned)p.msplit), dim3(256), 0, (hipStream_t)stream, a);
+  } else if (wgrad_is_big(K, N, dtype)) {
     const WgPlan p = wgrad128_plan(M, K, N, row_scale != nullptr, affine, a.rows_per_group, true, device);
     a.n_tiles = p.n_tiles; a.k_tiles = p.k_tiles;
     const int64_t tiles128 = (int64_t)a.n_tiles * a.k_tiles;

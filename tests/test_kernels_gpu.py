@@ -74,7 +74,7 @@ def test_pw_fwd_prologue_epilogue_stats(K, M, Kd, N, G, dtype):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,Kd,N", [(300, 16, 16), (1000, 16, 64), (257, 64, 24), (513, 120, 40), (260, 672, 160),
-                                    (150, 160, 960), (32, 1280, 13), (33, 13, 1280), (5000, 24, 72)])
+                                    (150, 160, 960), (32, 1280, 13), (33, 13, 1280), (5000, 24, 72), (70000, 16, 16), (4100, 16, 16)])
 def test_pw_bwd_weight(K, M, Kd, N, dtype):
     dy, x = rnd((M, N), dtype, 9), rnd((M, Kd), dtype, 10)
     G = 1
