@@ -30,7 +30,7 @@ class held_reductions(deferred_reductions):
     jobs = ()
 
 
-def weight_grad_branch(ref, params, thunks, keep, tag="", held=()):
+def weight_grad_branch(ref, params, thunks, keep, tag="", held=(), now=False):
     """Mirror of kernels.weight_grad_branch (the product may run a block's weight-gradient launches on a side stream and
     join later; the mirror runs them in place)."""
     for t in thunks:

@@ -671,7 +671,7 @@ class _ConvBnAct(torch.autograd.Function):
             wt = K.conv_weight_prep(w.reshape(-1), 1, Cout, Cin, taps)            # [Cin][taps reversed][Cout]
             pad_t = tuple(k - 1 - p for k, p in zip(kernel, pf))
             dx5 = K.conv3d_fwd(dz5, wt, Cin, kernel, (1, 1, 1), pad_t, (T, H, W))
-        K.weight_grad_branch(dz5, (w,), [weight_gradient], (dz5, x5, wg), "conv")
+        K.weight_grad_branch(dz5, (w,), [weight_gradient], (dz5, x5, wg), "conv", now=True)      # (the thunk creates its result)
         # (a fresh view: autograd adopts a gradient tensor only when nobody else holds the OBJECT - the branch keeps `wg` -
         # and would otherwise clone it on this stream at once, before the side stream has written it)
         return dx5, wg["dw"].view_as(w), dbias, dgamma, dbeta, None, None, None

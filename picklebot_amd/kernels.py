@@ -227,6 +227,10 @@ _lag = {}        # device index -> (done event, tensors kept alive) of the branc
 _pending = {}    # device index -> reduction jobs (with the tensors they keep alive) the deferred branches have not launched yet
 _flushed = []    # job lists already launched on the side stream: their workspaces live until the next join
 _REDUCE_BATCH = int(os.environ.get("PB_REDUCE_BATCH", "24"))     # jobs per reduction launch of the deferred branches (<= 32)
+_group = {}      # device index -> [(thunks, keep, held)] of blocks whose branch has not been forked yet
+# blocks per branch: every fork / join of the two streams costs the chain ~10 us inside a replayed HIP graph (the kernel in front
+# of it carries a completion signal, the one behind it a cross-queue wait)
+_WGRAD_GROUP = int(os.environ.get("PB_WGRAD_GROUP", "4"))
 _seen = {}       # graph-task id -> ids of the parameters whose gradient a branch of this pass has deferred
 branch_counts = {"side": 0, "inline": 0}      # how the blocks' weight gradients were issued (tests read this)
 
@@ -276,10 +280,12 @@ def _run_inline(thunks, held=()):
             t()
 
 
-def weight_grad_branch(ref, params, thunks, keep, tag="", held=()):
+def weight_grad_branch(ref, params, thunks, keep, tag="", held=(), now=False):
     """Run `thunks` (the weight-gradient launches of one block; their partial-tile reductions are issued as one launch at
     the end) - on the side stream without joining when that is safe (see above), in line otherwise.  held: reduction jobs
-    of kernels the CHAIN already launched (held_reductions) - they join the same single reduction launch."""
+    of kernels the CHAIN already launched (held_reductions) - they join the same single reduction launch.  The thunks of
+    _WGRAD_GROUP consecutive blocks are issued together, i.e. possibly AFTER this call has returned: they must write into
+    tensors that exist already - or pass now=True (the branch, with everything collected before it, is forked at once)."""
     region = weight_grad_overlap._depth > 0          # (process-wide: backward runs on autograd's device thread)
     defer = _WGRAD_OVERLAP and ref.is_cuda and all(_adopting(p, region) for p in params) and (not _WGRAD_TAGS or tag in _WGRAD_TAGS)
     if not defer:
@@ -302,9 +308,20 @@ def weight_grad_branch(ref, params, thunks, keep, tag="", held=()):
     except RuntimeError:                  # not inside a backward pass of the engine: nobody would join
         return _run_inline(thunks, held)
     seen.update(ids)
+    grp = _group.setdefault(idx, [])
+    grp.append((thunks, keep, held))
+    if now or len(grp) >= _WGRAD_GROUP:
+        _launch_group(idx, main, side)
+
+
+def _launch_group(idx, main, side):
+    """Fork: the collected blocks' weight-gradient launches as ONE branch of the side stream behind the calling stream."""
+    grp = _group.pop(idx, None)
+    if not grp:
+        return
     prev = _lag.pop(idx, None)
     if prev is not None:
-        main.wait_event(prev[0])          # the previous block's branch (normally long finished); its tensors may go now
+        main.wait_event(prev[0])          # the previous branch (normally long finished); its tensors may go now
     ev = torch.cuda.Event()
     ev.record(main)
     side.wait_event(ev)
@@ -312,15 +329,16 @@ def weight_grad_branch(ref, params, thunks, keep, tag="", held=()):
     with torch.cuda.stream(side):
         # the partial-tile reductions of SEVERAL blocks go out as one launch (whoever reads a gradient joins first, and the
         # join flushes what is left): 23 -> 6 reduction launches per MobileNetLarge3D step
-        with deferred_reductions(held, pending=pend):
-            for t in thunks:
-                t()
+        for thunks, _, held in grp:
+            with deferred_reductions(held, pending=pend):
+                for t in thunks:
+                    t()
         if len(pend) >= _REDUCE_BATCH:
             _flush_pending(idx)
     done = torch.cuda.Event()
     done.record(side)
-    _lag[idx] = (done, (keep, held))      # (held: the chain's workspaces the branch's reduction reads)
-    branch_counts["side"] += 1
+    _lag[idx] = (done, [(keep, held) for _, keep, held in grp])      # (held: the chain's workspaces the branch's reduction reads)
+    branch_counts["side"] += len(grp)
 
 
 def _flush_pending(idx):
@@ -338,6 +356,8 @@ def _flush_pending(idx):
 def join_weight_grads():
     """Order the current stream(s) behind every weight-gradient branch still in flight (cheap when there is none); reduction
     jobs the branches left pending are launched first (behind the last branch, on the side stream)."""
+    for idx in list(_group):
+        _launch_group(idx, torch.cuda.current_stream(idx), _side_stream(idx))
     for idx in [i for i, jobs in _pending.items() if jobs]:
         side = _side_stream(idx)
         with torch.cuda.stream(side):
