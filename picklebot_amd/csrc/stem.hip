@@ -23,6 +23,7 @@ struct StemArgs {
   float* dbias;
   pb_stem_shape s;
   int64_t npix;
+  int ablate;      // (experiments only: PB_STEM_ABLATE)
 };
 
 template <typename XT> __device__ __forceinline__ float ldx(const XT* p) { return (float)*p; }
@@ -455,24 +456,63 @@ constexpr int S3_NT = (S3_MAXROWS * S3_SP + 63) / 64;       // 5 slot tasks per 
 struct S3Regs {
   u32x4 v[S3_NT];
 };
-__device__ __forceinline__ void s3_load(S3Regs& rg, const bf16_t* x, const pb_stem_shape& s, int n, int to, int ho, int wo0,
-                                        int lane) {
+// a lane's S3_NT slot tasks: window row, (frame, line) of that row, slot position, element offset of its 12 bytes from the
+// window's first pixel - constants of the launch
+struct S3Tasks {
+  int row[S3_NT], at[S3_NT], ah[S3_NT], sp[S3_NT], off[S3_NT];
+  __device__ __forceinline__ void init(const pb_stem_shape& s, int lane) {
+#pragma unroll
+    for (int k = 0; k < S3_NT; ++k) {
+      const int t = lane + 64 * k;
+      row[k] = t / S3_SP;
+      sp[k] = t - row[k] * S3_SP;
+      at[k] = row[k] / s.kh;
+      ah[k] = row[k] - at[k] * s.kh;
+      off[k] = (int)((int64_t)at[k] * s.xs_t + (int64_t)ah[k] * s.xs_h) + 6 * sp[k];      // (< 2^31 elements: a few frames)
+    }
+  }
+};
+__device__ __forceinline__ void s3_load(S3Regs& rg, const bf16_t* x, const pb_stem_shape& s, const S3Tasks& tk, int n, int to, int ho,
+                                        int wo0) {
+  typedef __attribute__((ext_vector_type(3))) unsigned u32x3;
   const int nrows = s.kt * s.kh;
   const int ti0 = to * s.st - s.pt, hi0 = ho * s.sh - s.ph, wi0 = wo0 * 2 - s.pw;
   const bf16_t* xn = x + (int64_t)n * s.xs_n;
+  // (wave-uniform) every window row inside the clip - 7 of 8 frames: one base address, the lane's constant offset, and only
+  // the pixel tests along the row are left (the general path below costs ~60 instructions per slot task: three 64-bit
+  // multiplies and the row tests)
+  if (ti0 >= 0 && ti0 + s.kt <= s.Ti && hi0 >= 0 && hi0 + s.kh <= s.Hi) {
+    const bf16_t* base = xn + (int64_t)ti0 * s.xs_t + (int64_t)hi0 * s.xs_h + (int64_t)wi0 * 3;
+#pragma unroll
+    for (int k = 0; k < S3_NT; ++k) {
+      u32x4 o = {0u, 0u, 0u, tk.row[k] == 0 ? 0x3f80u : 0u};
+      const int wa = wi0 + 2 * tk.sp[k];
+      const bool oka = tk.row[k] < nrows && (unsigned)wa < (unsigned)s.Wi, okb = tk.row[k] < nrows && (unsigned)(wa + 1) < (unsigned)s.Wi;
+      const bf16_t* p = base + tk.off[k];
+      if (oka && okb) {
+        const u32x3 q = *reinterpret_cast<const u32x3*>(p);                    // 12 bytes at a 2-byte-aligned address
+        o[0] = q[0]; o[1] = q[1]; o[2] = q[2];
+      } else if (oka || okb) {
+        const unsigned short* ps = reinterpret_cast<const unsigned short*>(p);
+        unsigned e[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+        if (oka) { e[0] = ps[0]; e[1] = ps[1]; e[2] = ps[2]; }
+        if (okb) { e[3] = ps[3]; e[4] = ps[4]; e[5] = ps[5]; }
+        o[0] = e[0] | (e[1] << 16); o[1] = e[2] | (e[3] << 16); o[2] = e[4] | (e[5] << 16);
+      }
+      rg.v[k] = o;
+    }
+    return;
+  }
 #pragma unroll
   for (int k = 0; k < S3_NT; ++k) {
-    const int t = lane + 64 * k;
-    const int r = t / S3_SP, sp = t - r * S3_SP;
-    const int at = r / s.kh, ah = r - at * s.kh;
-    const int ti = ti0 + at, hi = hi0 + ah;
+    const int r = tk.row[k], sp = tk.sp[k];
+    const int ti = ti0 + tk.at[k], hi = hi0 + tk.ah[k];
     const bool rowok = r < nrows && ti >= 0 && ti < s.Ti && hi >= 0 && hi < s.Hi;
     const int wa = wi0 + 2 * sp, wb = wa + 1;
     const bool oka = rowok && wa >= 0 && wa < s.Wi, okb = rowok && wb >= 0 && wb < s.Wi;
     const bf16_t* p = xn + (int64_t)ti * s.xs_t + (int64_t)hi * s.xs_h + (int64_t)wa * 3;
     u32x4 o = {0u, 0u, 0u, r == 0 ? 0x3f80u : 0u};        // element 6 = 1.0 on window row 0 (bias), element 7 = 0
     if (oka && okb) {
-      typedef __attribute__((ext_vector_type(3))) unsigned u32x3;
       const u32x3 q = *reinterpret_cast<const u32x3*>(p);  // 12 bytes at a 2-byte-aligned address
       o[0] = q[0]; o[1] = q[1]; o[2] = q[2];
     } else if (oka || okb) {
@@ -507,6 +547,45 @@ __device__ __forceinline__ S3Item s3_item(const pb_stem_shape& s, int64_t it, in
   return q;
 }
 
+// The items of a wave are it0, it0 + step, it0 + 2 step, ...: s3_item's three 64-bit divisions per item (and per look-ahead)
+// were ~800 of the ~1700 instructions a wave issued per item - the stem kernels were bound by index arithmetic, not by
+// memory.  The walker splits `step` into its (wb, ho, to, n) digits once and advances with carries.
+struct S3Walk {
+  int wb, ho, to, n;           // current item
+  int dwb, dho, dto, dn;       // digits of the step
+  int wblocks, Ho, To, Wo;
+  __device__ __forceinline__ void init(const pb_stem_shape& s, int64_t it, int64_t step, int wblocks_) {
+    wblocks = wblocks_; Ho = s.Ho; To = s.To; Wo = s.Wo;
+    int64_t rr = it;
+    wb = (int)(rr % wblocks); rr /= wblocks;
+    ho = (int)(rr % Ho); rr /= Ho;
+    to = (int)(rr % To);
+    n = (int)(rr / To);
+    rr = step;
+    dwb = (int)(rr % wblocks); rr /= wblocks;
+    dho = (int)(rr % Ho); rr /= Ho;
+    dto = (int)(rr % To);
+    dn = (int)(rr / To);
+  }
+  __device__ __forceinline__ void next() {
+    wb += dwb;
+    int c = wb >= wblocks;
+    wb -= c ? wblocks : 0;
+    ho += dho + c;
+    c = ho >= Ho;
+    ho -= c ? Ho : 0;
+    to += dto + c;
+    c = to >= To;
+    to -= c ? To : 0;
+    n += dn + c;
+  }
+  __device__ __forceinline__ S3Item item() const {
+    S3Item q;
+    q.n = n; q.to = to; q.ho = ho; q.wo0 = wb * SW_PIX; q.npx = min(SW_PIX, Wo - q.wo0);
+    return q;
+  }
+};
+
 // 16 waves per workgroup: every workgroup ends with 1312 float atomics onto the same addresses, and those serialise
 // chip-wide (measured +147 us per 1024 extra workgroups) - same wave count per CU from a quarter of the workgroups
 constexpr int S3W_NW = 16;
@@ -516,7 +595,7 @@ __global__ __launch_bounds__(64 * S3W_NW) void stem3_wgrad_kernel(StemArgs a) {
   __shared__ __attribute__((aligned(16))) T dy_s[S3W_NW][SW_PIX * OCB];
   __shared__ float red[OCB * S3_MAXROWS * 16];
   const pb_stem_shape& s = a.s;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nrows = s.kt * s.kh, taps = nrows * 3, CT = 3 * taps;
   const int oc0 = blockIdx.y * OCB;
   const int wblocks = (s.Wo + SW_PIX - 1) / SW_PIX;
@@ -537,9 +616,17 @@ __global__ __launch_bounds__(64 * S3W_NW) void stem3_wgrad_kernel(StemArgs a) {
   S3Regs rg;
   Vec16<T> dyv;
   const int64_t step = (int64_t)gridDim.x * S3W_NW;
-  auto fetch = [&](int64_t it) {
-    const S3Item q = s3_item(s, it, wblocks);
-    s3_load(rg, x, s, q.n, q.to, q.ho, q.wo0, lane);
+  S3Tasks tk;
+  tk.init(s, lane);
+  S3Walk walk;                                             // the next item to fetch
+  {
+    const int64_t first = (int64_t)blockIdx.x * S3W_NW + wave;
+    walk.init(s, first < nitems ? first : 0, step, wblocks);
+  }
+  auto fetch = [&](int64_t) {
+    const S3Item q = walk.item();
+    walk.next();
+    s3_load(rg, x, s, tk, q.n, q.to, q.ho, q.wo0);
     const int64_t pix0 = (((int64_t)q.n * s.To + q.to) * s.Ho + q.ho) * s.Wo + q.wo0;
     const int p = lane * 8 / OCB;                          // 64 lanes x 16 B = the whole [32][16] tile
     dyv = p < q.npx ? vec_load<T>(dy + pix0 * OCB + (int64_t)lane * 8) : vec_zero<T>();
@@ -606,7 +693,7 @@ __global__ __launch_bounds__(256) void stem3_fwd_kernel(StemArgs a) {
   __shared__ __attribute__((aligned(16))) T out_s[4][SW_PIX * OCB];
   __shared__ float red[4][2 * OCB];
   const pb_stem_shape& s = a.s;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nrows = s.kt * s.kh, taps = nrows * 3, CT = 3 * taps;
   const int wblocks = (s.Wo + SW_PIX - 1) / SW_PIX;
   const int64_t nitems = (int64_t)s.N * s.To * s.Ho * wblocks;
@@ -639,12 +726,17 @@ __global__ __launch_bounds__(256) void stem3_fwd_kernel(StemArgs a) {
 
   // (fetching the next item's window before this item's MFMAs was measured slower here: 206 vs 152 us)
   const int64_t step = (int64_t)gridDim.x * 4;
+  S3Tasks tk;
+  tk.init(s, lane);
+  S3Walk walk;
+  walk.init(s, (int64_t)blockIdx.x * 4 + wave < nitems ? (int64_t)blockIdx.x * 4 + wave : 0, step, wblocks);
   for (int64_t it = (int64_t)blockIdx.x * 4 + wave; it < nitems; it += step) {
-    const S3Item cur = s3_item(s, it, wblocks);
+    const S3Item cur = walk.item();
+    walk.next();
     const int n = cur.n, to = cur.to, ho = cur.ho, wo0 = cur.wo0, npx = cur.npx;
     {
       S3Regs rg;
-      s3_load(rg, x, s, n, to, ho, wo0, lane);
+      s3_load(rg, x, s, tk, n, to, ho, wo0);
       s3_store(rg, win, nrows, lane);
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -711,11 +803,11 @@ __global__ __launch_bounds__(256) void stem3_fwd_kernel(StemArgs a) {
 // computed and without registers; the slot image (slot p = the 6 elements of pixels (2p-1, 2p) + [one, zero]) is then built
 // from LDS: 4 aligned ds_read_b32 + 3 v_alignbit per slot (the 12 bytes start 2 bytes into a dword).  MFMA part unchanged.
 // vmcnt: 4 DMAs and 1 store per item, counted exactly (switch over immediates).
-constexpr int S3D_NRAW = 3;
+constexpr int S3D_NRAW = 2;
 constexpr int S3D_RAWCH = 26;                 // 16-byte chunks per raw row: bytes [12 wo0 - 16, 12 wo0 + 400)
 constexpr int S3D_RAWROW = S3D_RAWCH * 16;
 constexpr int S3D_RAWBUF = 4096;              // 9 rows x 416 B = 3744 B, rounded to the 4 DMA instructions' 4 KiB
-constexpr int S3D_LDS = 4 * S3D_NRAW * S3D_RAWBUF + 4 * S3_MAXROWS * S3_SP * 16 + 4 * SW_PIX * OCB * 2;
+constexpr int S3D_LDS = 4 * S3D_NRAW * S3D_RAWBUF + 4 * S3_MAXROWS * S3_SP * 16;
 
 __device__ __forceinline__ void s3d_glds16(const void* gsrc, unsigned lds_dst) {
   unsigned keep;
@@ -732,7 +824,6 @@ __global__ __launch_bounds__(256) void stem3_fwd_dma_kernel(StemArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   unsigned char* raw_w = s3d_smem + wave * (S3D_NRAW * S3D_RAWBUF);
   T* win = (T*)(s3d_smem + 4 * S3D_NRAW * S3D_RAWBUF) + wave * (S3_MAXROWS * S3_SP * 8);
-  T* outt = (T*)(s3d_smem + 4 * S3D_NRAW * S3D_RAWBUF + 4 * S3_MAXROWS * S3_SP * 16) + wave * (SW_PIX * OCB);
   typedef __attribute__((address_space(3))) unsigned char* lds_b;
   const unsigned raw_lds = (unsigned)(uintptr_t)(lds_b)raw_w;
   const int nrows = s.kt * s.kh, taps = nrows * 3, CT = 3 * taps;
@@ -764,43 +855,89 @@ __global__ __launch_bounds__(256) void stem3_fwd_dma_kernel(StemArgs a) {
 #pragma unroll
   for (int ks = 0; ks < NKS; ++ks) asm volatile("" : "+v"(wf[ks]), "+v"(wl[ks]));     // (loads consumed: vmcnt is counted by hand below)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  float ssum = 0.f, ssq = 0.f;
+  // statistics: this lane's four output channels 4g .. 4g+3 (the MFMA result is [channel][pixel])
+  float cs[4] = {0.f, 0.f, 0.f, 0.f}, cq[4] = {0.f, 0.f, 0.f, 0.f};
 
+  // A wave issues one instruction every ~5 cycles and only two waves share a SIMD here (74 KB of LDS per workgroup): the
+  // kernel is bound by its own instruction count.  Measured per item (s_memtime): 1760 cycles building the slot image, 970
+  // for the MFMAs and the output, 760 issuing four DMAs, 570 on the item arithmetic - so: the item walk is incremental
+  // (S3Walk), everything that depends on the lane alone is computed once, interior items (all window rows and pixels inside
+  // the clip: 7 of 8 frames, the two middle blocks of a row) skip the masks and the address clamps, the output goes from
+  // the accumulators to memory (no LDS transpose: the MFMA operands are swapped so that a lane holds 4 channels of a pixel).
   // (An XCD-aware item order - XCD x sweeping whole clips so that the halo rows / frames are L2 hits - measured SLOWER: 159 ->
   // 174 us; the spread order stays.)
   const int64_t step = (int64_t)gridDim.x * 4;
   const int64_t it0 = (int64_t)blockIdx.x * 4 + wave;
   const int nloc = it0 < nitems ? (int)((nitems - it0 + step - 1) / step) : 0;        // this wave's items
-  auto item_of = [&](int k) -> S3Item { return s3_item(s, it0 + (int64_t)k * step, wblocks); };
+  S3Walk wcur, wahead;                              // the item being computed / the next one to fetch (both wave-uniform)
+  wcur.init(s, it0 < nitems ? it0 : 0, step, wblocks);
+  wahead = wcur;
   const int rowbytes = s.Wi * 6;
-  // DMA: instruction i moves raw chunks i*64 + lane (row = idx / 26, chunk = idx % 26; the 22 spare lanes repeat the last chunk)
-  int drow[4], dch[4];
+  // DMA: instruction i moves raw chunks i*64 + lane (row = idx / 26, chunk = idx % 26; the 22 spare lanes repeat the last chunk);
+  // the window row's (frame, line) and the chunk's byte offset are per-lane constants of the launch
+  int dat[4], dah[4], dcb[4], doff[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int idx = min(i * 64 + lane, nrows * S3D_RAWCH - 1);
-    drow[i] = idx / S3D_RAWCH;
-    dch[i] = idx - drow[i] * S3D_RAWCH;
+    const int dr = idx / S3D_RAWCH;
+    dat[i] = dr / s.kh;
+    dah[i] = dr - dat[i] * s.kh;
+    dcb[i] = 16 * (idx - dr * S3D_RAWCH) - 16;
+    doff[i] = (int)(((int64_t)dat[i] * s.xs_t + (int64_t)dah[i] * s.xs_h) * 2);      // (< 2^31: stem3_dma_ok)
   }
-  auto issue = [&](int k) {
-    const S3Item q = item_of(k);
-    const unsigned dst = raw_lds + (unsigned)(k % S3D_NRAW) * S3D_RAWBUF;
-    const T* xn = x + (int64_t)q.n * s.xs_n;
+  int slot = 0;                                      // ring slot of the next fetch
+  auto issue = [&]() {
+    const S3Item q = wahead.item();
+    wahead.next();
+    const unsigned dst = raw_lds + (unsigned)slot * S3D_RAWBUF;
+    slot = slot + 1 == S3D_NRAW ? 0 : slot + 1;
+    const unsigned char* xn = (const unsigned char*)(x + (int64_t)q.n * s.xs_n);
     const int ti0 = q.to * s.st - s.pt, hi0 = q.ho * s.sh - s.ph;
-    const int b0 = q.wo0 * 12 - 16;                                                  // raw byte 0 in row bytes
+    const int b0 = q.wo0 * 12;                                                       // (raw byte 0 = b0 - 16 in row bytes)
+    if (ti0 >= 0 && ti0 + s.kt <= s.Ti && hi0 >= 0 && hi0 + s.kh <= s.Hi) {          // (wave-uniform) every window row exists
+      const unsigned char* base = xn + ((int64_t)ti0 * s.xs_t + (int64_t)hi0 * s.xs_h) * 2;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int at = drow[i] / s.kh, ah = drow[i] - at * s.kh;
-      const int ti = min(max(ti0 + at, 0), s.Ti - 1), hi = min(max(hi0 + ah, 0), s.Hi - 1);   // rows / chunks outside: any valid
-      const int cb = min(max(b0 + 16 * dch[i], 0), rowbytes - 16);                                // address - masked when the slots are built
-      s3d_glds16((const unsigned char*)(xn + (int64_t)ti * s.xs_t + (int64_t)hi * s.xs_h) + cb, dst + i * 1024);
+      for (int i = 0; i < 4; ++i) {
+        const int cb = min(max(b0 + dcb[i], 0), rowbytes - 16);                     // chunks outside the row: any valid address -
+        s3d_glds16(base + (doff[i] + cb), dst + i * 1024);                           // masked when the slots are built
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ti = min(max(ti0 + dat[i], 0), s.Ti - 1), hi = min(max(hi0 + dah[i], 0), s.Hi - 1);   // rows outside: any valid
+        const int cb = min(max(b0 + dcb[i], 0), rowbytes - 16);
+        s3d_glds16(xn + ((int64_t)ti * s.xs_t + (int64_t)hi * s.xs_h) * 2 + cb, dst + i * 1024);
+      }
     }
   };
-  for (int k = 0; k < min(nloc, S3D_NRAW); ++k) issue(k);
+  if (a.ablate != 2)
+    for (int k = 0; k < min(nloc, S3D_NRAW); ++k) issue();
+  // slot build: task kk of a lane is slot t = lane + 64 kk of the image - its window row, frame / line and position, its 12
+  // source bytes inside a raw buffer and whether it exists are per-lane constants too
+  int brow[S3_NT], bat[S3_NT], bah[S3_NT], bsp[S3_NT], bsrc[S3_NT];
+  bool bok[S3_NT];
+#pragma unroll
+  for (int kk = 0; kk < S3_NT; ++kk) {
+    const int t = lane + 64 * kk;
+    brow[kk] = t / S3_SP;
+    bsp[kk] = t - brow[kk] * S3_SP;
+    bat[kk] = brow[kk] / s.kh;
+    bah[kk] = brow[kk] - bat[kk] * s.kh;
+    bok[kk] = brow[kk] < nrows && bsp[kk] < S3_SP - 1;
+    bsrc[kk] = min(brow[kk], S3_MAXROWS - 1) * S3D_RAWROW + 8 + 12 * bsp[kk];          // the slot's 12 bytes start at +2 (all inside the 4 KiB buffer)
+  }
+  int cslot = 0;                                     // ring slot of the item being computed
 
+  long long tph[6] = {0, 0, 0, 0, 0, 0};
+  long long tlast = __builtin_amdgcn_s_memtime();
+#define S3D_TICK(i) do { if (a.ablate == 3) { const long long tn = __builtin_amdgcn_s_memtime(); tph[i] += tn - tlast; tlast = tn; } } while (0)
   for (int k = 0; k < nloc; ++k) {
-    const S3Item cur = item_of(k);
+    const S3Item cur = wcur.item();
+    wcur.next();
     const int n = cur.n, to = cur.to, ho = cur.ho, wo0 = cur.wo0, npx = cur.npx;
-    // behind item k's DMAs: the DMAs of the items issued after it and one store per iteration since it was issued
+    S3D_TICK(5);
+    // behind item k's DMAs: the DMAs of the items issued after it and AT LEAST one store per iteration since it was issued (the
+    // second store of an item is skipped when its 16 pixels are past the row's end: the allowance may only round down)
     {
       const int behind = 4 * min(S3D_NRAW - 1, nloc - 1 - k) + min(k, S3D_NRAW);
       switch (behind) {
@@ -818,77 +955,108 @@ __global__ __launch_bounds__(256) void stem3_fwd_dma_kernel(StemArgs a) {
         default: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
       }
     }
-    // ---- raw rows -> slot image
+    S3D_TICK(0);
+    if (a.ablate == 1) {
+      if (k + S3D_NRAW < nloc) issue();
+      continue;
+    }
+    // ---- raw rows -> slot image: all of a lane's reads in flight together, then the shifts, then the writes
     {
-      const unsigned char* raw = raw_w + (k % S3D_NRAW) * S3D_RAWBUF;
+      const unsigned char* raw = raw_w + cslot * S3D_RAWBUF;
+      cslot = cslot + 1 == S3D_NRAW ? 0 : cslot + 1;
       const int ti0 = to * s.st - s.pt, hi0 = ho * s.sh - s.ph, wi0 = wo0 * 2 - s.pw;
+      unsigned d[S3_NT][4];
 #pragma unroll
       for (int kk = 0; kk < S3_NT; ++kk) {
-        const int t = lane + 64 * kk;
-        const int r = t / S3_SP, sp = t - r * S3_SP;
-        if (r < nrows && sp < S3_SP - 1) {
-          const int at = r / s.kh, ah = r - at * s.kh;
-          const int ti = ti0 + at, hi = hi0 + ah;
+        const unsigned* rp = reinterpret_cast<const unsigned*>(raw + bsrc[kk]);
+        d[kk][0] = rp[0]; d[kk][1] = rp[1]; d[kk][2] = rp[2]; d[kk][3] = rp[3];
+      }
+      unsigned o[S3_NT][3];
+#pragma unroll
+      for (int kk = 0; kk < S3_NT; ++kk) {
+        // elements 0..2 = pixel wa = wi0 + 2 sp, 3..5 = pixel wa + 1
+        o[kk][0] = __builtin_amdgcn_alignbit(d[kk][1], d[kk][0], 16);
+        o[kk][1] = __builtin_amdgcn_alignbit(d[kk][2], d[kk][1], 16);
+        o[kk][2] = __builtin_amdgcn_alignbit(d[kk][3], d[kk][2], 16);
+      }
+      const bool inside = ti0 >= 0 && ti0 + s.kt <= s.Ti && hi0 >= 0 && hi0 + s.kh <= s.Hi && wi0 >= 0 &&
+                          wi0 + 2 * (S3_SP - 2) + 1 < s.Wi;                           // (wave-uniform)
+      if (!inside) {
+#pragma unroll
+        for (int kk = 0; kk < S3_NT; ++kk) {
+          const int ti = ti0 + bat[kk], hi = hi0 + bah[kk];
           const bool rowok = ti >= 0 && ti < s.Ti && hi >= 0 && hi < s.Hi;
-          const int wa = wi0 + 2 * sp, wb = wa + 1;
+          const int wa = wi0 + 2 * bsp[kk], wb = wa + 1;
           const bool oka = rowok && wa >= 0 && wa < s.Wi, okb = rowok && wb >= 0 && wb < s.Wi;
-          const unsigned* rp = reinterpret_cast<const unsigned*>(raw + r * S3D_RAWROW + 8 + 12 * sp);   // the slot's 12 bytes start at +2
-          const unsigned d0 = rp[0], d1 = rp[1], d2 = rp[2], d3 = rp[3];
-          unsigned o0 = __builtin_amdgcn_alignbit(d1, d0, 16), o1 = __builtin_amdgcn_alignbit(d2, d1, 16), o2 = __builtin_amdgcn_alignbit(d3, d2, 16);
-          // elements 0..2 = pixel wa, 3..5 = pixel wb
-          if (!oka) { o0 = 0u; o1 &= 0xffff0000u; }
-          if (!okb) { o1 &= 0x0000ffffu; o2 = 0u; }
-          *reinterpret_cast<u32x4*>(win + t * 8) = u32x4{o0, o1, o2, r == 0 ? 0x3f80u : 0u};
+          if (!oka) { o[kk][0] = 0u; o[kk][1] &= 0xffff0000u; }
+          if (!okb) { o[kk][1] &= 0x0000ffffu; o[kk][2] = 0u; }
         }
       }
+#pragma unroll
+      for (int kk = 0; kk < S3_NT; ++kk)
+        if (bok[kk]) *reinterpret_cast<u32x4*>(win + (lane + 64 * kk) * 8) = u32x4{o[kk][0], o[kk][1], o[kk][2], brow[kk] == 0 ? 0x3f80u : 0u};
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    if (k + S3D_NRAW < nloc) issue(k + S3D_NRAW);                // this item's raw buffer is free again
+    S3D_TICK(1);
+    if (k + S3D_NRAW < nloc && a.ablate != 2) issue();           // this item's raw buffer is free again
+    S3D_TICK(2);
     f32x4 acc[2], accl[2];
     acc[0] = acc[1] = accl[0] = accl[1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
+        // (weights as the A operand: D[channel 4g + i][pixel mt*16 + row] - a lane ends up with 4 channels of one pixel)
         const bf16x8 fa = *reinterpret_cast<const bf16x8*>(win + aoff[ks] + (mt * 16 + row) * 8);
-        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, wf[ks], acc[mt], 0, 0, 0);
-        accl[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, wl[ks], accl[mt], 0, 0, 0);
+        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks], fa, acc[mt], 0, 0, 0);
+        accl[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ks], fa, accl[mt], 0, 0, 0);
       }
     }
     acc[0] += accl[0];
     acc[1] += accl[1];
+    S3D_TICK(3);
+    {
+      // 8 bytes per lane: pixel p's channels 4g .. 4g+3; a store instruction covers 16 pixels = 512 contiguous bytes.  Lane 0 of
+      // the first store is never off: at least ONE store instruction per item in the vmcnt count
+      const int64_t pix0 = (((int64_t)n * s.To + to) * s.Ho + ho) * s.Wo + wo0;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < 2; ++mt) {
+        const int p = mt * 16 + row;
+        const bf16x4 ov = __builtin_convertvector(acc[mt], bf16x4);
+        if (p < npx) {
+          *reinterpret_cast<bf16x4*>(y + (pix0 + p) * OCB + 4 * g) = ov;
+          if (a.stats) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int p = mt * 16 + g * 4 + i;
-        const T tv = from_f32<T>(acc[mt][i]);
-        outt[p * OCB + row] = tv;
-        if (a.stats && p < npx) {
-          const float fv = to_f32(tv);
-          ssum += fv;
-          ssq += fv * fv;
+            for (int i = 0; i < 4; ++i) {
+              const float fv = (float)ov[i];
+              cs[i] += fv;
+              cq[i] += fv * fv;
+            }
+          }
         }
       }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-    {
-      // one 16-byte store per lane and item (SW_PIX * OCB / 8 = 64 chunks); lanes of a ragged block's missing pixels are off,
-      // lane 0 never is: exactly ONE store instruction per item in the vmcnt count
-      const int64_t pix0 = (((int64_t)n * s.To + to) * s.Ho + ho) * s.Wo + wo0;
-      const int p = lane * 8 / OCB;
-      if (p < npx) vec_store<T>(y + pix0 * OCB + (int64_t)lane * 8, vec_load<T>(outt + lane * 8));
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
+    S3D_TICK(4);
   }
+  if (a.ablate == 3 && blockIdx.x == 7 && tid == 64)
+    printf("stem3 fwd phases (cycles/item, wave 1 of block 7, %d items): dma wait %lld, slot build %lld, issue %lld, mfma %lld, store+stats %lld, loop head %lld\n",
+           nloc, tph[0] / nloc, tph[1] / nloc, tph[2] / nloc, tph[3] / nloc, tph[4] / nloc, tph[5] / nloc);
   if (a.stats) {
-    ssum += __shfl_xor(ssum, 16, 64); ssum += __shfl_xor(ssum, 32, 64);
-    ssq += __shfl_xor(ssq, 16, 64); ssq += __shfl_xor(ssq, 32, 64);
-    if (lane < 16) {
-      red[wave][lane] = ssum;
-      red[wave][OCB + lane] = ssq;
+    // the 16 lanes of a group hold the same 4 channels for different pixels
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        cs[i] += __shfl_xor(cs[i], o, 64);
+        cq[i] += __shfl_xor(cq[i], o, 64);
+      }
+    if (row == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        red[wave][4 * g + i] = cs[i];
+        red[wave][OCB + 4 * g + i] = cq[i];
+      }
     }
     __syncthreads();
     if (tid < OCB) {
@@ -898,6 +1066,7 @@ __global__ __launch_bounds__(256) void stem3_fwd_dma_kernel(StemArgs a) {
     }
   }
 }
+#undef S3D_TICK
 
 // the DMA forward additionally needs 16-byte-aligned rows (pointer, strides) of whole chunks and the reference stem's 3x3 window rows
 bool stem3_dma_ok(const pb_stem_shape* s, const void* x) {
@@ -956,16 +1125,24 @@ extern "C" int pb_stem_conv3d_fwd(const void* x, int x_dtype, float x_scale, con
   if (s->kt * s->kh * wl * s->Cin <= SW_MAXWIN && s->Cin * s->kt * s->kh * s->kw <= 32 * SW_KS &&
       s->kt * s->kh <= FW_R && wl * s->Cin <= 64 * FW_I) {
     const int64_t items = (int64_t)s->N * s->To * s->Ho * pb_cdiv(s->Wo, SW_PIX);
+    static const int fwd_wgs = getenv("PB_STEM_FWD_WGS") ? atoi(getenv("PB_STEM_FWD_WGS")) : 0;
+    const bool dma = stem3_ok(s, x_dtype, dtype) && x_scale == 1.f && stem3_dma_ok(s, x);
+    // the DMA kernel: 3 resident workgroups per CU (52 KB of LDS each), each walking its share of the items - every
+    // workgroup pays ~8k cycles before its first item (the filter, the item walk's divisions): 2048 workgroups in three rounds
+    // measured 128 us, 768 in one round 122
+    const int64_t cap = fwd_wgs > 0 ? fwd_wgs : (dma ? 768 : 2048);
     int64_t gx = pb_cdiv(items, 4);
-    if (gx > 2048) gx = 2048;
+    if (gx > cap) gx = cap;
     if (stats && gx > stat_slots) gx = stat_slots;             // one statistics slot per workgroup
     dim3 grid((unsigned)gx, (unsigned)pb_cdiv(s->Cout, OCB));
-    if (stem3_ok(s, x_dtype, dtype) && x_scale == 1.f && stem3_dma_ok(s, x)) {
+    if (dma) {
       static bool attr = false;
       if (!attr) {
         PB_HIP(hipFuncSetAttribute((const void*)stem3_fwd_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S3D_LDS));
         attr = true;
       }
+      static const int ablate = getenv("PB_STEM_ABLATE") ? atoi(getenv("PB_STEM_ABLATE")) : 0;
+      a.ablate = ablate;
       hipLaunchKernelGGL(stem3_fwd_dma_kernel, grid, dim3(256), S3D_LDS, st, a);
     } else if (stem3_ok(s, x_dtype, dtype) && x_scale == 1.f) hipLaunchKernelGGL(stem3_fwd_kernel, grid, dim3(256), 0, st, a);
     else PB_STEM_DISPATCH(stem_fwd_mfma_kernel, grid);

@@ -109,6 +109,7 @@ CASES = {
                    dw(960, (15, 7, 7), 5, 1, se=True)],
     "dw_small": lambda: [dw(960, (15, 7, 7), 5, 1, se=True), dw(120, (10, 28, 28), 5, 1, se=True),
                          dw(672, (16, 14, 14), 3, 1, se=True)],
+    "ew_small": lambda: [ew(17248, 160), ew(50176, 80), ew(100352, 112), ew(150528, 40)],
     "ew": lambda: [ew(4014080, 16), ew(602112, 24), ew(351232, 40), ew(112896, 112), ew(29792, 160), ew(29792, 960)],
 }
 
