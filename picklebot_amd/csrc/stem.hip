@@ -457,17 +457,19 @@ struct S3Regs {
   u32x4 v[S3_NT];
 };
 // a lane's S3_NT slot tasks: window row, (frame, line) of that row, slot position, element offset of its 12 bytes from the
-// window's first pixel - constants of the launch
+// window's first pixel (of the LAST window row for the tasks past the image: a valid address, masked) - constants of the launch
 struct S3Tasks {
   int row[S3_NT], at[S3_NT], ah[S3_NT], sp[S3_NT], off[S3_NT];
   __device__ __forceinline__ void init(const pb_stem_shape& s, int lane) {
+    const int nrows = s.kt * s.kh;
 #pragma unroll
     for (int k = 0; k < S3_NT; ++k) {
       const int t = lane + 64 * k;
       row[k] = t / S3_SP;
       sp[k] = t - row[k] * S3_SP;
-      at[k] = row[k] / s.kh;
-      ah[k] = row[k] - at[k] * s.kh;
+      const int rc = min(row[k], nrows - 1);
+      at[k] = rc / s.kh;
+      ah[k] = rc - at[k] * s.kh;
       off[k] = (int)((int64_t)at[k] * s.xs_t + (int64_t)ah[k] * s.xs_h) + 6 * sp[k];      // (< 2^31 elements: a few frames)
     }
   }
@@ -478,28 +480,25 @@ __device__ __forceinline__ void s3_load(S3Regs& rg, const bf16_t* x, const pb_st
   const int nrows = s.kt * s.kh;
   const int ti0 = to * s.st - s.pt, hi0 = ho * s.sh - s.ph, wi0 = wo0 * 2 - s.pw;
   const bf16_t* xn = x + (int64_t)n * s.xs_n;
-  // (wave-uniform) every window row inside the clip - 7 of 8 frames: one base address, the lane's constant offset, and only
-  // the pixel tests along the row are left (the general path below costs ~60 instructions per slot task: three 64-bit
-  // multiplies and the row tests)
-  if (ti0 >= 0 && ti0 + s.kt <= s.Ti && hi0 >= 0 && hi0 + s.kh <= s.Hi) {
+  // (wave-uniform) every window row inside the clip - 7 of 8 frames.  ALL of the lane's loads are issued unconditionally from
+  // one base address plus the lane's constant offset, the pixels outside the row are masked afterwards: the general path below
+  // branches per slot (whole / half / no slot) and its loads, each waited for inside its branch, went out one round trip after
+  // the other - 3200 of the weight gradient's 5800 cycles per item.  A slot that hangs over the row's end reads the
+  // neighbouring line's bytes: never over the frame's first or last line (excluded here), so always inside the clip.
+  const bool over_first = wi0 < 0 && hi0 == 0, over_last = wi0 + 2 * (S3_SP - 1) + 1 >= s.Wi && hi0 + s.kh == s.Hi;
+  if (ti0 >= 0 && ti0 + s.kt <= s.Ti && hi0 >= 0 && hi0 + s.kh <= s.Hi && !over_first && !over_last && s.xs_h >= (int64_t)s.Wi * 3) {
     const bf16_t* base = xn + (int64_t)ti0 * s.xs_t + (int64_t)hi0 * s.xs_h + (int64_t)wi0 * 3;
+    u32x3 q[S3_NT];
+#pragma unroll
+    for (int k = 0; k < S3_NT; ++k) q[k] = *reinterpret_cast<const u32x3*>(base + tk.off[k]);     // 12 bytes at a 2-byte-aligned address
 #pragma unroll
     for (int k = 0; k < S3_NT; ++k) {
-      u32x4 o = {0u, 0u, 0u, tk.row[k] == 0 ? 0x3f80u : 0u};
       const int wa = wi0 + 2 * tk.sp[k];
-      const bool oka = tk.row[k] < nrows && (unsigned)wa < (unsigned)s.Wi, okb = tk.row[k] < nrows && (unsigned)(wa + 1) < (unsigned)s.Wi;
-      const bf16_t* p = base + tk.off[k];
-      if (oka && okb) {
-        const u32x3 q = *reinterpret_cast<const u32x3*>(p);                    // 12 bytes at a 2-byte-aligned address
-        o[0] = q[0]; o[1] = q[1]; o[2] = q[2];
-      } else if (oka || okb) {
-        const unsigned short* ps = reinterpret_cast<const unsigned short*>(p);
-        unsigned e[6] = {0u, 0u, 0u, 0u, 0u, 0u};
-        if (oka) { e[0] = ps[0]; e[1] = ps[1]; e[2] = ps[2]; }
-        if (okb) { e[3] = ps[3]; e[4] = ps[4]; e[5] = ps[5]; }
-        o[0] = e[0] | (e[1] << 16); o[1] = e[2] | (e[3] << 16); o[2] = e[4] | (e[5] << 16);
-      }
-      rg.v[k] = o;
+      const bool rok = tk.row[k] < nrows;
+      const bool oka = rok && (unsigned)wa < (unsigned)s.Wi, okb = rok && (unsigned)(wa + 1) < (unsigned)s.Wi;
+      // elements 0..2 = pixel wa, 3..5 = pixel wa + 1
+      rg.v[k] = u32x4{oka ? q[k][0] : 0u, (oka ? q[k][1] & 0x0000ffffu : 0u) | (okb ? q[k][1] & 0xffff0000u : 0u), okb ? q[k][2] : 0u,
+                      tk.row[k] == 0 ? 0x3f80u : 0u};
     }
     return;
   }
@@ -633,12 +632,27 @@ __global__ __launch_bounds__(64 * S3W_NW) void stem3_wgrad_kernel(StemArgs a) {
   };
   int64_t it = (int64_t)blockIdx.x * S3W_NW + wave;
   if (it < nitems) fetch(it);
+  long long tph[4] = {0, 0, 0, 0};
+  long long tlast = __builtin_amdgcn_s_memtime();
+  int nit = 0;
+#ifdef PB_STEM_PROBE
+#define S3W_TICK(i) do { if (a.ablate == 3) { const long long tn = __builtin_amdgcn_s_memtime(); tph[i] += tn - tlast; tlast = tn; } } while (0)
+#define S3W_ABLATE a.ablate
+#else
+#define S3W_TICK(i) do { } while (0)
+#define S3W_ABLATE 0
+#endif
   for (; it < nitems; it += step) {
+    ++nit;
+    if (S3W_ABLATE == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    S3W_TICK(0);
     s3_store(rg, win, nrows, lane);
     vec_store<T>(dyt + lane * 8, dyv);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
+    S3W_TICK(1);
     if (it + step < nitems) fetch(it + step);
+    S3W_TICK(2);
     typedef __attribute__((address_space(3))) bf16x4* lds_p;
     const bf16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(dyt + (8 * g + q) * OCB + 4 * p4));
     const bf16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(dyt + (8 * g + 4 + q) * OCB + 4 * p4));
@@ -654,7 +668,13 @@ __global__ __launch_bounds__(64 * S3W_NW) void stem3_wgrad_kernel(StemArgs a) {
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
+    S3W_TICK(3);
   }
+  if (S3W_ABLATE == 3 && blockIdx.x == 7 && tid == 64)
+    printf("stem3 wgrad phases (cycles/item, wave 1 of block 7, %d items): load wait %lld, lds stores %lld, fetch issue %lld, mfma %lld\n",
+           nit, tph[0] / nit, tph[1] / nit, tph[2] / nit, tph[3] / nit);
+#undef S3W_TICK
+#undef S3W_ABLATE
   // D[oc][n] per window row: n < 6 -> tap (aw = n/3, ci = n%3); 8 <= n < 11 -> (aw = 2, ci = n-8); row 0, n = 6 -> bias.
   // Cross-wave sum in wave order (no atomics), then plain stores into this workgroup's slot of the workspace.
   for (int i = tid; i < OCB * S3_MAXROWS * 16; i += 64 * S3W_NW) red[i] = 0.f;
@@ -815,6 +835,13 @@ __device__ __forceinline__ void s3d_glds16(const void* gsrc, unsigned lds_dst) {
                : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
+#ifdef PB_STEM_PROBE     // (hipcc -DPB_STEM_PROBE + PB_STEM_ABLATE=1 DMA only / 2 compute only / 3 cycles per phase: how the numbers above were taken)
+#define S3D_TICK(i) do { if (a.ablate == 3) { const long long tn = __builtin_amdgcn_s_memtime(); tph[i] += tn - tlast; tlast = tn; } } while (0)
+#define S3D_ABLATE a.ablate
+#else
+#define S3D_TICK(i) do { } while (0)
+#define S3D_ABLATE 0
+#endif
 __global__ __launch_bounds__(256) void stem3_fwd_dma_kernel(StemArgs a) {
   typedef bf16_t T;
   extern __shared__ __attribute__((aligned(1024))) unsigned char s3d_smem[];
@@ -910,7 +937,7 @@ __global__ __launch_bounds__(256) void stem3_fwd_dma_kernel(StemArgs a) {
       }
     }
   };
-  if (a.ablate != 2)
+  if (S3D_ABLATE != 2)
     for (int k = 0; k < min(nloc, S3D_NRAW); ++k) issue();
   // slot build: task kk of a lane is slot t = lane + 64 kk of the image - its window row, frame / line and position, its 12
   // source bytes inside a raw buffer and whether it exists are per-lane constants too
@@ -930,7 +957,7 @@ __global__ __launch_bounds__(256) void stem3_fwd_dma_kernel(StemArgs a) {
 
   long long tph[6] = {0, 0, 0, 0, 0, 0};
   long long tlast = __builtin_amdgcn_s_memtime();
-#define S3D_TICK(i) do { if (a.ablate == 3) { const long long tn = __builtin_amdgcn_s_memtime(); tph[i] += tn - tlast; tlast = tn; } } while (0)
+
   for (int k = 0; k < nloc; ++k) {
     const S3Item cur = wcur.item();
     wcur.next();
@@ -956,7 +983,7 @@ __global__ __launch_bounds__(256) void stem3_fwd_dma_kernel(StemArgs a) {
       }
     }
     S3D_TICK(0);
-    if (a.ablate == 1) {
+    if (S3D_ABLATE == 1) {
       if (k + S3D_NRAW < nloc) issue();
       continue;
     }
@@ -999,7 +1026,7 @@ __global__ __launch_bounds__(256) void stem3_fwd_dma_kernel(StemArgs a) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
     S3D_TICK(1);
-    if (k + S3D_NRAW < nloc && a.ablate != 2) issue();           // this item's raw buffer is free again
+    if (k + S3D_NRAW < nloc && S3D_ABLATE != 2) issue();         // this item's raw buffer is free again
     S3D_TICK(2);
     f32x4 acc[2], accl[2];
     acc[0] = acc[1] = accl[0] = accl[1] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1039,7 +1066,7 @@ __global__ __launch_bounds__(256) void stem3_fwd_dma_kernel(StemArgs a) {
     }
     S3D_TICK(4);
   }
-  if (a.ablate == 3 && blockIdx.x == 7 && tid == 64)
+  if (S3D_ABLATE == 3 && blockIdx.x == 7 && tid == 64)
     printf("stem3 fwd phases (cycles/item, wave 1 of block 7, %d items): dma wait %lld, slot build %lld, issue %lld, mfma %lld, store+stats %lld, loop head %lld\n",
            nloc, tph[0] / nloc, tph[1] / nloc, tph[2] / nloc, tph[3] / nloc, tph[4] / nloc, tph[5] / nloc);
   if (a.stats) {
@@ -1067,6 +1094,7 @@ __global__ __launch_bounds__(256) void stem3_fwd_dma_kernel(StemArgs a) {
   }
 }
 #undef S3D_TICK
+#undef S3D_ABLATE
 
 // the DMA forward additionally needs 16-byte-aligned rows (pointer, strides) of whole chunks and the reference stem's 3x3 window rows
 bool stem3_dma_ok(const pb_stem_shape* s, const void* x) {
@@ -1194,6 +1222,8 @@ extern "C" int pb_stem_conv3d_bwd_weight(const void* dy, const void* x, int x_dt
                "pb_stem_conv3d_bwd_weight: window (%d rows x %d) exceeds the staged maximum", s->kt * s->kh, wl * s->Cin);
   const int64_t gx = stem_wgrad_gx(s, x_dtype, x_scale, dtype);
   dim3 grid((unsigned)gx, (unsigned)pb_cdiv(s->Cout, OCB));
+  static const int ablate_w = getenv("PB_STEM_ABLATE") ? atoi(getenv("PB_STEM_ABLATE")) : 0;
+  a.ablate = ablate_w;
   if (stem3_ok(s, x_dtype, dtype) && x_scale == 1.f) hipLaunchKernelGGL(stem3_wgrad_kernel, grid, dim3(64 * S3W_NW), 0, st, a);
   else PB_STEM_DISPATCH(stem_wgrad_kernel, grid);
   PB_LAUNCH_CHECK();
