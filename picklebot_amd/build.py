@@ -20,6 +20,7 @@ LIB = os.path.join(LIBDIR, "libpicklebot_amd.so")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable", "-I", INCLUDE]
+FLAGS += os.environ.get("PB_BUILD_DEFINES", "").split()      # e.g. -DPB_STEM_PROBE / -DPB_STREAM_PROBE: phase timers (experiments)
 
 
 def _hipcc():

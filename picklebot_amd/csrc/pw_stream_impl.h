@@ -24,6 +24,15 @@
 #include <stdlib.h>
 #include <type_traits>
 
+// -DPB_STREAM_PROBE: cycles per phase of one wave (block 9, wave 1) printed at the end of every launch (experiments only)
+#ifdef PB_STREAM_PROBE
+#define PWS_PROBE_DECL long long pws_t[5] = {0, 0, 0, 0, 0}; long long pws_last = __builtin_amdgcn_s_memtime();
+#define PWS_TICK(i) do { const long long tn = __builtin_amdgcn_s_memtime(); pws_t[i] += tn - pws_last; pws_last = tn; } while (0)
+#else
+#define PWS_PROBE_DECL
+#define PWS_TICK(i) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int STHREADS = 512;
@@ -91,6 +100,7 @@ __global__ __launch_bounds__(STHREADS) void pw_stream_kernel(StreamArgs a) {
   float* osc = (float*)(dump + 8192);                // [CG][2][BN] scale / shift (non-plain epilogues only)
   const bool rot = (CH & 1) == 0;
 
+  PWS_PROBE_DECL
   // ---- this workgroup's tiles
   const int r8 = (int)(blockIdx.x & 7), u = (int)(blockIdx.x >> 3);
   const int g0 = u / a.wgc, ntw = u - g0 * a.wgc;
@@ -100,21 +110,6 @@ __global__ __launch_bounds__(STHREADS) void pw_stream_kernel(StreamArgs a) {
   const int G_r = a.m_tiles > r8 ? (a.m_tiles - r8 + 7) >> 3 : 0;          // row-panel groups that exist for this r8
   const int n_my = g0 < G_r ? (G_r - g0 + a.q - 1) / a.q : 0;
   if (n_my == 0) return;
-
-  // ---- the weight slice, in registers for the whole launch (rows past N repeat row N-1: never stored)
-  bf16x8 wf[NT][KS];
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int n = min(n0 + j * 16 + frow, a.N - 1);
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const int k = ks * 32 + fk * 8;
-      bf16x8 z;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) z[e] = (bf16_t)0.f;
-      wf[j][ks] = (k < a.K && active) ? *reinterpret_cast<const bf16x8*>(a.WB + (int64_t)n * a.K + k) : z;
-    }
-  }
 
   // ---- DMA: instruction q of a stage moves chunks q*512 + tid; constant per thread, the source advances by a fixed
   // stride from one of this workgroup's panels to the next
@@ -168,6 +163,30 @@ __global__ __launch_bounds__(STHREADS) void pw_stream_kernel(StreamArgs a) {
     }
   };
 
+  // The first stage's DMA goes out BEFORE the weight slice is fetched: the two round trips used to follow each other (the
+  // compiler waits for the weight loads with vmcnt(0) ahead of everything that follows), ~2500 of a workgroup's ~8000 prologue
+  // cycles on layers that give a workgroup only 2-4 panels (PB_STREAM_PROBE).  The deeper stages follow once the weights are in.
+  issue(0, 0);
+  // ---- the weight slice, in registers for the whole launch (rows past N repeat row N-1: never stored)
+  bf16x8 wf[NT][KS];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int n = min(n0 + j * 16 + frow, a.N - 1);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int k = ks * 32 + fk * 8;
+      bf16x8 z;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) z[e] = (bf16_t)0.f;
+      wf[j][ks] = (k < a.K && active) ? *reinterpret_cast<const bf16x8*>(a.WB + (int64_t)n * a.K + k) : z;
+    }
+  }
+
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(wf[j][ks]));      // (consumed HERE: a wait for them at their first use inside the
+  // panel loop is an s_waitcnt vmcnt(0) in that loop, behind the prefetched stages and the stores - measured 3-23 % per panel)
   // ---- epilogue constants
   const bool plain = !a.out_scale && !a.out_shift && a.out_act == PB_ACT_NONE;
   if (!plain) {
@@ -287,12 +306,13 @@ __global__ __launch_bounds__(STHREADS) void pw_stream_kernel(StreamArgs a) {
     }
   };
 
-  int it = 0, ibuf = 0;
+  int it = 1, ibuf = 1;                              // (stage 0 was issued ahead of the weight loads)
 #pragma unroll 1
   for (; it < NS - 1; ++it) {
     issue(it, ibuf);
     if (++ibuf == NS) ibuf = 0;
   }
+  PWS_TICK(0);
   int cbuf = 0;
   const int64_t row_step = (int64_t)16 * a.N;        // elements between row blocks
 #pragma unroll 1
@@ -316,7 +336,9 @@ __global__ __launch_bounds__(STHREADS) void pw_stream_kernel(StreamArgs a) {
       wait_vm<0>();
     }
     lds_barrier();                                   // everybody's chunks are in; everybody is done with the stage refilled next
+    PWS_TICK(1);
     issue(it, ibuf);
+    PWS_TICK(2);
     ++it;
     if (++ibuf == NS) ibuf = 0;
     const unsigned char* As = smem + cbuf * stage_bytes;
@@ -343,7 +365,14 @@ __global__ __launch_bounds__(STHREADS) void pw_stream_kernel(StreamArgs a) {
         }
       }
     }
+    PWS_TICK(3);
   }
+  PWS_TICK(4);
+#ifdef PB_STREAM_PROBE
+  if (blockIdx.x == 9 && tid == 64)
+    printf("pw_stream<NT %d KS %d CG %d RB %d> M %lld K %d N %d grid %d: %d panels; cycles: prologue %lld, per panel: wait+barrier %lld, issue %lld, compute %lld; tail %lld\n",
+           NT, KS, CG, RB, (long long)a.M, a.K, a.N, (int)gridDim.x, n_my, pws_t[0], pws_t[1] / n_my, pws_t[2] / n_my, pws_t[3] / n_my, pws_t[4]);
+#endif
   wait_vm<0>();                                      // no DMA may land in LDS after the workgroup has given it back
   if constexpr (STATS) {
     // column sums: over the 16 rows of a block (lanes with equal fk), then over the RG row groups through LDS

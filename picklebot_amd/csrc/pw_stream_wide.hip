@@ -119,6 +119,12 @@ __global__ __launch_bounds__(STHREADS) void pw_stream_wide_kernel(WideArgs wa) {
     if (a.out_scale) osc[r] = a.out_scale[n];
     if (a.out_shift) osh[r] = a.out_shift[n];
   }
+  // Everything this wave loads into registers is CONSUMED here, ahead of the DMA prologue: a register whose load the compiler
+  // still has to wait for at its first use inside the panel loop costs an s_waitcnt vmcnt(0) in that loop - behind the
+  // prefetched stages and the stores - and the ring stops being a ring (pw_stream_impl.h: 3-23 % per panel, PB_STREAM_PROBE)
+#pragma unroll
+  for (int ks = 0; ks < KSMAX; ++ks) asm volatile("" : "+v"(wf[ks]));
+  asm volatile("" : "+v"(osc), "+v"(osh));
   const bool col_ok = n0 + fk * 4 < a.N;             // N % 8 == 0: a lane's 4 columns are valid together
   const int n_st = (a.R || !active) ? 0 : RB;        // (residual loads are waited for with vmcnt(0) by the compiler)
   int allow = (NS - 2) * DPS + (NS - 2) * n_st;
