@@ -600,14 +600,30 @@ extern "C" int pb_pwconv_fwd_bf16w(const void* x, const void* wb, void* y, int64
   PB_CHECK_ARG(total <= 0x3fffffffLL, "pb_pwconv_fwd_bf16w: too many tiles");
   hipStream_t st = (hipStream_t)stream;
   int rc = 0;
-  // a 2-stage ring leaves room for two workgroups per CU, whose epilogues overlap each other's streaming
-  switch (nt) {
-    case 2: rc = launch_dma<2, 2>(a, total, device, st); break;
-    case 3: rc = launch_dma<3, 2>(a, total, device, st); break;
-    case 4: rc = launch_dma<4, 2>(a, total, device, st); break;
-    case 5: rc = launch_dma<5, 2>(a, total, device, st); break;
-    case 6: rc = launch_dma<6, 2>(a, total, device, st); break;
-    default: rc = launch_dma<7, 2>(a, total, device, st); break;
+  // a 2-stage ring leaves room for two workgroups per CU, whose epilogues overlap each other's streaming.  Long reductions
+  // (K >= 400: 8-15 stages per tile, each waited for with one stage in flight) run ONE workgroup per CU with a 4-stage ring -
+  // three stages in flight: 32-34 -> 27 us on the 960 -> 160 layers of the 7x7 stage, 34.6 -> 30.5 on 480 -> 80; shorter
+  // reductions measured slower that way (PB_GEMM_DMA_NS / PB_GEMM_DMA_NS_MINK)
+  static const int deep_ns = getenv("PB_GEMM_DMA_NS") ? atoi(getenv("PB_GEMM_DMA_NS")) : 4;
+  static const int deep_mink = getenv("PB_GEMM_DMA_NS_MINK") ? atoi(getenv("PB_GEMM_DMA_NS_MINK")) : 400;
+  if (deep_ns == 4 && K >= deep_mink) {
+    switch (nt) {
+      case 2: rc = launch_dma<2, 4>(a, total, device, st); break;
+      case 3: rc = launch_dma<3, 4>(a, total, device, st); break;
+      case 4: rc = launch_dma<4, 4>(a, total, device, st); break;
+      case 5: rc = launch_dma<5, 4>(a, total, device, st); break;
+      case 6: rc = launch_dma<6, 4>(a, total, device, st); break;
+      default: rc = launch_dma<7, 4>(a, total, device, st); break;
+    }
+  } else {
+    switch (nt) {
+      case 2: rc = launch_dma<2, 2>(a, total, device, st); break;
+      case 3: rc = launch_dma<3, 2>(a, total, device, st); break;
+      case 4: rc = launch_dma<4, 2>(a, total, device, st); break;
+      case 5: rc = launch_dma<5, 2>(a, total, device, st); break;
+      case 6: rc = launch_dma<6, 2>(a, total, device, st); break;
+      default: rc = launch_dma<7, 2>(a, total, device, st); break;
+    }
   }
   if (rc) return rc;
   PB_LAUNCH_CHECK();
