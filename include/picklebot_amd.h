@@ -34,7 +34,7 @@ typedef enum {
   PB_ACT_HSIGMOID = 4, PB_ACT_SILU = 5
 } pb_act;
 
-#define PB_ABI_VERSION 20
+#define PB_ABI_VERSION 21
 
 /* Determinism.  Nothing in this library accumulates with floating-point atomics: two runs of the same binary on the
  * same inputs give bit-identical outputs and gradients.  Every reduction that spans workgroups stores one partial
@@ -356,6 +356,22 @@ int pb_se_fused_bwd(const float* dscale_part, int slots, const float* pool, floa
  * bias gradients follow from `work` with pb_se_fc_bwd_w - later, or on another stream (nothing on the data-gradient chain reads them). */
 int pb_se_fc_bwd_w(const float* work, const float* pool, float inv_count, const float* hidden, float* dw1, float* db1, float* dw2,
                    float* db2, int G, int C, int Cm, int device, void* stream);
+
+/* The pooled classifier head - AdaptiveAvgPool3d(1) -> Conv3d(C, Cm, 1) -> Hardswish (or ReLU) -> Conv3d(Cm, Co, 1)
+ * (mobilenet.py:143-146 / 227-230 `classifier`) - on the squeeze-excite gate's kernels (fp32 weights, fixed-order sums): three
+ * launches forward (pb_rowgroup_partials + the two here), two on the data-gradient chain backward, the weight gradients apart.
+ *   forward:  pool_part fp32 [slots][G][C] -> pool [G][C] (sums), pre1 [G][Cm] (pre-activation of the hidden layer),
+ *             logits [G][Co] fp32 and, optionally, a bf16 copy (what the reference's autocast returns).
+ *   backward: dlogits fp32 [G][Co] -> dpool_row [G][C] (optionally also as bf16): the gradient of EVERY row of clip g that
+ *             was pooled (1/count included); work [G][Co + Cm] = dlogits | dpre1 for pb_pool_head_bwd_w.
+ *   weights:  dw1 [Cm][C], db1 [Cm], dw2 [Co][Cm], db2 [Co] += (fixed order over the clips). */
+int pb_pool_head_fwd(const float* pool_part, int slots, float inv_count, const float* w1, const float* b1, const float* w2, const float* b2,
+                     pb_act act1, float* pool, float* logits, void* logits_bf16, float* pre1, int G, int C, int Cm, int Co, int device,
+                     void* stream);
+int pb_pool_head_bwd(const float* dlogits, float inv_count, const float* pre1, const float* w1, const float* w2, pb_act act1,
+                     float* dpool_row, void* dpool_row_bf16, float* work, int G, int C, int Cm, int Co, int device, void* stream);
+int pb_pool_head_bwd_w(const float* work, const float* pool, float inv_count, const float* pre1, pb_act act1, float* dw1, float* db1,
+                       float* dw2, float* db2, int G, int C, int Cm, int Co, int device, void* stream);
 /* Row-group partial sums only (the first half of pb_rowgroup_reduce): part fp32 [slots][G][C] with
  * slots = pb_rowgroup_slots(...) for a consumer that adds the slots itself (pb_se_fused_bwd / pb_se_fused_fwd). */
 int pb_rowgroup_slots(int64_t G, int64_t rows_per_group, int C, pb_dtype dtype);

@@ -398,6 +398,39 @@ def se_fused_fwd(pool_part, inv_count, w1, b1, w2, b2, wproj=None, want_scaled=F
     return pool, scale, hidden, None
 
 
+def _head_act(x, act):
+    return F.hardswish(x) if act == "hardswish" else torch.relu(x)
+
+
+def pool_head_fwd(pool_part, inv_count, w1, b1, w2, b2, act, out_dtype):
+    """mirror of kernels.pool_head_fwd (fp32 throughout; logits rounded to out_dtype at the end)"""
+    pool = pool_part.sum(0)
+    pre1 = (pool * inv_count) @ w1.t() + (b1 if b1 is not None else 0)
+    logits = _head_act(pre1, act) @ w2.t() + (b2 if b2 is not None else 0)
+    return pool, pre1, logits.to(out_dtype)
+
+
+def pool_head_bwd(dlogits, inv_count, pre1, w1, w2, act, row_dtype):
+    h = pre1.detach().clone().requires_grad_(True)
+    with torch.enable_grad():
+        a = _head_act(h, act)
+    dpre1, = torch.autograd.grad(a, h, dlogits @ w2)
+    row = (dpre1 @ w1) * inv_count
+    return row.to(row_dtype), torch.cat([dlogits, dpre1], dim=1)
+
+
+def pool_head_bwd_w(work, pool, inv_count, pre1, act, dw1, db1, dw2, db2):
+    Cm = pre1.shape[1]
+    Co = work.shape[1] - Cm
+    dlogits, dpre1 = work[:, :Co], work[:, Co:]
+    dw2 += dlogits.t() @ _head_act(pre1, act)
+    dw1 += dpre1.t() @ (pool * inv_count)
+    if db2 is not None:
+        db2 += dlogits.sum(0)
+    if db1 is not None:
+        db1 += dpre1.sum(0)
+
+
 def rowgroup_partials(a, b, G):
     return rowgroup_reduce(a, b, G).unsqueeze(0)
 

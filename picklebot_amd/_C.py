@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libpicklebot_amd.so")
 
 PB_F32, PB_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY_RELU, ACT_HSWISH, ACT_HSIGMOID, ACT_SILU = range(6)
-ABI_VERSION = 20
+ABI_VERSION = 21
 STAT_SLOTS = 512
 
 
@@ -65,6 +65,9 @@ SIGNATURES = {
     "pb_se_fused_fwd": [P, I, F, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P],
     "pb_se_fused_bwd": [P, I, P, F, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P],
     "pb_se_fc_bwd_w": [P, P, F, P, P, P, P, P, I, I, I, I, P],
+    "pb_pool_head_fwd": [P, I, F, P, P, P, P, I, P, P, P, P, I, I, I, I, I, P],
+    "pb_pool_head_bwd": [P, F, P, P, P, I, P, P, P, I, I, I, I, I, P],
+    "pb_pool_head_bwd_w": [P, P, F, P, I, P, P, P, P, I, I, I, I, I, P],
     "pb_rowgroup_partials": [P, P, P, L, L, I, I, I, P],
     "pb_transpose_f32": [P, P, I, I, I, P],
     "pb_pw_weight_prep": [P, I, I, I, P, I, P, I, P],

@@ -79,36 +79,42 @@ __global__ __launch_bounds__(256) void se_dpre2_kernel(const float* dscale, cons
 }
 
 // weight gradients: loops over the G clips, one thread per weight element (deterministic)
+// (Co = outputs of the second FC: C for a squeeze-excite gate, the class count for the pooled head; act1 = 1: `hidden` holds
+// the PRE-activation of a hardswish, act1 = 0: the ReLU's output)
+__device__ __forceinline__ float se_hswish(float x) { return x * fminf(fmaxf(x + 3.f, 0.f), 6.f) * (1.f / 6.f); }
 __global__ __launch_bounds__(256) void se_fc_bwd_w_kernel(const float* work, const float* pool, float inv_count,
                                                           const float* hidden, float* dw1, float* db1, float* dw2,
-                                                          float* db2, int G, int C, int Cm) {
+                                                          float* db2, int G, int C, int Cm, int Co, int act1) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t nW = (int64_t)C * Cm;
-  const int stride = C + Cm;
-  if (idx < nW) {                       // dW2[c][j] = sum_g dpre2[g][c] * h[g][j]
+  const int64_t nW2 = (int64_t)Co * Cm, nW1 = (int64_t)C * Cm;
+  const int stride = Co + Cm;
+  if (idx < nW2) {                      // dW2[c][j] = sum_g dpre2[g][c] * h[g][j]
     const int c = (int)(idx / Cm), j = (int)(idx - (int64_t)c * Cm);
     float s = 0.f;
 #pragma unroll 8
-    for (int g = 0; g < G; ++g) s += work[(int64_t)g * stride + c] * hidden[(int64_t)g * Cm + j];
+    for (int g = 0; g < G; ++g) {
+      const float h = hidden[(int64_t)g * Cm + j];
+      s += work[(int64_t)g * stride + c] * (act1 ? se_hswish(h) : h);
+    }
     dw2[idx] += s;
-  } else if (idx < 2 * nW) {            // dW1[j][c] = sum_g dh[g][j] * mean[g][c]
-    const int64_t i = idx - nW;
+  } else if (idx < nW2 + nW1) {         // dW1[j][c] = sum_g dh[g][j] * mean[g][c]
+    const int64_t i = idx - nW2;
     const int j = (int)(i / C), c = (int)(i - (int64_t)j * C);
     float s = 0.f;
 #pragma unroll 8
-    for (int g = 0; g < G; ++g) s += work[(int64_t)g * stride + C + j] * pool[(int64_t)g * C + c] * inv_count;
+    for (int g = 0; g < G; ++g) s += work[(int64_t)g * stride + Co + j] * pool[(int64_t)g * C + c] * inv_count;
     dw1[i] += s;
-  } else if (idx < 2 * nW + C) {        // db2
-    const int c = (int)(idx - 2 * nW);
+  } else if (idx < nW2 + nW1 + Co) {    // db2
+    const int c = (int)(idx - nW2 - nW1);
     float s = 0.f;
 #pragma unroll 8
     for (int g = 0; g < G; ++g) s += work[(int64_t)g * stride + c];
     if (db2) db2[c] += s;
-  } else if (idx < 2 * nW + C + Cm) {   // db1
-    const int j = (int)(idx - 2 * nW - C);
+  } else if (idx < nW2 + nW1 + Co + Cm) {   // db1
+    const int j = (int)(idx - nW2 - nW1 - Co);
     float s = 0.f;
 #pragma unroll 8
-    for (int g = 0; g < G; ++g) s += work[(int64_t)g * stride + C + j];
+    for (int g = 0; g < G; ++g) s += work[(int64_t)g * stride + Co + j];
     if (db1) db1[j] += s;
   }
 }
@@ -130,6 +136,9 @@ struct SeFwdArgs {
   bf16_t* wbs;            // ... scaled per clip for the LDS-DMA GEMM: out bf16 [G][N][C] = wproj[n][c] * scale[g][c]
   int G, C, Cm, N;
   int assoc;              // slot-sum association (slot_sum_to_lds)
+  int Co;                 // outputs of the second FC (= C for a squeeze-excite gate; the class count for the pooled head)
+  int act1, act2;         // 0 / 0: ReLU, hardsigmoid (squeeze-excite); 1: hardswish with `hidden` = its PRE-activation; act2 = 1: none
+  bf16_t* scale_bf16;     // optional bf16 copy of `scale` (the head's logits)
 };
 
 // sum over the slots of part[.][g][c] for c = tid, tid + nthreads, ... -> dst (LDS).  Eight loads in flight per thread:
@@ -200,7 +209,7 @@ __global__ __launch_bounds__(SE_HT) void se_hidden_kernel(SeFwdArgs a) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     float v = wave_sum(s[q]) * a.inv_count + ((a.b1 && j0 + q < a.Cm) ? a.b1[j0 + q] : 0.f);
-    if (lane == 0 && j0 + q < a.Cm) a.hidden[(int64_t)g * a.Cm + j0 + q] = v > 0.f ? v : 0.f;
+    if (lane == 0 && j0 + q < a.Cm) a.hidden[(int64_t)g * a.Cm + j0 + q] = a.act1 ? v : (v > 0.f ? v : 0.f);
   }
 }
 
@@ -209,10 +218,13 @@ __global__ __launch_bounds__(SE_HT) void se_hidden_kernel(SeFwdArgs a) {
 __global__ __launch_bounds__(256) void se_scale_kernel(SeFwdArgs a) {
   extern __shared__ float sm[];                 // hidden[Cm] | scale block[64]
   const int g = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int C = a.C, Cm = a.Cm;
+  const int C = a.C, Cm = a.Cm, Co = a.Co;
   float* hid = sm;
   float* scl = sm + Cm;
-  for (int j = tid; j < Cm; j += 256) hid[j] = a.hidden[(int64_t)g * Cm + j];
+  for (int j = tid; j < Cm; j += 256) {
+    const float h = a.hidden[(int64_t)g * Cm + j];
+    hid[j] = a.act1 ? se_hswish(h) : h;
+  }
   __syncthreads();
   const int cb = blockIdx.x * 64;
   {
@@ -225,17 +237,20 @@ __global__ __launch_bounds__(256) void se_scale_kernel(SeFwdArgs a) {
       const float h = hid[j];
       float wv[16];
 #pragma unroll
-      for (int q = 0; q < 16; ++q) wv[q] = c0 + q < C ? a.w2[(int64_t)(c0 + q) * Cm + j] : 0.f;
+      for (int q = 0; q < 16; ++q) wv[q] = c0 + q < Co ? a.w2[(int64_t)(c0 + q) * Cm + j] : 0.f;
 #pragma unroll
       for (int q = 0; q < 16; ++q) sacc[q] += wv[q] * h;
     }
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-      float v = wave_sum(sacc[q]) + ((a.b2 && c0 + q < C) ? a.b2[c0 + q] : 0.f);
-      v = fminf(fmaxf(v * (1.f / 6.f) + 0.5f, 0.f), 1.f);
+      float v = wave_sum(sacc[q]) + ((a.b2 && c0 + q < Co) ? a.b2[c0 + q] : 0.f);
+      if (a.act2 == 0) v = fminf(fmaxf(v * (1.f / 6.f) + 0.5f, 0.f), 1.f);
       if (lane == 0) {
         scl[wave * 16 + q] = v;
-        if (c0 + q < C) a.scale[(int64_t)g * C + c0 + q] = v;
+        if (c0 + q < Co) {
+          a.scale[(int64_t)g * Co + c0 + q] = v;
+          if (a.scale_bf16) a.scale_bf16[(int64_t)g * Co + c0 + q] = (bf16_t)v;
+        }
       }
     }
   }
@@ -281,6 +296,8 @@ struct SeBwdArgs {
   float* work;            // out [G][C + Cm]: dpre2 | dh (read by the weight-gradient kernel)
   int G, C, Cm;
   int assoc;
+  int Co, act1, act2;     // as in SeFwdArgs (dpart / scale / the first Co entries of a `work` row have Co columns)
+  bf16_t* g_shift_bf16;   // optional bf16 copy of g_shift (the head's pooled-input gradient row)
 };
 
 constexpr int SEB_T = 1024, SEB_W = SEB_T / 64;
@@ -290,14 +307,17 @@ constexpr int SEB_T = 1024, SEB_W = SEB_T / 64;
 __global__ __launch_bounds__(SEB_T) void se_bwd_dh_kernel(SeBwdArgs a) {
   extern __shared__ float sm[];                 // dpre2[C] | partials [16][64]
   const int g = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int C = a.C, Cm = a.Cm;
+  const int C = a.Co, Cm = a.Cm;                // (this kernel only sees the second FC: its Co outputs)
   float* dpre2 = sm;
   float* red = sm + C;
   slot_sum_to_lds(a.dpart, a.slots, a.G, g, C, dpre2, SEB_T, a.assoc);
   __syncthreads();
   for (int c = tid; c < C; c += SEB_T) {
-    const float sc = a.scale[(int64_t)g * C + c];
-    const float d = (sc > 0.f && sc < 1.f) ? dpre2[c] * (1.f / 6.f) : 0.f;
+    float d = dpre2[c];
+    if (a.act2 == 0) {
+      const float sc = a.scale[(int64_t)g * C + c];
+      d = (sc > 0.f && sc < 1.f) ? d * (1.f / 6.f) : 0.f;
+    }
     dpre2[c] = d;
     if (blockIdx.x == 0) a.work[(int64_t)g * (C + Cm) + c] = d;
   }
@@ -326,7 +346,9 @@ __global__ __launch_bounds__(SEB_T) void se_bwd_dh_kernel(SeBwdArgs a) {
     float s = 0.f;
 #pragma unroll
     for (int w = 0; w < SEB_W; ++w) s += red[w * 64 + lane];
-    if (!(a.hidden[(int64_t)g * Cm + j] > 0.f)) s = 0.f;
+    const float h = a.hidden[(int64_t)g * Cm + j];
+    if (a.act1) s *= h <= -3.f ? 0.f : (h >= 3.f ? 1.f : (2.f * h + 3.f) * (1.f / 6.f));      // hardswish'(pre-activation)
+    else if (!(h > 0.f)) s = 0.f;
     a.work[(int64_t)g * (C + Cm) + C + j] = s;
   }
 }
@@ -338,7 +360,7 @@ __global__ __launch_bounds__(SEB_T) void se_bwd_gshift_kernel(SeBwdArgs a) {
   const int C = a.C, Cm = a.Cm;
   float* dh = sm;
   float* red = sm + Cm;
-  for (int j = tid; j < Cm; j += SEB_T) dh[j] = a.work[(int64_t)g * (C + Cm) + C + j];
+  for (int j = tid; j < Cm; j += SEB_T) dh[j] = a.work[(int64_t)g * (a.Co + Cm) + a.Co + j];
   __syncthreads();
   const int c = blockIdx.x * 64 + lane;
   const int jq = (Cm + SEB_W - 1) / SEB_W, j0 = wave * jq, j1 = min(Cm, j0 + jq);
@@ -362,6 +384,7 @@ __global__ __launch_bounds__(SEB_T) void se_bwd_gshift_kernel(SeBwdArgs a) {
 #pragma unroll
     for (int w = 0; w < SEB_W; ++w) t += red[w * 64 + lane];
     a.g_shift[(int64_t)g * C + c] = t * a.inv_count;
+    if (a.g_shift_bf16) a.g_shift_bf16[(int64_t)g * C + c] = (bf16_t)(t * a.inv_count);
   }
 }
 
@@ -405,7 +428,7 @@ extern "C" int pb_se_fc_bwd(const float* dscale, const float* pool, float inv_co
                      C, Cm);
   const int64_t total = 2LL * C * Cm + C + Cm;
   hipLaunchKernelGGL(se_fc_bwd_w_kernel, dim3((unsigned)pb_cdiv(total, 256)), dim3(256), 0, st, work, pool,
-                     inv_count, hidden, dw1, db1, dw2, db2, G, C, Cm);
+                     inv_count, hidden, dw1, db1, dw2, db2, G, C, Cm, C, 0);
   PB_LAUNCH_CHECK();
   return 0;
 }
@@ -424,7 +447,7 @@ extern "C" int pb_se_fused_fwd(const float* pool_part, int slots, float inv_coun
                "pb_se_fused_fwd: scaled weights need C %% 8 == 0 and 16-byte aligned pointers");
   PB_ENTER(device);
   hipStream_t st = (hipStream_t)stream;
-  SeFwdArgs a = {pool_part, slots, inv_count, w1, b1, w2, b2, pool, scale, hidden, wproj, (bf16_t*)wbs_bf16, G, C, Cm, N, se_assoc()};
+  SeFwdArgs a = {pool_part, slots, inv_count, w1, b1, w2, b2, pool, scale, hidden, wproj, (bf16_t*)wbs_bf16, G, C, Cm, N, se_assoc(), C, 0, 0, nullptr};
   hipLaunchKernelGGL(se_hidden_kernel, dim3((unsigned)pb_cdiv(Cm, SE_JB), (unsigned)G), dim3(SE_HT), (size_t)C * 4, st, a);
   hipLaunchKernelGGL(se_scale_kernel, dim3((unsigned)pb_cdiv(C, 64), (unsigned)G), dim3(256), ((size_t)Cm + 64) * 4, st, a);
   PB_LAUNCH_CHECK();
@@ -441,13 +464,13 @@ extern "C" int pb_se_fused_bwd(const float* dscale_part, int slots, const float*
   PB_CHECK_ARG(G > 0 && G <= 65535 && C > 0 && Cm > 0 && C <= 8192 && Cm <= 8192, "pb_se_fused_bwd: bad sizes G=%d C=%d Cm=%d", G, C, Cm);
   PB_ENTER(device);
   hipStream_t st = (hipStream_t)stream;
-  SeBwdArgs a = {dscale_part, slots, inv_count, scale, hidden, w1, w2, g_shift, work, G, C, Cm, se_assoc()};
+  SeBwdArgs a = {dscale_part, slots, inv_count, scale, hidden, w1, w2, g_shift, work, G, C, Cm, se_assoc(), C, 0, 0, nullptr};
   hipLaunchKernelGGL(se_bwd_dh_kernel, dim3((unsigned)pb_cdiv(Cm, 64), (unsigned)G), dim3(SEB_T), ((size_t)C + SEB_T) * 4, st, a);
   hipLaunchKernelGGL(se_bwd_gshift_kernel, dim3((unsigned)pb_cdiv(C, 64), (unsigned)G), dim3(SEB_T), ((size_t)Cm + SEB_T) * 4, st, a);
   if (dw1) {      // (dw1 == dw2 == NULL: the weight gradients are left to pb_se_fc_bwd_w - off the data-gradient chain)
     const int64_t total = 2LL * C * Cm + C + Cm;
     hipLaunchKernelGGL(se_fc_bwd_w_kernel, dim3((unsigned)pb_cdiv(total, 256)), dim3(256), 0, st, (const float*)work, pool,
-                       inv_count, hidden, dw1, db1, dw2, db2, G, C, Cm);
+                       inv_count, hidden, dw1, db1, dw2, db2, G, C, Cm, C, 0);
   }
   PB_LAUNCH_CHECK();
   return 0;
@@ -462,7 +485,58 @@ extern "C" int pb_se_fc_bwd_w(const float* work, const float* pool, float inv_co
   PB_ENTER(device);
   const int64_t total = 2LL * C * Cm + C + Cm;
   hipLaunchKernelGGL(se_fc_bwd_w_kernel, dim3((unsigned)pb_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, work, pool,
-                     inv_count, hidden, dw1, db1, dw2, db2, G, C, Cm);
+                     inv_count, hidden, dw1, db1, dw2, db2, G, C, Cm, C, 0);
+  PB_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------- the pooled classifier head
+// AdaptiveAvgPool3d(1) -> Conv3d(C, Cm, 1) -> Hardswish / ReLU -> Conv3d(Cm, Co, 1) (mobilenet.py classifier) is the squeeze-
+// excite gate's machine with other activations and Co != C: the same kernels (fp32 weights, fixed-order sums), 3 launches
+// forward and 2 + 1 backward where the generic path ran 8 and ~15 launches of ~5 us on [32 x 1280] tensors.
+extern "C" int pb_pool_head_fwd(const float* pool_part, int slots, float inv_count, const float* w1, const float* b1, const float* w2,
+                                const float* b2, pb_act act1, float* pool, float* logits, void* logits_bf16, float* pre1, int G, int C,
+                                int Cm, int Co, int device, void* stream) {
+  PB_CHECK_ARG(pool_part && w1 && w2 && pool && logits && pre1 && slots >= 1, "pb_pool_head_fwd: null pointer / bad slots");
+  PB_CHECK_ARG(act1 == PB_ACT_HSWISH || act1 == PB_ACT_RELU, "pb_pool_head_fwd: the hidden activation must be hardswish or ReLU");
+  PB_CHECK_ARG(G > 0 && G <= 65535 && C > 0 && Cm > 0 && Co > 0 && C <= 8192 && Cm <= 8192 && Co <= 8192, "pb_pool_head_fwd: bad sizes G=%d C=%d Cm=%d Co=%d", G, C, Cm, Co);
+  PB_ENTER(device);
+  hipStream_t st = (hipStream_t)stream;
+  SeFwdArgs a = {pool_part, slots, inv_count, w1, b1, w2, b2, pool, logits, pre1, nullptr, nullptr, G, C, Cm, 0, se_assoc(), Co,
+                 act1 == PB_ACT_HSWISH ? 1 : 0, 1, (bf16_t*)logits_bf16};
+  hipLaunchKernelGGL(se_hidden_kernel, dim3((unsigned)pb_cdiv(Cm, SE_JB), (unsigned)G), dim3(SE_HT), (size_t)C * 4, st, a);
+  hipLaunchKernelGGL(se_scale_kernel, dim3((unsigned)pb_cdiv(Co, 64), (unsigned)G), dim3(256), ((size_t)Cm + 64) * 4, st, a);
+  PB_LAUNCH_CHECK();
+  return 0;
+}
+
+// dlogits fp32 [G][Co] -> dpool_row [G][C] (= the gradient of EVERY pooled row: dlogits through both FCs, times inv_count) and
+// `work` [G][Co + Cm] (dlogits | dpre1) for pb_pool_head_bwd_w.
+extern "C" int pb_pool_head_bwd(const float* dlogits, float inv_count, const float* pre1, const float* w1, const float* w2, pb_act act1,
+                                float* dpool_row, void* dpool_row_bf16, float* work, int G, int C, int Cm, int Co, int device,
+                                void* stream) {
+  PB_CHECK_ARG(dlogits && pre1 && w1 && w2 && dpool_row && work, "pb_pool_head_bwd: null pointer");
+  PB_CHECK_ARG(act1 == PB_ACT_HSWISH || act1 == PB_ACT_RELU, "pb_pool_head_bwd: the hidden activation must be hardswish or ReLU");
+  PB_CHECK_ARG(G > 0 && G <= 65535 && C > 0 && Cm > 0 && Co > 0 && C <= 8192 && Cm <= 8192 && Co <= 8192, "pb_pool_head_bwd: bad sizes G=%d C=%d Cm=%d Co=%d", G, C, Cm, Co);
+  PB_ENTER(device);
+  hipStream_t st = (hipStream_t)stream;
+  SeBwdArgs a = {dlogits, 1, inv_count, nullptr, pre1, w1, w2, dpool_row, work, G, C, Cm, se_assoc(), Co, act1 == PB_ACT_HSWISH ? 1 : 0, 1,
+                 (bf16_t*)dpool_row_bf16};
+  hipLaunchKernelGGL(se_bwd_dh_kernel, dim3((unsigned)pb_cdiv(Cm, 64), (unsigned)G), dim3(SEB_T), ((size_t)Co + SEB_T) * 4, st, a);
+  hipLaunchKernelGGL(se_bwd_gshift_kernel, dim3((unsigned)pb_cdiv(C, 64), (unsigned)G), dim3(SEB_T), ((size_t)Cm + SEB_T) * 4, st, a);
+  PB_LAUNCH_CHECK();
+  return 0;
+}
+
+// dw1 [Cm][C], db1 [Cm], dw2 [Co][Cm], db2 [Co] += ... from `work` (off the data-gradient chain, like pb_se_fc_bwd_w)
+extern "C" int pb_pool_head_bwd_w(const float* work, const float* pool, float inv_count, const float* pre1, pb_act act1, float* dw1,
+                                  float* db1, float* dw2, float* db2, int G, int C, int Cm, int Co, int device, void* stream) {
+  PB_CHECK_ARG(work && pool && pre1 && dw1 && dw2, "pb_pool_head_bwd_w: null pointer");
+  PB_CHECK_ARG(G > 0 && G <= 65535 && C > 0 && Cm > 0 && Co > 0 && C <= 8192 && Cm <= 8192 && Co <= 8192, "pb_pool_head_bwd_w: bad sizes");
+  PB_ENTER(device);
+  const int64_t total = (int64_t)Co * Cm + (int64_t)C * Cm + Co + Cm;
+  hipLaunchKernelGGL(se_fc_bwd_w_kernel, dim3((unsigned)pb_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, work, pool,
+                     inv_count, pre1, dw1, db1, dw2, db2, G, C, Cm, Co, act1 == PB_ACT_HSWISH ? 1 : 0);
   PB_LAUNCH_CHECK();
   return 0;
 }

@@ -533,6 +533,55 @@ def pool_mean(x5):
     return _PoolMean.apply(_contig5(x5))
 
 
+class _PooledHead(torch.autograd.Function):
+    """AdaptiveAvgPool3d(1) -> Conv3d(C, Cm, 1) -> Hardswish / ReLU -> Conv3d(Cm, Co, 1) (mobilenet.py `classifier`) on the
+    squeeze-excite gate's kernels (K.pool_head_*: fp32 weights and sums): 3 launches forward, 2 (+ one cast of the incoming
+    gradient) on the data-gradient chain backward, the weight gradients in the block's branch - the generic path (pool_mean +
+    two pw_bn_act) ran 8 and ~15 launches of ~5 us each on [N x 1280] tensors.  Backward returns the expand()ed row view of
+    _PoolMean (no [N,T,H,W,C] gradient is written)."""
+
+    @staticmethod
+    def forward(ctx, x5, w1, b1, w2, b2, act):
+        N, C = x5.shape[0], x5.shape[-1]
+        x2 = x5.view(-1, C)
+        R = x2.shape[0] // N
+        Cm, Co = w1.shape[0], w2.shape[0]
+        part = K.rowgroup_partials(x2, None, N)
+        pool, pre1, logits = K.pool_head_fwd(part, 1.0 / R, w1.view(Cm, C), b1, w2.view(Co, Cm), b2, act, x5.dtype)
+        ctx.save_for_backward(pool, pre1, w1, b1, w2, b2)
+        ctx.meta = (x5.shape, R, act, x5.dtype)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        pool, pre1, w1, b1, w2, b2 = ctx.saved_tensors
+        shape, R, act, dt = ctx.meta
+        N, C = pool.shape
+        Cm, Co = w1.shape[0], w2.shape[0]
+        dl = dlogits.float().contiguous()                  # [N, Co]: host-side glue
+        row, work = K.pool_head_bwd(dl, 1.0 / R, pre1, w1.view(Cm, C), w2.view(Co, Cm), act, dt)
+        dw1, db1, dw2, db2 = _zeros_many(pool, (Cm, C), (Cm,), (Co, Cm), (Co,))
+        K.weight_grad_branch(row, (w1, b1, w2, b2),
+                             [lambda: K.pool_head_bwd_w(work, pool, 1.0 / R, pre1, act, dw1, db1, dw2, db2)],
+                             (work, pool, pre1, dw1, db1, dw2, db2), "head")
+        # (fresh views: autograd adopts a gradient tensor only when nobody else holds the OBJECT - the branch keeps them)
+        return (row.view(N, 1, 1, 1, C).expand(shape), dw1.view_as(w1), db1.view_as(b1) if b1 is not None else None,
+                dw2.view_as(w2), db2.view_as(b2) if b2 is not None else None, None)
+
+
+def pooled_head_ok(x5, fc1, fc2, act):
+    """the fused head takes: hardswish / ReLU between two 1x1x1 convs with fp32 weights, bf16 or fp32 activations"""
+    return (act in ("hardswish", "relu") and x5.dtype in (torch.bfloat16, torch.float32) and fc1.weight.dtype == torch.float32
+            and fc2.weight.dtype == torch.float32 and fc1.weight[0].numel() == x5.shape[-1] and fc2.weight[0].numel() == fc1.weight.shape[0]
+            and max(x5.shape[-1], fc1.weight.shape[0], fc2.weight.shape[0]) <= 8192 and hasattr(K, "pool_head_fwd")
+            and os.environ.get("PB_POOLED_HEAD", "1") != "0")
+
+
+def pooled_head(x5, fc1, fc2, act):
+    """logits [N, classes] of `pool -> fc1 -> act -> fc2` (fc1, fc2: nn.Conv3d / nn.Linear with 1x1x1 kernels)"""
+    return _PooledHead.apply(_contig5(x5), fc1.weight, fc1.bias, fc2.weight, fc2.bias, act)
+
+
 # =============================================================================== standalone SE block
 class _SEBlock(torch.autograd.Function):
     @staticmethod

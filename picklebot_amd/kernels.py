@@ -1203,6 +1203,53 @@ def se_fused_fwd(pool_part, inv_count, w1, b1, w2, b2, wproj=None, want_scaled=F
     return pool, scale, hidden, wbs
 
 
+def pool_head_fwd(pool_part, inv_count, w1, b1, w2, b2, act, out_dtype):
+    """The pooled classifier head on the squeeze-excite kernels: pool_part fp32 [slots,G,C] -> (pool [G,C] sums, pre1 [G,Cm]
+    fp32: the hidden layer's PRE-activation for hardswish, its output for ReLU - what the backward kernels need, logits [G,Co]
+    in out_dtype); act = "hardswish" | "relu" between the two FCs."""
+    pool_part = _few_slots(pool_part)
+    slots, G, C = pool_part.shape
+    Cm, Co = w1.shape[0], w2.shape[0]
+    _f32(pool_part, name="pool_part"); _f32(w1, (Cm, C), "w1"); _f32(w2, (Co, Cm), "w2"); _f32(b1, (Cm,), "b1"); _f32(b2, (Co,), "b2")
+    dev_t = pool_part.device
+    pool = torch.empty((G, C), dtype=torch.float32, device=dev_t)
+    pre1 = torch.empty((G, Cm), dtype=torch.float32, device=dev_t)
+    logits = torch.empty((G, Co), dtype=torch.float32, device=dev_t)
+    lb = torch.empty((G, Co), dtype=torch.bfloat16, device=dev_t) if out_dtype == torch.bfloat16 else None
+    dev, st = _dev_stream(pool_part)
+    _launch("se_fused_fwd", _nb(pool_part, w1, w2, logits), "pb_pool_head_fwd", _p(pool_part), slots, float(inv_count), _p(w1), _p(b1), _p(w2),
+            _p(b2), ACT[act], _p(pool), _p(logits), _p(lb), _p(pre1), G, C, Cm, Co, dev, st)
+    return pool, pre1, (lb if lb is not None else logits)
+
+
+def pool_head_bwd(dlogits, inv_count, pre1, w1, w2, act, row_dtype):
+    """dlogits fp32 [G,Co] -> (dpool_row [G,C] in row_dtype: the gradient of every pooled row of clip g, work [G,Co+Cm] for
+    pool_head_bwd_w)."""
+    G, Co = dlogits.shape
+    Cm, C = w1.shape
+    _f32(dlogits, (G, Co), "dlogits"); _f32(pre1, (G, Cm), "pre1"); _f32(w1, (Cm, C), "w1"); _f32(w2, (Co, Cm), "w2")
+    dev_t = dlogits.device
+    row = torch.empty((G, C), dtype=torch.float32, device=dev_t)
+    rb = torch.empty((G, C), dtype=torch.bfloat16, device=dev_t) if row_dtype == torch.bfloat16 else None
+    work = torch.empty((G, Co + Cm), dtype=torch.float32, device=dev_t)
+    dev, st = _dev_stream(dlogits)
+    _launch("se_fused_bwd", _nb(dlogits, w1, w2, row), "pb_pool_head_bwd", _p(dlogits), float(inv_count), _p(pre1), _p(w1), _p(w2), ACT[act],
+            _p(row), _p(rb), _p(work), G, C, Cm, Co, dev, st)
+    return (rb if rb is not None else row), work
+
+
+def pool_head_bwd_w(work, pool, inv_count, pre1, act, dw1, db1, dw2, db2):
+    """dw1 [Cm,C], db1, dw2 [Co,Cm], db2 += the head's weight / bias gradients (off the data-gradient chain)."""
+    G, C = pool.shape
+    Cm = pre1.shape[1]
+    Co = work.shape[1] - Cm
+    _f32(work, (G, Co + Cm), "work"); _f32(pool, (G, C), "pool"); _f32(pre1, (G, Cm), "pre1")
+    _f32(dw1, (Cm, C), "dw1"); _f32(dw2, (Co, Cm), "dw2"); _f32(db1, (Cm,), "db1"); _f32(db2, (Co,), "db2")
+    dev, st = _dev_stream(work)
+    _launch("se_fc_bwd_w", _nb(dw1, dw2), "pb_pool_head_bwd_w", _p(work), _p(pool), float(inv_count), _p(pre1), ACT[act], _p(dw1), _p(db1), _p(dw2),
+            _p(db2), G, C, Cm, Co, dev, st)
+
+
 def rowgroup_partials(a, b, G):
     """Per-workgroup partial sums [slots,G,C] of rowgroup_reduce (for se_fused_bwd, which adds the slots itself)."""
     _rows(a, "a")

@@ -212,9 +212,11 @@ class _MobileNet3D(nn.Module):
         se = se_params(tail[1]) if len(tail) == 4 else None
         act, slope = act_of(act_m)
         y5 = PF.pw_bn_act(to_ndhwc(y), conv.weight, conv.bias, bn, act=act, slope=slope, training=bn.training, se=se)
-        pooled = PF.pool_mean(y5)
         fc1, act_m, fc2 = self.classifier[1], self.classifier[2], self.classifier[3]
         act, slope = act_of(act_m)
+        if PF.pooled_head_ok(y5, fc1, fc2, act):
+            return PF.pooled_head(y5, fc1, fc2, act).view(x.shape[0], self.num_classes)
+        pooled = PF.pool_mean(y5)
         h = PF.pw_bn_act(pooled, fc1.weight, fc1.bias, None, act=act, slope=slope, training=self.training)
         logits = PF.pw_bn_act(h, fc2.weight, fc2.bias, None, act="none", slope=0.0, training=self.training)
         return logits.view(x.shape[0], self.num_classes)

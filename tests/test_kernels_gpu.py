@@ -831,3 +831,35 @@ def test_norm_act_frame_map(K, G, full, data, lead, C, dtype):
     assert tuple(g.shape) == (G * data, C)
     check("act_bwd_fm_g", g, g_ref, dtype)
     check("act_bwd_fm_sums", s.sum(0), s_ref.sum(0), dtype, tol_scale=3.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("G,rows,C,Cm,Co,act", [(32, 49, 960, 1280, 13, "hardswish"), (5, 30, 576, 1024, 2, "hardswish"),
+                                                (3, 17, 40, 24, 7, "relu")])
+def test_pooled_head_kernels(K, G, rows, C, Cm, Co, act, dtype):
+    """pool -> fc -> hardswish / ReLU -> fc (the MobileNet classifiers) on the squeeze-excite kernels with Co != C: forward,
+    the data-gradient pair and the weight gradients against the mirror; bit-identical reruns."""
+    x = rnd((G * rows, C), dtype, 71)
+    w1, b1 = rnd((Cm, C), seed=72, scale=C ** -0.5), rnd((Cm,), seed=73) * 0.1
+    w2, b2 = rnd((Co, Cm), seed=74, scale=Cm ** -0.5), rnd((Co,), seed=75) * 0.1
+    pool_r, pre_r, lg_r = R.pool_head_fwd(R.rowgroup_partials(x, None, G), 1.0 / rows, w1, b1, w2, b2, act, dtype)
+    part = K.rowgroup_partials(dev(x), None, G)
+    pool, pre, lg = K.pool_head_fwd(part, 1.0 / rows, dev(w1), dev(b1), dev(w2), dev(b2), act, dtype)
+    assert lg.dtype == dtype
+    check("head_pool", pool, pool_r, torch.float32)
+    check("head_pre1", pre, pre_r if act == "hardswish" else torch.relu(pre_r), torch.float32)     # (ReLU: its output is kept)
+    check("head_logits", lg, lg_r, dtype)
+    pool2, pre2, lg2 = K.pool_head_fwd(part, 1.0 / rows, dev(w1), dev(b1), dev(w2), dev(b2), act, dtype)
+    assert torch.equal(pre, pre2) and torch.equal(lg, lg2)
+    dl = rnd((G, Co), seed=76)
+    row_r, work_r = R.pool_head_bwd(dl, 1.0 / rows, pre_r, w1, w2, act, dtype)
+    row, work = K.pool_head_bwd(dev(dl), 1.0 / rows, pre, dev(w1), dev(w2), act, dtype)
+    assert row.dtype == dtype
+    check("head_row", row, row_r, dtype)
+    check("head_work", work, work_r, torch.float32)
+    gr = [torch.zeros(Cm, C), torch.zeros(Cm), torch.zeros(Co, Cm), torch.zeros(Co)]
+    R.pool_head_bwd_w(work_r, pool_r, 1.0 / rows, pre_r, act, *gr)
+    gg = [dev(torch.zeros_like(t)) for t in gr]
+    K.pool_head_bwd_w(work, pool, 1.0 / rows, pre, act, *gg)
+    for n, a_, b_ in zip(("dw1", "db1", "dw2", "db2"), gg, gr):
+        check("head_" + n, a_, b_, torch.float32)
