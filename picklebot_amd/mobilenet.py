@@ -85,19 +85,17 @@ class _MaskPool:
             gen = getattr(PF.K, "_wgen", 0)
             ent = self._cap.get((device, p))
             if ent is None or ent[0] != gen or ent[2] + numel > self.CAPTURE_SIZE:
-                keep = torch.full((self.CAPTURE_SIZE,), 1.0 - p, dtype=torch.float32, device=device)
-                ent = [gen, torch.bernoulli(keep).mul_(1.0 / (1.0 - p)), 0]
+                # (bernoulli_(float): one launch - torch.full + torch.bernoulli(tensor) were two)
+                ent = [gen, torch.empty((self.CAPTURE_SIZE,), dtype=torch.float32, device=device).bernoulli_(1.0 - p).mul_(1.0 / (1.0 - p)), 0]
                 self._cap[(device, p)] = ent
             off = ent[2]
             ent[2] = off + (numel + 3) // 4 * 4
             return ent[1][off:off + numel]
         if numel > self.SIZE // 4 or capturing:
-            keep = torch.full((numel,), 1.0 - p, dtype=torch.float32, device=device)
-            return torch.bernoulli(keep) * (1.0 / (1.0 - p))
+            return torch.empty((numel,), dtype=torch.float32, device=device).bernoulli_(1.0 - p).mul_(1.0 / (1.0 - p))
         ent = self._pools.get((device, p))
         if ent is None or ent[1] + numel > self.SIZE:
-            keep = torch.full((self.SIZE,), 1.0 - p, dtype=torch.float32, device=device)
-            ent = [torch.bernoulli(keep).mul_(1.0 / (1.0 - p)), 0]
+            ent = [torch.empty((self.SIZE,), dtype=torch.float32, device=device).bernoulli_(1.0 - p).mul_(1.0 / (1.0 - p)), 0]
             self._pools[(device, p)] = ent
         off = ent[1]
         ent[1] = off + (numel + 3) // 4 * 4          # keep every mask 16-byte aligned
